@@ -1,0 +1,7 @@
+"""MI355X-native ELIC_united encode/decode hot path.
+
+The directory name is not a Python identifier; import it through the `rgbd_amd` alias package at the
+repository root (`import rgbd_amd`), which resolves to this package.
+"""
+from . import arch, synth  # noqa: F401
+from .arch import Config, model_config  # noqa: F401

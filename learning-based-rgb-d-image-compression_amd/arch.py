@@ -1,0 +1,266 @@
+"""Parameter inventory of the ELIC_united hot path.
+
+The reference checkpoint format is the interface: this module enumerates every
+state_dict entry of `ELIC_united` (reference: models/elic_united.py:14-86) by name, shape and role, so
+that (a) checkpoints written by the reference load here, (b) synthetic weights can be produced for any
+entry, and (c) the device-side weight packer knows what each tensor is.
+
+Nothing here is executable network code; it is a table.
+"""
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+# config/config.py:5-10 of the reference
+DEFAULT_CONFIG = {
+    "N": 192,
+    "M": 320,
+    "slice_num": 5,
+    "context_window": 5,
+    "slice_ch": [16, 16, 32, 64, 192],
+    "quant": "ste",
+}
+
+
+class Config(dict):
+    """Attribute dict with the same access pattern as the reference's utils/IOutils.py:14-23."""
+
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def model_config() -> Config:
+    return Config({k: (list(v) if isinstance(v, list) else v) for k, v in DEFAULT_CONFIG.items()})
+
+
+@dataclass(frozen=True)
+class Entry:
+    shape: Tuple[int, ...]
+    kind: str  # conv_w | deconv_w | bias | linear_w | eb_matrix | eb_bias | eb_factor | eb_quantiles | buffer
+    dtype: str = "float32"
+    fan_in: int = 0
+    is_param: bool = True
+
+
+class _Builder:
+    def __init__(self):
+        self.entries: "OrderedDict[str, Entry]" = OrderedDict()
+
+    def conv(self, name: str, cin: int, cout: int, k: int):
+        self.entries[f"{name}.weight"] = Entry((cout, cin, k, k), "conv_w", fan_in=cin * k * k)
+        self.entries[f"{name}.bias"] = Entry((cout,), "bias", fan_in=cin * k * k)
+
+    def deconv(self, name: str, cin: int, cout: int, k: int):
+        # ConvTranspose2d weight is (Cin, Cout, kH, kW); torch's fan_in for it is size(1)*k*k
+        self.entries[f"{name}.weight"] = Entry((cin, cout, k, k), "deconv_w", fan_in=cout * k * k)
+        self.entries[f"{name}.bias"] = Entry((cout,), "bias", fan_in=cout * k * k)
+
+    def linear_nobias(self, name: str, cin: int, cout: int):
+        self.entries[f"{name}.weight"] = Entry((cout, cin), "linear_w", fan_in=cin)
+
+    # modules/layers/res_blk.py:7-27
+    def bottleneck(self, name: str, n: int, out: Optional[int] = None):
+        out = n if out is None else out
+        self.conv(f"{name}.branch.0", n, n // 2, 1)
+        self.conv(f"{name}.branch.2", n // 2, n // 2, 3)
+        self.conv(f"{name}.branch.4", n // 2, out, 1)
+        if out != n:
+            self.conv(f"{name}.skip", n, out, 1)
+
+    # CompressAI/compressai/layers/layers.py:162-213
+    def attention(self, name: str, n: int):
+        for br in ("conv_a", "conv_b"):
+            for u in range(3):
+                self.conv(f"{name}.{br}.{u}.conv.0", n, n // 2, 1)
+                self.conv(f"{name}.{br}.{u}.conv.2", n // 2, n // 2, 3)
+                self.conv(f"{name}.{br}.{u}.conv.4", n // 2, n, 1)
+        self.conv(f"{name}.conv_b.3", n, n, 1)
+
+    # modules/transform/attention.py:70-83
+    def esa(self, name: str, n: int):
+        f = n // 4
+        self.conv(f"{name}.conv1", n, f, 1)
+        self.conv(f"{name}.conv_f", f, f, 1)
+        self.conv(f"{name}.conv_max", f, f, 3)
+        self.conv(f"{name}.conv2", f, f, 3)
+        self.conv(f"{name}.conv3", f, f, 3)
+        self.conv(f"{name}.conv3_", f, f, 3)
+        self.conv(f"{name}.conv4", f, n, 1)
+
+    # modules/transform/attention.py:14-48
+    def bi_spf(self, name: str, n: int):
+        self.conv(f"{name}.r_ext", n, n // 2, 3)
+        self.conv(f"{name}.d_ext", n, n // 2, 3)
+        self.esa(f"{name}.d_esa", n)
+        self.esa(f"{name}.r_esa", n)
+
+    # modules/transform/attention.py:52-61
+    def se(self, name: str, c: int, reduction: int = 16):
+        self.linear_nobias(f"{name}.fc.0", c, c // reduction)
+        self.linear_nobias(f"{name}.fc.2", c // reduction, c)
+
+    # modules/transform/entropy.py:56-67
+    def entropy_params(self, name: str, in_dim: int, out_dim: int):
+        self.conv(f"{name}.fusion.0", in_dim, in_dim // 6, 1)
+        self.conv(f"{name}.fusion.2", in_dim // 6, out_dim * 4 // 3, 3)
+        self.conv(f"{name}.fusion.4", out_dim * 4 // 3, out_dim, 5)
+        self.se(f"{name}.se", in_dim)
+
+    # modules/transform/context.py:10-19 (attribute really is spelled "fushion")
+    def channel_context(self, name: str, in_dim: int, out_dim: int):
+        self.conv(f"{name}.fushion.0", in_dim, 224, 5)
+        self.conv(f"{name}.fushion.2", 224, 128, 5)
+        self.conv(f"{name}.fushion.4", 128, out_dim, 5)
+
+    # CompressAI/compressai/entropy_models/entropy_models.py:282-314
+    def entropy_bottleneck(self, name: str, channels: int, filters=(3, 3, 3, 3)):
+        f = (1,) + tuple(filters) + (1,)
+        for i in range(len(filters) + 1):
+            self.entries[f"{name}._matrix{i}"] = Entry((channels, f[i + 1], f[i]), "eb_matrix")
+            self.entries[f"{name}._bias{i}"] = Entry((channels, f[i + 1], 1), "eb_bias")
+            if i < len(filters):
+                self.entries[f"{name}._factor{i}"] = Entry((channels, f[i + 1], 1), "eb_factor")
+        self.entries[f"{name}.quantiles"] = Entry((channels, 1, 3), "eb_quantiles")
+        self.buffer(f"{name}._offset", (0,), "int32")
+        self.buffer(f"{name}._quantized_cdf", (0,), "int32")
+        self.buffer(f"{name}._cdf_length", (0,), "int32")
+        self.buffer(f"{name}.target", (3,))
+        self.buffer(f"{name}.likelihood_lower_bound.bound", (1,))
+
+    # entropy_models.py:462-485
+    def gaussian_conditional(self, name: str):
+        self.buffer(f"{name}._offset", (0,), "int32")
+        self.buffer(f"{name}._quantized_cdf", (0,), "int32")
+        self.buffer(f"{name}._cdf_length", (0,), "int32")
+        self.buffer(f"{name}.scale_table", (0,))
+        self.buffer(f"{name}.scale_bound", (1,))
+        self.buffer(f"{name}.likelihood_lower_bound.bound", (1,))
+        self.buffer(f"{name}.lower_bound_scale.bound", (1,))
+
+    def buffer(self, name: str, shape, dtype: str = "float32"):
+        self.entries[name] = Entry(tuple(shape), "buffer", dtype=dtype, is_param=False)
+
+
+def slice_offsets(slice_ch: List[int]) -> List[int]:
+    out, acc = [], 0
+    for c in slice_ch:
+        out.append(acc)
+        acc += c
+    return out
+
+
+def entropy_param_in_dims(M: int, slice_ch: List[int], i: int) -> Dict[str, int]:
+    """Input widths of the four EntropyParametersEX nets of slice i (models/elic_united.py:53-78)."""
+    c = slice_ch[i]
+    base = 4 * M
+    if i == 0:
+        return {"rgb_anchor": base, "depth_anchor": base + 2 * c, "rgb_nonanchor": base + 4 * c,
+                "depth_nonanchor": base + 4 * c}
+    return {"rgb_anchor": base + 4 * c, "depth_anchor": base + 6 * c, "rgb_nonanchor": base + 8 * c,
+            "depth_nonanchor": base + 8 * c}
+
+
+def elic_united_entries(config=None) -> "OrderedDict[str, Entry]":
+    """Every state_dict entry of ELIC_united, in a stable order."""
+    cfg = model_config() if config is None else config
+    N, M = int(cfg["N"]), int(cfg["M"])
+    slice_ch = list(cfg["slice_ch"])
+    b = _Builder()
+
+    # g_a: modules/transform/analysis.py:116-159
+    for mod, cin in (("rgb", 3), ("depth", 1)):
+        p = f"g_a.{mod}_analysis_transform"
+        b.conv(f"{p}.0", cin, N, 5)
+        for j in (1, 2, 3):
+            b.bottleneck(f"{p}.{j}", N)
+        if mod == "rgb":
+            b.bi_spf(f"{p}.4", N)
+        b.conv(f"{p}.5", 2 * N, N, 5)
+        for j in (6, 7, 8):
+            b.bottleneck(f"{p}.{j}", N)
+        b.attention(f"{p}.9", N)
+        if mod == "rgb":
+            b.bi_spf(f"{p}.10", N)
+        b.conv(f"{p}.11", 2 * N, N, 5)
+        for j in (12, 13, 14):
+            b.bottleneck(f"{p}.{j}", N)
+        if mod == "rgb":
+            b.bi_spf(f"{p}.15", N)
+        b.conv(f"{p}.16", 2 * N, M, 5)
+        b.attention(f"{p}.17", M)
+
+    # g_s: modules/transform/synthesis.py:126-169
+    for mod, cout in (("rgb", 3), ("depth", 1)):
+        p = f"g_s.{mod}_synthesis_transform"
+        b.attention(f"{p}.0", M)
+        b.deconv(f"{p}.1", M, N, 5)
+        if mod == "rgb":
+            b.bi_spf(f"{p}.2", N)
+        b.bottleneck(f"{p}.3", 2 * N, N)
+        b.bottleneck(f"{p}.4", N)
+        b.bottleneck(f"{p}.5", N)
+        b.deconv(f"{p}.6", N, N, 5)
+        b.attention(f"{p}.7", N)
+        if mod == "rgb":
+            b.bi_spf(f"{p}.8", N)
+        b.bottleneck(f"{p}.9", 2 * N, N)
+        b.bottleneck(f"{p}.10", N)
+        b.bottleneck(f"{p}.11", N)
+        b.deconv(f"{p}.12", N, N, 5)
+        if mod == "rgb":
+            b.bi_spf(f"{p}.13", N)
+        b.bottleneck(f"{p}.14", 2 * N, N)
+        b.bottleneck(f"{p}.15", N)
+        b.bottleneck(f"{p}.16", N)
+        b.deconv(f"{p}.17", N, cout, 5)
+
+    # h_a: analysis.py:231-237
+    for mod in ("rgb", "depth"):
+        p = f"h_a.{mod}_reduction"
+        b.conv(f"{p}.0", M, N, 3)
+        b.conv(f"{p}.2", N, N, 5)
+        b.conv(f"{p}.4", N, N, 5)
+
+    # h_s: synthesis.py:305-314, 345-354
+    for m in ("r", "d"):
+        for idx, (cin, cout, k) in enumerate(((2 * N, M, 5), (2 * M, M * 3 // 2, 5), (3 * M, 2 * M, 3)), 1):
+            p = f"h_s.{m}_h_s{idx}"
+            b.se(f"{p}.se", cin)
+            b.deconv(f"{p}.deconv", cin, cout, k)
+
+    # Bi-CEE nets: models/elic_united.py:30-78
+    for fam in ("rgb_local_context", "rgb_local_context_anchor_with_nonanchor", "depth_local_context"):
+        for i, c in enumerate(slice_ch):
+            b.conv(f"{fam}.{i}", c, 2 * c, 5)
+    for fam in ("rgb_channel_context", "depth_channel_context"):
+        for i in range(1, len(slice_ch)):
+            b.channel_context(f"{fam}.{i}", sum(slice_ch[:i]), 2 * slice_ch[i])
+    for i, c in enumerate(slice_ch):
+        dims = entropy_param_in_dims(M, slice_ch, i)
+        b.entropy_params(f"rgb_entropy_parameters_anchor.{i}", dims["rgb_anchor"], 2 * c)
+    for i, c in enumerate(slice_ch):
+        dims = entropy_param_in_dims(M, slice_ch, i)
+        b.entropy_params(f"depth_entropy_parameters_anchor.{i}", dims["depth_anchor"], 2 * c)
+    for i, c in enumerate(slice_ch):
+        dims = entropy_param_in_dims(M, slice_ch, i)
+        b.entropy_params(f"rgb_entropy_parameters_nonanchor.{i}", dims["rgb_nonanchor"], 2 * c)
+    for i, c in enumerate(slice_ch):
+        dims = entropy_param_in_dims(M, slice_ch, i)
+        b.entropy_params(f"depth_entropy_parameters_nonanchor.{i}", dims["depth_nonanchor"], 2 * c)
+
+    b.entropy_bottleneck("rgb_entropy_bottleneck", N)
+    b.entropy_bottleneck("depth_entropy_bottleneck", N)
+    b.gaussian_conditional("rgb_gaussian_conditional")
+    b.gaussian_conditional("depth_gaussian_conditional")
+    return b.entries
+
+
+def count_parameters(entries) -> int:
+    n = 0
+    for e in entries.values():
+        if e.is_param:
+            k = 1
+            for s in e.shape:
+                k *= s
+            n += k
+    return n

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kat():
+    return dict(np.load(os.path.join(GOLDEN, "coder_kat.npz")))
+
+
+@pytest.fixture(scope="session")
+def gc_tables(kat):
+    from oracle import coder
+
+    return coder.Tables(kat["gc_cdf"], kat["gc_sizes"], kat["gc_offsets"])
+
+
+@pytest.fixture(scope="session")
+def synth_sd():
+    import rgbd_amd  # noqa: F401
+    from rgbd_amd import synth
+
+    return synth.synthetic_state_dict(0)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, f"model_{name}.npz")))

@@ -1,0 +1,102 @@
+"""The CPU restatement (oracle/elic_oracle.py) against what the unmodified reference produced in this container
+(tests/golden/model_*.npz, written by tests/golden/make_golden.py).
+
+Streams are compared bit-for-bit when this machine's torch CPU kernels reproduce the golden latents exactly (always
+true in the container that generated them); on another CPU the float stage may differ in the last bits, and then the
+float tensors are checked to 1e-5 relative and the integer stage is checked on the golden latents instead."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import elic_oracle as eo
+
+
+@pytest.fixture(scope="module")
+def codec(synth_sd):
+    c = eo.OracleCodec(synth_sd)
+    c.update()
+    return c
+
+
+def _inputs(g):
+    from rgbd_amd import synth
+
+    r, d = synth.synthetic_batch(int(g["B"]), int(g["H"]), int(g["W"]), config_id=int(g["config_id"]))
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    return r, d, eo.pad_replicate0(r), eo.pad_replicate0(d)
+
+
+def test_entropy_bottleneck_tables(codec, kat):
+    for m in ("rgb", "depth"):
+        assert np.array_equal(codec.eb[m].cdf, kat[f"{m}_eb_cdf"])
+        assert np.array_equal(codec.eb[m].sizes, kat[f"{m}_eb_sizes"])
+        assert np.array_equal(codec.eb[m].offsets, kat[f"{m}_eb_offsets"])
+
+
+def test_full_case_a(codec):
+    g = load_golden("a_128x192")
+    r, d, rp, dp = _inputs(g)
+    codec.trace = {}
+    out = codec.compress(rp, dp)
+    tr, codec.trace = codec.trace, None
+    for k in ("y_r", "y_d", "z_r", "z_d", "hyper_r", "hyper_d"):
+        np.testing.assert_allclose(tr[k].numpy(), g[k], rtol=1e-5, atol=1e-5)
+    exact = np.array_equal(tr["y_r"].numpy(), g["y_r"]) and np.array_equal(tr["hyper_r"].numpy(), g["hyper_r"])
+    if not exact:
+        pytest.skip("this CPU's conv kernels differ in the last bits from the golden machine; floats within 1e-5")
+    assert out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes()
+    assert out["r_strings"][1][0] == g["r_z0"].tobytes() and out["d_strings"][1][0] == g["d_z0"].tobytes()
+    assert tuple(out["shape"]) == tuple(g["shape"])
+    dec = codec.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert np.array_equal(dec["x_hat"]["r"].numpy(), g["xhat_r"]) and np.array_equal(dec["x_hat"]["d"].numpy(), g["xhat_d"])
+    assert abs(eo.psnr(dec["x_hat"]["r"], r) - g["psnr"][0]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["b_100x150", "c_b2_128x128", "d_256x256"])
+def test_streams_other_cases(codec, name):
+    g = load_golden(name)
+    r, d, rp, dp = _inputs(g)
+    assert tuple(rp.shape[-2:]) == tuple(g["padded"])
+    out = codec.compress(rp, dp)
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    same = out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes()
+    if not same:
+        assert abs(len(out["r_strings"][0][0]) - g["r_y"].shape[0]) <= 64  # float-stage flips only
+        pytest.skip("float stage differs in the last bits on this CPU")
+    for i in range(B):
+        assert out["r_strings"][1][i] == g[f"r_z{i}"].tobytes() and out["d_strings"][1][i] == g[f"d_z{i}"].tobytes()
+    dec = codec.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    xr, xd = dec["x_hat"]["r"][:, :, :H, :W], dec["x_hat"]["d"][:, :, :H, :W]
+    assert np.array_equal(xr[:, :, ::8, ::8].numpy(), g["xhat_r_sub"])
+    assert abs(eo.psnr(xr, r) - g["psnr"][0]) < 1e-4 and abs(eo.psnr(xd, d) - g["psnr"][1]) < 1e-4
+    if B == 1:
+        cr = eo.container_bytes(H, W, out["shape"], out["r_strings"])
+        cd = eo.container_bytes(H, W, out["shape"], out["d_strings"])
+        assert hashlib.sha256(cr).hexdigest()[:16] == g["r_container_sha"].tobytes().decode()
+        assert hashlib.sha256(cd).hexdigest()[:16] == g["d_container_sha"].tobytes().decode()
+        assert len(cr) * 8.0 / (H * W) == g["bpp"][0] and len(cd) * 8.0 / (H * W) == g["bpp"][1]
+
+
+def test_integer_stage_on_golden_latents(codec):
+    """Machine-independent: quantise/index/encode the GOLDEN latents -> the golden z streams."""
+    g = load_golden("a_128x192")
+    for m, k in (("rgb", "r"), ("depth", "d")):
+        strings, _ = codec._z_compress(m, torch.from_numpy(g[f"z_{k}"]))
+        assert strings[0] == g[f"{k}_z0"].tobytes()
+        zh = codec._z_decompress(m, strings, tuple(g["shape"]))
+        assert np.array_equal(zh.numpy(), g[f"zhat_{k}"])
+
+
+def test_pack_unpack_roundtrip():
+    x = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    for anchor in (True, False):
+        p = eo.pack(x, anchor)
+        assert p.shape == (2, 3, 4, 3)
+        u = eo.unpack(p, anchor)
+        assert torch.equal(u + eo.unpack(eo.pack(x, not anchor), not anchor), x)
+    # anchors = (even row, odd col) U (odd row, even col): utils/ckbd.py:37-41
+    assert eo.pack(x, True)[0, 0, 0].tolist() == [1.0, 3.0, 5.0]
+    assert eo.pack(x, True)[0, 0, 1].tolist() == [6.0, 8.0, 10.0]
