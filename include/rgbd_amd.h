@@ -1,0 +1,124 @@
+/*
+ * rgbd_amd.h -- C ABI of the MI355X-native ELIC_united encode/decode path.
+ *
+ * Shared library: learning-based-rgb-d-image-compression_amd/librgbd_amd.so (built by __graft_entry__.build()).
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative errno-style code
+ * (-22 invalid argument, -12 out of memory, -28 buffer too small, -5 HIP runtime error, -1 wrong call order);
+ * no exceptions cross the boundary; a handle may be used from one thread at a time.  "dev" pointers are HIP device
+ * pointers (e.g. torch tensor .data_ptr() on ROCm); all others are host pointers.  `stream` is a hipStream_t passed
+ * as void* (NULL = default stream).
+ *
+ * Each entry point names the reference interface it stands in for (paths relative to the reference repository).
+ */
+#ifndef RGBD_AMD_H
+#define RGBD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBD_AMD_ABI_VERSION 1
+
+int rgbd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Table construction (host, one-off).
+ * Replaces compressai._CXX.pmf_to_quantized_cdf -- CompressAI/compressai/cpp_exts/ops/ops.cpp:24-81, bound at
+ * ops.cpp:83-90 and called from entropy_models.py:60-63.   cdf_out receives n+1 entries.
+ * ------------------------------------------------------------------------------------------------------------- */
+int rgbd_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, uint32_t* cdf_out);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Stand-alone rANS coder on the GPU (host buffers in / out).
+ * Replaces compressai.ans.{RansEncoder,BufferedRansEncoder,RansDecoder} --
+ * CompressAI/compressai/cpp_exts/rans/rans_interface.cpp:99-205 (encode_with_indexes + flush),
+ * :207-276 (decode_with_indexes), :278-351 (set_stream / decode_stream), bound at :353-373.
+ * cdf is row-major [n_cdf][cdf_stride] int32; cdf_sizes / offsets have n_cdf entries.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct rgbd_tables rgbd_tables; /* packed CDF rows + search accelerator resident in HBM */
+
+int rgbd_tables_create(const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                       int32_t n_cdf, rgbd_tables** out);
+void rgbd_tables_destroy(rgbd_tables* t);
+
+/* Worst-case stream size in bytes for n symbols (escape-heavy input). */
+int64_t rgbd_rans_max_bytes(int64_t n);
+
+/* One stream from n (symbol, index) pairs.  out_len receives the byte count (multiple of 4, >= 8). */
+int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t* indexes, int64_t n, uint8_t* out,
+                     int64_t cap, int64_t* out_len);
+
+typedef struct rgbd_rans_decoder rgbd_rans_decoder;
+int rgbd_rans_decoder_create(rgbd_rans_decoder** out);
+int rgbd_rans_decoder_set_stream(rgbd_rans_decoder* d, const uint8_t* stream, int64_t nbytes);
+/* Decodes n symbols for the given table indexes, continuing from the decoder's current state. */
+int rgbd_rans_decoder_decode(rgbd_rans_decoder* d, const rgbd_tables* t, const int32_t* indexes, int64_t n,
+                             int32_t* symbols_out);
+void rgbd_rans_decoder_destroy(rgbd_rans_decoder* d);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Single operators on device tensors (NCHW fp32, contiguous) -- used by the parity tests of the conv kernels.
+ * Replaces torch.nn.functional.conv2d / conv_transpose2d as used by modules/layers/conv.py:7-34.
+ * weight: Conv2d layout (Cout,Cin,k,k) or ConvTranspose2d layout (Cin,Cout,k,k) when transposed != 0 (host ptr).
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 sigmoid.  residual_dev (optional, output-shaped) is added before act.
+ * ------------------------------------------------------------------------------------------------------------- */
+int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
+                     const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
+                     int32_t act, const float* residual_dev, float* y_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The codec.  Replaces models/elic_united.py: ELIC_united.__init__ :14-86, load_state_dict :588-620,
+ * update :580-586, compress :403-427 (+ compress_united :350-401, compress_one_slice :265-348),
+ * decompress :429-452 (+ decompress_united :543-578, decompress_one_slice :454-541).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct rgbd_elic rgbd_elic;
+
+/* config/config.py:5-10: N, M and the channel count of each latent slice. */
+int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out);
+void rgbd_elic_destroy(rgbd_elic* m);
+
+/* One state_dict entry (float32, host, reference name and shape).  Call for every parameter, then finalize. */
+int rgbd_elic_set_tensor(rgbd_elic* m, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* which: 0 rgb gaussian, 1 depth gaussian, 2 rgb bottleneck, 3 depth bottleneck (results of update()). */
+int rgbd_elic_set_tables(rgbd_elic* m, int32_t which, const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes,
+                         const int32_t* offsets, int32_t n_cdf);
+/* scale_table: 64 floats (utils/moduleFunc.py:11-12). */
+int rgbd_elic_set_scale_table(rgbd_elic* m, const float* table, int32_t n);
+/* Packs the weights for the MFMA kernels and uploads everything to the current device. */
+int rgbd_elic_finalize(rgbd_elic* m);
+
+/*
+ * compress(): rgb_dev [B,3,H,W], depth_dev [B,1,H,W] fp32 on the device, H and W multiples of 64.
+ * per_image_streams = 0 reproduces the reference's batched call (ONE y-stream per modality for the whole batch,
+ * elic_united.py:392-400); 1 emits one y-stream per image (= what B separate reference calls produce).
+ * z-streams are always per image.  Results are fetched with rgbd_elic_stream().
+ */
+int rgbd_elic_compress(rgbd_elic* m, const float* rgb_dev, const float* depth_dev, int32_t B, int32_t H, int32_t W,
+                       int32_t per_image_streams, void* stream);
+/* modality: 0 rgb, 1 depth; kind: 0 y, 1 z; index < count.  Pointer stays valid until the next compress(). */
+int rgbd_elic_stream_count(const rgbd_elic* m, int32_t modality, int32_t kind);
+int rgbd_elic_stream(const rgbd_elic* m, int32_t modality, int32_t kind, int32_t index, const uint8_t** data,
+                     int64_t* nbytes);
+
+/*
+ * decompress(): streams as produced above (y: n_y = 1 or B per modality; z: B per modality), z-grid zh x zw
+ * (= H/64, W/64).  Writes x_hat clamped to [0,1]: xr_dev [B,3,64*zh,64*zw], xd_dev [B,1,64*zh,64*zw].
+ */
+int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_t* y_rgb_len, int32_t n_y,
+                         const uint8_t* const* y_depth, const int64_t* y_depth_len, const uint8_t* const* z_rgb,
+                         const int64_t* z_rgb_len, const uint8_t* const* z_depth, const int64_t* z_depth_len, int32_t B,
+                         int32_t zh, int32_t zw, float* xr_dev, float* xd_dev, void* stream);
+
+/* Intermediate of the last compress()/decompress() as NCHW fp32 on the host (parity tests).  Names: y_r y_d z_r z_d
+ * zhat_r zhat_d hyper_r hyper_d yhat_r yhat_d.  shape_out receives 4 ints; data may be NULL to query the shape. */
+int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t cap_floats, int32_t* shape_out);
+/* Symbols / indexes of the last compress() in stream order (modality 0/1), total count in *n. */
+int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBD_AMD_H */

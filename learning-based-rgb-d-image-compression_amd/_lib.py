@@ -1,0 +1,94 @@
+"""Loader (and builder) of librgbd_amd.so, the C-ABI HIP library of this package (include/rgbd_amd.h).
+
+There is no CPU fallback: if the library is missing or a HIP call fails, the operators raise.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librgbd_amd.so")
+_SRCS = ["conv_mfma.hip", "pointwise.hip", "entropy.hip", "engine.hip"]
+_LIB = None
+
+ERRORS = {-22: "invalid argument", -12: "out of memory", -5: "HIP runtime error", -28: "buffer too small",
+          -1: "wrong call order / missing weights or tables"}
+
+
+class RgbdError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RgbdError(f"librgbd_amd: {what} failed with {rc} ({ERRORS.get(rc, 'unknown')})")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into librgbd_amd.so (in-tree, next to this file)."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, s) for s in _SRCS]
+    deps = srcs + [os.path.join(csrc, "common.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"] + srcs + ["-o", _SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise RgbdError(f"{_SO} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); "
+                        "this package has no CPU fallback")
+    L = ctypes.CDLL(_SO)
+    c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    i32p, i64p, f32p = ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_float)
+    u8p, u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)
+    u8pp = ctypes.POINTER(u8p)
+    sig = {
+        "rgbd_abi_version": (ctypes.c_int, []),
+        "rgbd_pmf_to_quantized_cdf": (ctypes.c_int, [f32p, c_i32, c_i32, u32p]),
+        "rgbd_tables_create": (ctypes.c_int, [i32p, c_i32, i32p, i32p, c_i32, ctypes.POINTER(c_vp)]),
+        "rgbd_tables_destroy": (None, [c_vp]),
+        "rgbd_rans_max_bytes": (c_i64, [c_i64]),
+        "rgbd_rans_encode": (ctypes.c_int, [c_vp, i32p, i32p, c_i64, u8p, c_i64, i64p]),
+        "rgbd_rans_decoder_create": (ctypes.c_int, [ctypes.POINTER(c_vp)]),
+        "rgbd_rans_decoder_set_stream": (ctypes.c_int, [c_vp, u8p, c_i64]),
+        "rgbd_rans_decoder_decode": (ctypes.c_int, [c_vp, c_vp, i32p, c_i64, i32p]),
+        "rgbd_rans_decoder_destroy": (None, [c_vp]),
+        "rgbd_conv2d_nchw": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32, c_i32,
+                                            c_i32, c_i32, c_vp, c_vp, c_vp]),
+        "rgbd_elic_create": (ctypes.c_int, [c_i32, c_i32, i32p, c_i32, ctypes.POINTER(c_vp)]),
+        "rgbd_elic_destroy": (None, [c_vp]),
+        "rgbd_elic_set_tensor": (ctypes.c_int, [c_vp, ctypes.c_char_p, f32p, i64p, c_i32]),
+        "rgbd_elic_set_tables": (ctypes.c_int, [c_vp, c_i32, i32p, c_i32, i32p, i32p, c_i32]),
+        "rgbd_elic_set_scale_table": (ctypes.c_int, [c_vp, f32p, c_i32]),
+        "rgbd_elic_finalize": (ctypes.c_int, [c_vp]),
+        "rgbd_elic_compress": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+        "rgbd_elic_stream_count": (ctypes.c_int, [c_vp, c_i32, c_i32]),
+        "rgbd_elic_stream": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(u8p), i64p]),
+        "rgbd_elic_decompress": (ctypes.c_int, [c_vp, u8pp, i64p, c_i32, u8pp, i64p, u8pp, i64p, u8pp, i64p, c_i32,
+                                                c_i32, c_i32, c_vp, c_vp, c_vp]),
+        "rgbd_elic_debug_tensor": (ctypes.c_int, [c_vp, ctypes.c_char_p, f32p, c_i64, i32p]),
+        "rgbd_elic_debug_symbols": (ctypes.c_int, [c_vp, c_i32, i32p, i32p, c_i64, i64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export what include/rgbd_amd.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+EXPORTS = ["rgbd_abi_version", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
+           "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
+           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_elic_create",
+           "rgbd_elic_destroy", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
+           "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_stream_count", "rgbd_elic_stream",
+           "rgbd_elic_decompress", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols"]

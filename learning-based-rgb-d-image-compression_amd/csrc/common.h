@@ -1,0 +1,122 @@
+// Shared declarations for the gfx950 ELIC_united engine (internal; the public C ABI is include/rgbd_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define RGBD_OK 0
+#define RGBD_EINVAL (-22)
+#define RGBD_ENOMEM (-12)
+#define RGBD_EHIP (-5)
+#define RGBD_ENOSPC (-28)
+#define RGBD_ESTATE (-1)
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            fprintf(stderr, "[rgbd_amd] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr,          \
+                    hipGetErrorString(_e));                                                    \
+            return RGBD_EHIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// Activation tensor in device memory: NHWC fp32, channel stride cs (multiple of 16, pad channels hold zeros).
+struct Act {
+    float* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0, cs = 0;
+    size_t elems() const { return (size_t)n * h * w * cs; }
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- convolution launcher (conv_mfma.hip) -----------------------------------------------------
+struct TapTable {
+    int8_t dy[4][25];
+    int8_t dx[4][25];
+    int8_t wt[4][25];
+    int8_t n[4];
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3 };
+
+struct ConvArgs {
+    const float* x;  // input NHWC (already offset to the first input channel)
+    int N, H, W, xcs;
+    int cin_pad;  // channels reduced over (multiple of 16)
+    const float* w;  // packed [cout_pad][ntaps_total][cin_pad]
+    int ntaps_total;
+    const float* bias;  // [cout_pad]
+    float* y;  // output NHWC (already offset to the first output channel)
+    int OH, OW, ycs;
+    int cout_pad;  // channels written (multiple of 16)
+    int GH, GW;  // tile-grid extent (output positions per phase)
+    int IS, OS;  // input step / output step per grid position
+    int nphase;  // 1, or 4 for stride-2 transposed conv (phase = py*2+px)
+    int min_dy, min_dx, span_y, span_x;
+    int act;
+    const float* res1;  // added before the activation
+    int r1cs;
+    const float* mul;  // multiplied after the activation
+    int mcs;
+    const float* res2;  // added last
+    int r2cs;
+    TapTable taps;
+};
+
+int launch_conv(const ConvArgs& a, hipStream_t s);
+
+// ---- pointwise kernels (pointwise.hip) --------------------------------------------------------
+int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s);
+int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int cs, float* dst, int clamp01,
+                              hipStream_t s);
+int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s);
+int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s);
+int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s);
+int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, float* scale,
+                 hipStream_t s);
+// mode 0: y = x*s ; mode 1: y = x + x*s   (s per (n, c))
+int launch_channel_scale(const float* x, int N, int HW, int cs, int C, const float* scale, int mode, float* y,
+                         hipStream_t s);
+int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s);
+int launch_fill_zero(float* p, size_t n, hipStream_t s);
+
+// ---- entropy stage (entropy.hip) --------------------------------------------------------------
+struct DevTables {  // packed CDF rows for the device coder
+    const uint16_t* cdf;  // concatenated rows, entries [0, size-1) (the final 65536 is implicit)
+    const int32_t* row_off;  // [nrows] start of each row in cdf
+    const int32_t* sizes;  // [nrows] reference cdf_length (= pmf_length + 2)
+    const int32_t* offsets;  // [nrows]
+    const uint16_t* lut;  // [nrows][257] decoder search accelerator: largest j with row[j] <= (b << 8)
+    int nrows;
+    int total;  // total packed entries
+};
+
+struct PartGeom {
+    int B, h, w;  // latent geometry
+    int C;  // channels of this slice
+    int anchor;  // 1 = anchor positions
+    int per_image;  // 1: one stream per image; 0: one stream for the batch (reference B>1 format)
+};
+
+int launch_ckbd_encode_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs,
+                            const float* table, PartGeom g, int32_t* sym, int32_t* idx, const int64_t* stream_base,
+                            int64_t part_off_per_image, hipStream_t s);
+int launch_ckbd_index_part(const float* params, int pcs, const float* table, PartGeom g, int32_t* idx,
+                           const int64_t* stream_base, int64_t part_off_per_image, hipStream_t s);
+int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs, PartGeom g, const int32_t* sym,
+                            const int64_t* stream_base, int64_t part_off_per_image, hipStream_t s);
+int launch_z_quant(const float* z, int zcs, int B, int h, int w, int C, const float* medians, int32_t* sym,
+                   int32_t* idx, hipStream_t s);
+int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float* medians, float* zhat, int zcs,
+                     hipStream_t s);
+
+// One wave per stream.  counts[s] symbols starting at sym_base[s]; writes words backwards into
+// out + s*cap_words; out_words[s] receives the number of 32-bit words produced (stream = last out_words words).
+int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sym_base, const int64_t* counts,
+                       int nstreams, DevTables t, uint32_t* out, int64_t cap_words, int64_t* out_words, int* err,
+                       hipStream_t s);
+// Stateful decode: state[s] = {x, pos}; init=1 loads the state from the first two words of each stream.
+int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,
+                       int nstreams, uint64_t* state, int init, const int32_t* idx, int32_t* sym,
+                       const int64_t* sym_base, int64_t part_off, int64_t count, DevTables t, hipStream_t s);

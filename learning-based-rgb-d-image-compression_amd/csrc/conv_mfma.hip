@@ -1,0 +1,237 @@
+// Implicit-GEMM convolution / transposed convolution for gfx950 (MI355X), fp32 in / fp32 accumulate on the
+// matrix cores (v_mfma_f32_16x16x4_f32).  Replaces every nn.Conv2d / nn.ConvTranspose2d of the reference's
+// ELIC_united path (modules/layers/conv.py:7-34 and the convs inside res_blk.py, attention.py, context.py,
+// entropy.py, compressai/layers/layers.py) -- see DESIGN.md "K1/K2".
+//
+// Data layout: activations NHWC with a channel stride that is a multiple of 16 (pad channels are zero), weights
+// pre-packed as [cout_pad][tap][cin_pad].  GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel] with
+// k = (ci-chunk of 16, tap, ci).  One 256-thread workgroup owns TM couts x TP pixels (a TH x TW spatial tile of one
+// image).  Per 16-channel chunk the input patch (tile + halo) is staged ONCE in LDS and every tap reads it at a
+// shifted address, so global traffic per workgroup is patch + weights instead of taps x tile.
+//
+// Numerics: every output element is one k-ordered fp32 fma chain (MFMA f32 semantics) whose order depends only on
+// the layer (chunk -> tap -> channel), never on tiling or batch size: results are run-to-run, batch- and
+// tile-invariant, which the entropy decoder relies on to reproduce the encoder's means/scales bit for bit.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define KC 16  // channels per LDS stage
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
+                                                         int taps_per_stage)
+{
+    constexpr int TM = 16 * MT * WM;
+    constexpr int TP = 16 * NT * WN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int l15 = lane & 15;
+    const int q = lane >> 4;
+
+    const int TW = 1 << tw_log2;
+    const int TH = TP >> tw_log2;
+    const int phase = blockIdx.z;
+    const int co0 = blockIdx.y * TM;
+    int bt = blockIdx.x;
+    const int tile_x = bt % tiles_x;
+    bt /= tiles_x;
+    const int tile_y = bt % tiles_y;
+    const int n = bt / tiles_y;
+    const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+
+    const int PH = (TH - 1) * a.IS + a.span_y;
+    const int PW = (TW - 1) * a.IS + a.span_x;
+    float* patch = smem;                      // [PH*PW][KC]
+    float* wl = smem + (size_t)PH * PW * KC;  // [taps_per_stage][TM][KC]
+
+    const int ntaps = a.taps.n[phase];
+    const int iy0 = ty0 * a.IS + a.min_dy;
+    const int ix0 = tx0 * a.IS + a.min_dx;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane pixel coordinates of the NT column groups this wave owns (tile-local)
+    int ppy[NT], ppx[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int p = (wn * NT + j) * 16 + l15;
+        ppy[j] = p >> tw_log2;
+        ppx[j] = p & (TW - 1);
+    }
+
+    const int npatch4 = PH * PW * (KC / 4);
+    const size_t img_base = (size_t)n * a.H * a.W;
+
+    for (int ci0 = 0; ci0 < a.cin_pad; ci0 += KC) {
+        __syncthreads();  // previous chunk's readers are done with patch and wl
+        for (int f = tid; f < npatch4; f += 256) {
+            const int row = f >> 2, c4 = f & 3;
+            const int pr = row / PW, pc = row - pr * PW;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const f32x4*>(a.x + (img_base + (size_t)iy * a.W + ix) * a.xcs + ci0 + c4 * 4);
+            *reinterpret_cast<f32x4*>(patch + (size_t)row * KC + c4 * 4) = v;
+        }
+        for (int t0 = 0; t0 < ntaps; t0 += taps_per_stage) {
+            const int tg = min(taps_per_stage, ntaps - t0);
+            if (t0) __syncthreads();  // readers of the previous tap group are done with wl
+            const int nw4 = tg * TM * (KC / 4);
+            for (int f = tid; f < nw4; f += 256) {
+                const int c4 = f & 3;
+                const int m = (f >> 2) % TM;
+                const int j = (f >> 2) / TM;
+                const int co = co0 + m;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (co < a.cout_pad)
+                    v = *reinterpret_cast<const f32x4*>(
+                        a.w + ((size_t)co * a.ntaps_total + a.taps.wt[phase][t0 + j]) * a.cin_pad + ci0 + c4 * 4);
+                *reinterpret_cast<f32x4*>(wl + ((size_t)j * TM + m) * KC + c4 * 4) = v;
+            }
+            __syncthreads();
+            for (int j = 0; j < tg; ++j) {
+                const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
+                const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(
+                        wl + ((size_t)j * TM + (wm * MT + i) * 16 + l15) * KC + q * 4);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const int row = (ppy[k] * a.IS + dy) * PW + ppx[k] * a.IS + dx;
+                    bf[k] = *reinterpret_cast<const f32x4*>(patch + (size_t)row * KC + q * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+                            acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: lane holds couts cb..cb+3 of pixel (ppy,ppx) for each (i,k)
+    const int oy_off = a.nphase > 1 ? (phase >> 1) : 0;
+    const int ox_off = a.nphase > 1 ? (phase & 1) : 0;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int gy = ty0 + ppy[k], gx = tx0 + ppx[k];
+        if (gy >= a.GH || gx >= a.GW) continue;
+        const int oy = gy * a.OS + oy_off, ox = gx * a.OS + ox_off;
+        const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int cb = co0 + (wm * MT + i) * 16 + q * 4;
+            if (cb >= a.cout_pad) continue;
+            f32x4 v = acc[i][k];
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + cb);
+            v += b;
+            if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb);
+            if (a.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (a.act == ACT_LEAKY) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
+            } else if (a.act == ACT_SIGMOID) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+            }
+            if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb);
+            if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb);
+            *reinterpret_cast<f32x4*>(a.y + pix * a.ycs + cb) = v;
+        }
+    }
+}
+
+namespace {
+
+struct TileCfg {
+    int wm, mt;  // WM in {1,2}; TM = 16*mt*wm
+};
+
+TileCfg pick_tile(int cout_pad)
+{
+    // candidates (TM): WM=1: 16,32,48 ; WM=2: 64,96,128,160 -- minimise padded couts, prefer the larger tile
+    static const TileCfg cands[] = {{2, 5}, {2, 4}, {2, 3}, {2, 2}, {1, 3}, {1, 2}, {1, 1}};
+    TileCfg best = cands[0];
+    long best_pad = -1;
+    for (const TileCfg& c : cands) {
+        const int tm = 16 * c.mt * c.wm;
+        const long padded = (long)((cout_pad + tm - 1) / tm) * tm;
+        if (best_pad < 0 || padded < best_pad) {
+            best = c;
+            best_pad = padded;
+        }
+    }
+    return best;
+}
+
+constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
+
+template <int WM, int WN, int MT, int NT>
+int launch_cfg(const ConvArgs& a, hipStream_t s)
+{
+    constexpr int TM = 16 * MT * WM;
+    constexpr int TP = 16 * NT * WN;
+    const int tw_log2 = (a.GW <= 8 || (a.GW % 16 != 0 && a.GW % 16 <= 8 && a.GW < 64)) ? 3 : 4;
+    const int TW = 1 << tw_log2, TH = TP / TW;
+    const int tiles_x = (a.GW + TW - 1) / TW, tiles_y = (a.GH + TH - 1) / TH;
+    const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
+    const size_t patch_bytes = (size_t)PH * PW * KC * sizeof(float);
+    const size_t tap_bytes = (size_t)TM * KC * sizeof(float);
+    int max_taps = 1;
+    for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
+    if (patch_bytes + tap_bytes > 150 * 1024) return RGBD_ENOSPC;
+    long room = ((long)LDS_BUDGET - (long)patch_bytes) / (long)tap_bytes;
+    if (room < 1) room = 1;
+    int tps = (int)(room < max_taps ? room : max_taps);
+    const size_t lds = patch_bytes + (size_t)tps * tap_bytes;
+    auto kern = conv_mfma_kernel<WM, WN, MT, NT>;
+    static size_t configured = 0;  // per instantiation
+    if (lds > 64 * 1024 && lds > configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(160 * 1024)));
+        configured = 160 * 1024;
+    }
+    dim3 grid((unsigned)(tiles_x * tiles_y * a.N), (unsigned)((a.cout_pad + TM - 1) / TM), (unsigned)a.nphase);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+}  // namespace
+
+int launch_conv(const ConvArgs& a, hipStream_t s)
+{
+    if (a.cin_pad % KC || a.cout_pad % 16 || a.xcs % 4 || a.ycs % 4) return RGBD_EINVAL;
+    if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;
+    if (a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
+    const TileCfg c = pick_tile(a.cout_pad);
+    if (c.wm == 2) {
+        switch (c.mt) {
+        case 5: return launch_cfg<2, 2, 5, 4>(a, s);
+        case 4: return launch_cfg<2, 2, 4, 4>(a, s);
+        case 3: return launch_cfg<2, 2, 3, 4>(a, s);
+        default: return launch_cfg<2, 2, 2, 4>(a, s);
+        }
+    }
+    switch (c.mt) {
+    case 3: return launch_cfg<1, 4, 3, 2>(a, s);
+    case 2: return launch_cfg<1, 4, 2, 2>(a, s);
+    default: return launch_cfg<1, 4, 1, 2>(a, s);
+    }
+}

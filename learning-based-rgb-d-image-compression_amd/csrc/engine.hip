@@ -1,0 +1,1499 @@
+// Host runtime of the gfx950 ELIC_united engine: weight packing, workspace arena, the layer graph of
+// compress()/decompress() as a sequence of HIP kernel launches on one stream, and the C ABI (include/rgbd_amd.h).
+// Mirrors the call structure of the reference's models/elic_united.py:350-578 but keeps every tensor, symbol,
+// index and bitstream resident in HBM; the only device->host traffic is the finished streams.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbd_amd.h"
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device tables
+// ------------------------------------------------------------------------------------------------
+struct TableSet {
+    DevTables d{};
+    void* blob = nullptr;
+    bool ready = false;
+    int stride_src = 0;
+};
+
+int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int32_t* offsets, int nrows, TableSet* ts)
+{
+    if (!cdf || !sizes || !offsets || nrows <= 0 || stride < 3) return RGBD_EINVAL;
+    std::vector<int32_t> row_off(nrows);
+    int total = 0;
+    for (int r = 0; r < nrows; ++r) {
+        if (sizes[r] < 3 || sizes[r] > stride) return RGBD_EINVAL;
+        row_off[r] = total;
+        total += sizes[r] - 1;  // final 65536 entry is implicit
+    }
+    std::vector<uint16_t> packed(total);
+    const int LN = 257;
+    std::vector<uint16_t> lut((size_t)nrows * LN);
+    for (int r = 0; r < nrows; ++r) {
+        const int32_t* row = cdf + (size_t)r * stride;
+        const int len = sizes[r];
+        if (row[0] != 0 || row[len - 1] != 65536) return RGBD_EINVAL;
+        for (int j = 0; j < len - 1; ++j) {
+            if (row[j] < 0 || row[j] > 65535 || row[j + 1] <= row[j]) return RGBD_EINVAL;
+            packed[row_off[r] + j] = (uint16_t)row[j];
+        }
+        int j = 0;
+        for (int b = 0; b < LN; ++b) {
+            const int64_t lim = (int64_t)b << 8;
+            while (j + 1 <= len - 2 && row[j + 1] <= lim) ++j;
+            lut[(size_t)r * LN + b] = (uint16_t)j;
+        }
+    }
+    const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
+    const size_t b_lut = ((size_t)nrows * LN * 2 + 15) & ~(size_t)15;
+    const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
+    const size_t bytes = b_cdf + b_lut + 3 * b_i32;
+    if (ts->blob) (void)hipFree(ts->blob);
+    ts->blob = nullptr;
+    HIP_TRY(hipMalloc(&ts->blob, bytes));
+    std::vector<unsigned char> host(bytes, 0);
+    unsigned char* p = host.data();
+    memcpy(p, packed.data(), (size_t)total * 2);
+    memcpy(p + b_cdf, lut.data(), (size_t)nrows * LN * 2);
+    memcpy(p + b_cdf + b_lut, row_off.data(), (size_t)nrows * 4);
+    memcpy(p + b_cdf + b_lut + b_i32, sizes, (size_t)nrows * 4);
+    memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);
+    HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
+    unsigned char* dp = (unsigned char*)ts->blob;
+    ts->d.cdf = (const uint16_t*)dp;
+    ts->d.lut = (const uint16_t*)(dp + b_cdf);
+    ts->d.row_off = (const int32_t*)(dp + b_cdf + b_lut);
+    ts->d.sizes = (const int32_t*)(dp + b_cdf + b_lut + b_i32);
+    ts->d.offsets = (const int32_t*)(dp + b_cdf + b_lut + 2 * b_i32);
+    ts->d.nrows = nrows;
+    ts->d.total = total;
+    ts->ready = true;
+    ts->stride_src = stride;
+    return RGBD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed layers
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+};
+
+struct PackedConv {
+    float* w = nullptr;  // [cout_pad][k*k][cin_pad]
+    float* bias = nullptr;
+    int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0, k = 0;
+    bool transposed = false;
+};
+
+int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedConv* pc)
+{
+    if (w.shape.size() != 4 || w.shape[2] != w.shape[3]) return RGBD_EINVAL;
+    const int k = (int)w.shape[2];
+    const int cout = transposed ? (int)w.shape[1] : (int)w.shape[0];
+    const int cin = transposed ? (int)w.shape[0] : (int)w.shape[1];
+    pc->cin = cin;
+    pc->cout = cout;
+    pc->k = k;
+    pc->transposed = transposed;
+    pc->cin_pad = round_up(cin, 16);
+    pc->cout_pad = round_up(cout, 16);
+    const size_t n = (size_t)pc->cout_pad * k * k * pc->cin_pad;
+    std::vector<float> h(n, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < k * k; ++t) {
+                const size_t src = transposed ? (((size_t)ci * cout + co) * k * k + t) : (((size_t)co * cin + ci) * k * k + t);
+                h[((size_t)co * k * k + t) * pc->cin_pad + ci] = w.v[src];
+            }
+    std::vector<float> hb(pc->cout_pad, 0.f);
+    if (b) {
+        if ((int)b->v.size() != cout) return RGBD_EINVAL;
+        memcpy(hb.data(), b->v.data(), sizeof(float) * cout);
+    }
+    HIP_TRY(hipMalloc((void**)&pc->w, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&pc->bias, hb.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(pc->w, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pc->bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RGBD_OK;
+}
+
+void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
+{
+    const int k = pc.k;
+    memset(&a->taps, 0, sizeof(a->taps));
+    if (!pc.transposed) {
+        a->nphase = 1;
+        a->IS = stride;
+        a->OS = 1;
+        int n = 0;
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) {
+                a->taps.dy[0][n] = (int8_t)(ky - pad);
+                a->taps.dx[0][n] = (int8_t)(kx - pad);
+                a->taps.wt[0][n] = (int8_t)(ky * k + kx);
+                ++n;
+            }
+        a->taps.n[0] = (int8_t)n;
+        a->min_dy = a->min_dx = -pad;
+        a->span_y = a->span_x = k;
+        return;
+    }
+    // transposed: o = i*s - pad + k  =>  for o = s*t + r: i = t + (r + pad - k)/s for k == (r + pad) mod s
+    a->nphase = stride * stride;
+    a->IS = 1;
+    a->OS = stride;
+    int mn = 127, mx = -127;
+    for (int ry = 0; ry < stride; ++ry)
+        for (int rx = 0; rx < stride; ++rx) {
+            const int ph = ry * stride + rx;
+            int n = 0;
+            for (int ky = 0; ky < k; ++ky) {
+                if ((ry + pad - ky) % stride) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    if ((rx + pad - kx) % stride) continue;
+                    const int dy = (ry + pad - ky) / stride, dx = (rx + pad - kx) / stride;
+                    a->taps.dy[ph][n] = (int8_t)dy;
+                    a->taps.dx[ph][n] = (int8_t)dx;
+                    a->taps.wt[ph][n] = (int8_t)(ky * k + kx);
+                    mn = std::min(mn, std::min(dy, dx));
+                    mx = std::max(mx, std::max(dy, dx));
+                    ++n;
+                }
+            }
+            a->taps.n[ph] = (int8_t)n;
+        }
+    a->min_dy = a->min_dx = mn;
+    a->span_y = a->span_x = mx - mn + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the model
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    unsigned char* base = nullptr;
+    size_t cap = 0, top = 0, peak = 0;
+    bool dry = false;
+    void* take(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        void* p = dry ? (void*)(uintptr_t)(0x1000 + top) : (void*)(base + top);
+        top += bytes;
+        peak = std::max(peak, top);
+        return p;
+    }
+};
+
+struct Epi {
+    int act = ACT_NONE;
+    const Act* res1 = nullptr;
+    const Act* mul = nullptr;
+    const Act* res2 = nullptr;
+};
+
+}  // namespace
+
+struct rgbd_tables {
+    TableSet ts;
+};
+
+struct rgbd_elic {
+    int N = 192, M = 320;
+    std::vector<int> slice_ch;
+    std::map<std::string, HostTensor> raw;
+    std::map<std::string, PackedConv> convs;
+    std::map<std::string, float*> dense;  // SE fc weights, EB medians (device)
+    TableSet tables[4];
+    float* scale_table = nullptr;
+    bool finalized = false;
+
+    Arena arena;
+    hipStream_t s = nullptr;
+    int rc = 0;
+    std::map<std::string, Act> named;  // intermediates of the last call (live in the arena)
+
+    // last compress() results (host)
+    std::vector<std::vector<uint8_t>> streams[2][2];
+    // last compress() symbol buffers (device, inside the arena) for debug
+    int32_t* dbg_sym = nullptr;
+    int32_t* dbg_idx = nullptr;
+    int64_t dbg_per_mod = 0;
+
+    // --- small helpers -------------------------------------------------------------------------
+    bool dry() const { return arena.dry; }
+    void fail(int code)
+    {
+        if (!rc) rc = code;
+    }
+    Act alloc(int n, int h, int w, int c)
+    {
+        Act a;
+        a.n = n;
+        a.h = h;
+        a.w = w;
+        a.c = c;
+        a.cs = round_up(c, 16);
+        a.p = (float*)arena.take(a.elems() * sizeof(float));
+        return a;
+    }
+    static Act view(const Act& a, int c0, int c)
+    {
+        Act v = a;
+        v.p = a.p + c0;
+        v.c = c;
+        return v;
+    }
+    const PackedConv* conv_of(const std::string& name)
+    {
+        auto it = convs.find(name);
+        if (it == convs.end()) {
+            fprintf(stderr, "[rgbd_amd] missing layer %s\n", name.c_str());
+            fail(RGBD_ESTATE);
+            return nullptr;
+        }
+        return &it->second;
+    }
+    float* dense_of(const std::string& name)
+    {
+        auto it = dense.find(name);
+        if (it == dense.end()) {
+            fprintf(stderr, "[rgbd_amd] missing tensor %s\n", name.c_str());
+            fail(RGBD_ESTATE);
+            return nullptr;
+        }
+        return it->second;
+    }
+
+    // --- operators -----------------------------------------------------------------------------
+    Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr)
+    {
+        const PackedConv* pc = conv_of(name + ".weight");
+        if (!pc) return Act();
+        const int k = pc->k;
+        int OH, OW;
+        if (!pc->transposed) {
+            OH = (x.h + 2 * pad - k) / stride + 1;
+            OW = (x.w + 2 * pad - k) / stride + 1;
+        } else {
+            OH = (x.h - 1) * stride - 2 * pad + k + (stride - 1);
+            OW = (x.w - 1) * stride - 2 * pad + k + (stride - 1);
+        }
+        Act y = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
+        if (round_up(x.c, 16) != pc->cin_pad || y.h != OH || y.w != OW || y.n != x.n || y.c != pc->cout) {
+            fprintf(stderr, "[rgbd_amd] shape mismatch at %s: x.c=%d cin=%d y=(%d,%d,%d) expect (%d,%d,%d)\n", name.c_str(),
+                    x.c, pc->cin, y.h, y.w, y.c, OH, OW, pc->cout);
+            fail(RGBD_EINVAL);
+            return y;
+        }
+        if (dry() || rc) return y;
+        ConvArgs a{};
+        a.x = x.p;
+        a.N = x.n;
+        a.H = x.h;
+        a.W = x.w;
+        a.xcs = x.cs;
+        a.cin_pad = pc->cin_pad;
+        a.w = pc->w;
+        a.ntaps_total = k * k;
+        a.bias = pc->bias;
+        a.y = y.p;
+        a.OH = OH;
+        a.OW = OW;
+        a.ycs = y.cs;
+        a.cout_pad = pc->cout_pad;
+        make_taps(*pc, stride, pad, &a);
+        a.GH = pc->transposed ? x.h : OH;
+        a.GW = pc->transposed ? x.w : OW;
+        a.act = ep.act;
+        if (ep.res1) {
+            a.res1 = ep.res1->p;
+            a.r1cs = ep.res1->cs;
+        }
+        if (ep.mul) {
+            a.mul = ep.mul->p;
+            a.mcs = ep.mul->cs;
+        }
+        if (ep.res2) {
+            a.res2 = ep.res2->p;
+            a.r2cs = ep.res2->cs;
+        }
+        const int r = launch_conv(a, s);
+        if (r) {
+            fprintf(stderr, "[rgbd_amd] conv launch failed at %s (%d)\n", name.c_str(), r);
+            fail(r);
+        }
+        return y;
+    }
+
+    void copy_ch(const Act& src, const Act& dst)
+    {
+        if (dry() || rc) return;
+        const int r = launch_copy_channels(src.p, src.cs, dst.p, dst.cs, src.n * src.h * src.w, round_up(src.c, 4), s);
+        if (r) fail(r);
+    }
+
+    // modules/layers/res_blk.py:7-27
+    Act bottleneck(const std::string& p, const Act& x, const Act* dst = nullptr)
+    {
+        const PackedConv* last = conv_of(p + ".branch.4.weight");
+        if (!last) return Act();
+        Act out = dst ? *dst : alloc(x.n, x.h, x.w, last->cout);
+        const size_t mark = arena.top;
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act t1 = conv(p + ".branch.0", x, 1, 0, relu);
+        Act t2 = conv(p + ".branch.2", t1, 1, 1, relu);
+        Epi e;
+        Act idn = x;
+        if (convs.count(p + ".skip.weight")) idn = conv(p + ".skip", x, 1, 0);
+        e.res1 = &idn;
+        conv(p + ".branch.4", t2, 1, 0, e, &out);
+        arena.top = mark;
+        return out;
+    }
+
+    // CompressAI/compressai/layers/layers.py:177-196
+    Act res_unit(const std::string& p, const Act& x)
+    {
+        Act out = alloc(x.n, x.h, x.w, x.c);
+        const size_t mark = arena.top;
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act t1 = conv(p + ".conv.0", x, 1, 0, relu);
+        Act t2 = conv(p + ".conv.2", t1, 1, 1, relu);
+        Epi e;
+        e.act = ACT_RELU;
+        e.res1 = &x;
+        conv(p + ".conv.4", t2, 1, 0, e, &out);
+        arena.top = mark;
+        return out;
+    }
+
+    // layers.py:198-213
+    Act attention(const std::string& p, const Act& x, const Act* dst = nullptr)
+    {
+        Act out = dst ? *dst : alloc(x.n, x.h, x.w, x.c);
+        const size_t mark = arena.top;
+        Act a = x;
+        for (int u = 0; u < 3; ++u) a = res_unit(p + ".conv_a." + std::to_string(u), a);
+        Act b = x;
+        for (int u = 0; u < 3; ++u) b = res_unit(p + ".conv_b." + std::to_string(u), b);
+        Epi e;
+        e.act = ACT_SIGMOID;
+        e.mul = &a;
+        e.res2 = &x;
+        conv(p + ".conv_b.3", b, 1, 0, e, &out);
+        arena.top = mark;
+        return out;
+    }
+
+    // modules/transform/attention.py:84-97; x: [.., n_feats]; writes x * sigmoid(...) into dst
+    void esa(const std::string& p, const Act& x, const Act& dst)
+    {
+        const size_t mark = arena.top;
+        Act c1_ = conv(p + ".conv1", x, 1, 0);
+        Act c1 = conv(p + ".conv2", c1_, 2, 0);
+        const int ph = (c1.h - 7) / 3 + 1, pw = (c1.w - 7) / 3 + 1;
+        if (c1.h < 7 || c1.w < 7) {
+            fail(RGBD_EINVAL);
+            return;
+        }
+        Act v = alloc(x.n, ph, pw, c1.c);
+        if (!dry() && !rc) {
+            const int r = launch_maxpool7s3(c1.p, c1.n, c1.h, c1.w, c1.cs, v.p, ph, pw, s);
+            if (r) fail(r);
+        }
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act vr = conv(p + ".conv_max", v, 1, 1, relu);
+        Act c3 = conv(p + ".conv3", vr, 1, 1, relu);
+        c3 = conv(p + ".conv3_", c3, 1, 1);
+        Act up = alloc(x.n, x.h, x.w, c3.c);
+        if (!dry() && !rc) {
+            const int r = launch_bilinear(c3.p, c3.n, c3.h, c3.w, c3.cs, up.p, x.h, x.w, s);
+            if (r) fail(r);
+        }
+        Epi addup;
+        addup.res1 = &up;
+        Act sum = conv(p + ".conv_f", c1_, 1, 0, addup);
+        Epi gate;
+        gate.act = ACT_SIGMOID;
+        gate.mul = &x;
+        conv(p + ".conv4", sum, 1, 0, gate, &dst);
+        arena.top = mark;
+    }
+
+    // modules/transform/attention.py:35-48; rgb/depth: views of N channels; writes the gated features into
+    // r_dst / d_dst (N channels each)
+    void bi_spf(const std::string& p, const Act& rgb, const Act& depth, const Act& r_dst, const Act& d_dst)
+    {
+        const size_t mark = arena.top;
+        const int half = rgb.c / 2;
+        Act rd = alloc(rgb.n, rgb.h, rgb.w, rgb.c);  // cat(rf, df)
+        Act dr = alloc(rgb.n, rgb.h, rgb.w, rgb.c);  // cat(df, rf)
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act rf = view(rd, 0, half), df = view(rd, half, half);
+        conv(p + ".r_ext", rgb, 1, 1, relu, &rf);
+        conv(p + ".d_ext", depth, 1, 1, relu, &df);
+        copy_ch(df, view(dr, 0, half));
+        copy_ch(rf, view(dr, half, half));
+        esa(p + ".r_esa", rd, r_dst);
+        esa(p + ".d_esa", dr, d_dst);
+        arena.top = mark;
+    }
+
+    // modules/transform/attention.py:63-67 -- returns the per-(n,c) sigmoid weights
+    float* se_weights(const std::string& p, const Act& x)
+    {
+        float* w0 = dense_of(p + ".fc.0.weight");
+        float* w1 = dense_of(p + ".fc.2.weight");
+        float* mean = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
+        float* sc = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
+        if (dry() || rc || !w0 || !w1) return sc;
+        int r = launch_channel_mean(x.p, x.n, x.h * x.w, x.cs, x.c, mean, s);
+        if (!r) r = launch_se_fc(mean, x.n, x.c, x.c / 16, w0, w1, sc, s);
+        if (r) fail(r);
+        return sc;
+    }
+
+    void scale_inplace(const Act& x, const float* sc, int mode)
+    {
+        if (dry() || rc) return;
+        const int r = launch_channel_scale(x.p, x.n, x.h * x.w, x.cs, x.c, sc, mode, x.p, s);
+        if (r) fail(r);
+    }
+
+    // ---- transforms -----------------------------------------------------------------------------
+    // analysis.py:116-174
+    void g_a(const Act& rgb_in, const Act& depth_in, Act* y_r, Act* y_d)
+    {
+        static const char* kinds[18] = {"conv", "rb", "rb", "rb", "spf", "conv", "rb", "rb", "rb",
+                                        "attn", "spf", "conv", "rb", "rb", "rb", "spf", "conv", "attn"};
+        const std::string pr = "g_a.rgb_analysis_transform.", pd = "g_a.depth_analysis_transform.";
+        Act r = rgb_in, d = depth_in;
+        for (int i = 0; i < 18; ++i) {
+            const std::string k = kinds[i], si = std::to_string(i);
+            const bool next_spf = (i + 1 < 18) && std::string(kinds[i + 1]) == "spf";
+            Act rdst, ddst;
+            const Act *pr_dst = nullptr, *pd_dst = nullptr;
+            Act rcat, dcat;
+            if (next_spf) {  // the stage feeding a fusion writes into the first half of the concat buffer
+                rcat = alloc(r.n, r.h, r.w, 2 * N);
+                dcat = alloc(d.n, d.h, d.w, 2 * N);
+                rdst = view(rcat, 0, N);
+                ddst = view(dcat, 0, N);
+                pr_dst = &rdst;
+                pd_dst = &ddst;
+            }
+            if (k == "conv") {
+                r = conv(pr + si, r, 2, 2);
+                d = conv(pd + si, d, 2, 2);
+            } else if (k == "rb") {
+                r = bottleneck(pr + si, r, pr_dst);
+                d = bottleneck(pd + si, d, pd_dst);
+                if (next_spf) {
+                    r = rcat;
+                    d = dcat;
+                }
+            } else if (k == "attn") {
+                r = attention(pr + si, r, pr_dst);
+                d = attention(pd + si, d, pd_dst);
+                if (next_spf) {
+                    r = rcat;
+                    d = dcat;
+                }
+            } else {  // spf: r and d are the 2N-channel concat buffers whose first half is filled
+                bi_spf(pr + si, view(r, 0, N), view(d, 0, N), view(r, N, N), view(d, N, N));
+            }
+        }
+        *y_r = r;
+        *y_d = d;
+    }
+
+    // synthesis.py:126-184
+    void g_s(const Act& yr, const Act& yd, Act* xr, Act* xd)
+    {
+        static const char* kinds[18] = {"attn", "deconv", "spf", "rb", "rb", "rb", "deconv", "attn", "spf",
+                                        "rb", "rb", "rb", "deconv", "spf", "rb", "rb", "rb", "deconv"};
+        const std::string pr = "g_s.rgb_synthesis_transform.", pd = "g_s.depth_synthesis_transform.";
+        Act r = yr, d = yd;
+        for (int i = 0; i < 18; ++i) {
+            const std::string k = kinds[i], si = std::to_string(i);
+            const bool next_spf = (i + 1 < 18) && std::string(kinds[i + 1]) == "spf";
+            if (k == "spf") {
+                bi_spf(pr + si, view(r, 0, N), view(d, 0, N), view(r, N, N), view(d, N, N));
+                continue;
+            }
+            Act rcat, dcat, rdst, ddst;
+            const Act *pr_dst = nullptr, *pd_dst = nullptr;
+            if (next_spf) {
+                const int oh = (k == "deconv") ? r.h * 2 : r.h, ow = (k == "deconv") ? r.w * 2 : r.w;
+                rcat = alloc(r.n, oh, ow, 2 * N);
+                dcat = alloc(d.n, oh, ow, 2 * N);
+                rdst = view(rcat, 0, N);
+                ddst = view(dcat, 0, N);
+                pr_dst = &rdst;
+                pd_dst = &ddst;
+            }
+            if (k == "deconv") {
+                r = conv(pr + si, r, 2, 2, Epi(), pr_dst);
+                d = conv(pd + si, d, 2, 2, Epi(), pd_dst);
+            } else if (k == "rb") {
+                r = bottleneck(pr + si, r, pr_dst);
+                d = bottleneck(pd + si, d, pd_dst);
+            } else {
+                r = attention(pr + si, r, pr_dst);
+                d = attention(pd + si, d, pd_dst);
+            }
+            if (next_spf) {
+                r = rcat;
+                d = dcat;
+            }
+        }
+        *xr = r;
+        *xd = d;
+    }
+
+    // analysis.py:231-242
+    void h_a(const Act& yr, const Act& yd, Act* zr, Act* zd)
+    {
+        Epi relu;
+        relu.act = ACT_RELU;
+        const char* mods[2] = {"rgb", "depth"};
+        const Act* in[2] = {&yr, &yd};
+        Act* out[2] = {zr, zd};
+        for (int m = 0; m < 2; ++m) {
+            const std::string p = std::string("h_a.") + mods[m] + "_reduction.";
+            Act t = conv(p + "0", *in[m], 1, 1, relu);
+            t = conv(p + "2", t, 2, 2, relu);
+            *out[m] = conv(p + "4", t, 2, 2);
+        }
+    }
+
+    // synthesis.py:345-362
+    Act hs_block(const std::string& p, const Act& own, const Act& other, bool last)
+    {
+        Act f = alloc(own.n, own.h, own.w, own.c + other.c);
+        copy_ch(own, view(f, 0, own.c));
+        copy_ch(other, view(f, own.c, other.c));
+        float* sc = se_weights(p + ".se", f);
+        scale_inplace(f, sc, 0);
+        Epi e;
+        e.act = last ? ACT_NONE : ACT_LEAKY;
+        return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
+    }
+
+    // synthesis.py:316-323
+    void h_s(const Act& zr, const Act& zd, Act* hr, Act* hd)
+    {
+        Act r1 = hs_block("h_s.r_h_s1", zr, zd, false);
+        Act d1 = hs_block("h_s.d_h_s1", zd, zr, false);
+        Act r2 = hs_block("h_s.r_h_s2", r1, d1, false);
+        Act d2 = hs_block("h_s.d_h_s2", d1, r1, false);
+        *hr = hs_block("h_s.r_h_s3", r2, d2, true);
+        *hd = hs_block("h_s.d_h_s3", d2, r2, true);
+    }
+
+    // entropy.py:69-78 on the concatenation of `segs`
+    Act entropy_params(const std::string& p, const std::vector<Act>& segs)
+    {
+        int cin = 0;
+        for (const Act& a : segs) cin += a.c;
+        const PackedConv* last = conv_of(p + ".fusion.4.weight");
+        if (!last) return Act();
+        Act out = alloc(segs[0].n, segs[0].h, segs[0].w, last->cout);
+        const size_t mark = arena.top;
+        Act cat = alloc(segs[0].n, segs[0].h, segs[0].w, cin);
+        int c0 = 0;
+        for (const Act& a : segs) {
+            copy_ch(a, view(cat, c0, a.c));
+            c0 += a.c;
+        }
+        float* sc = se_weights(p + ".se", cat);
+        scale_inplace(cat, sc, 1);  // params + se(params)
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act t = conv(p + ".fusion.0", cat, 1, 0, relu);
+        t = conv(p + ".fusion.2", t, 1, 1, relu);
+        conv(p + ".fusion.4", t, 1, 2, Epi(), &out);
+        arena.top = mark;
+        return out;
+    }
+
+    // context.py:10-30
+    Act channel_context(const std::string& p, const Act& x)
+    {
+        const PackedConv* last = conv_of(p + ".fushion.4.weight");
+        if (!last) return Act();
+        Act out = alloc(x.n, x.h, x.w, last->cout);
+        const size_t mark = arena.top;
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act t = conv(p + ".fushion.0", x, 1, 2, relu);
+        t = conv(p + ".fushion.2", t, 1, 2, relu);
+        conv(p + ".fushion.4", t, 1, 2, Epi(), &out);
+        arena.top = mark;
+        return out;
+    }
+
+    // ---- Bi-CEE loop (elic_united.py:265-348 / 454-541) -----------------------------------------
+    struct Coding {
+        bool encode = true;
+        int per_image = 1;
+        int64_t per_image_total = 0;  // symbols per image per modality
+        int32_t* sym = nullptr;       // [2][B*per_image_total]
+        int32_t* idx = nullptr;
+        const int64_t* stream_base = nullptr;  // device [B] symbol base of each stream inside a modality region
+        // decode side
+        const uint32_t* words = nullptr;
+        const int64_t* stream_off = nullptr;  // device [2][nstreams]
+        const int64_t* stream_len = nullptr;
+        uint64_t* state = nullptr;  // device [2][nstreams][2]
+        int nstreams = 0;
+        bool first[2] = {true, true};
+    };
+
+    void code_part(Coding& cd, int mod, int anchor, const Act& params, const Act& y_slice, const Act& yhat_slice,
+                   int64_t part_off)
+    {
+        if (dry() || rc) return;
+        PartGeom g;
+        g.B = params.n;
+        g.h = params.h;
+        g.w = params.w;
+        g.C = yhat_slice.c;
+        g.anchor = anchor;
+        g.per_image = cd.per_image;
+        const int64_t mod_off = (int64_t)mod * g.B * cd.per_image_total;
+        int32_t* sym = cd.sym + mod_off;
+        int32_t* idx = cd.idx + mod_off;
+        const int64_t* sb = cd.stream_base;  // relative to the modality's region
+        int r;
+        if (cd.encode) {
+            r = launch_ckbd_encode_part(y_slice.p, y_slice.cs, params.p, params.cs, yhat_slice.p, yhat_slice.cs,
+                                        scale_table, g, sym, idx, sb, part_off, s);
+        } else {
+            r = launch_ckbd_index_part(params.p, params.cs, scale_table, g, idx, sb, part_off, s);
+            const int64_t count = (int64_t)g.C * g.h * (g.w / 2) * (cd.per_image ? 1 : g.B);
+            const int64_t poff = cd.per_image ? part_off : part_off * g.B;
+            if (!r)
+                r = launch_rans_decode(cd.words, cd.stream_off + (size_t)mod * cd.nstreams,
+                                       cd.stream_len + (size_t)mod * cd.nstreams, cd.nstreams,
+                                       cd.state + (size_t)mod * cd.nstreams * 2, cd.first[mod] ? 1 : 0, idx, sym, sb, poff,
+                                       count, tables[mod].d, s);
+            cd.first[mod] = false;
+            if (!r) r = launch_ckbd_decode_part(params.p, params.cs, yhat_slice.p, yhat_slice.cs, g, sym, sb, part_off, s);
+        }
+        if (r) fail(r);
+    }
+
+    void bicee(Coding& cd, const Act* y_r, const Act* y_d, const Act& hyp_r, const Act& hyp_d, const Act& yhat_r,
+               const Act& yhat_d)
+    {
+        int c0 = 0;
+        int64_t part_off = 0;
+        const int B = hyp_r.n, h = hyp_r.h, w = hyp_r.w;
+        (void)B;
+        for (size_t i = 0; i < slice_ch.size(); ++i) {
+            const int C = slice_ch[i];
+            const size_t mark = arena.top;
+            const std::string si = std::to_string(i);
+            std::vector<Act> ctx0 = {hyp_r, hyp_d};
+            if (i) {
+                ctx0.push_back(channel_context("rgb_channel_context." + si, view(yhat_r, 0, c0)));
+                ctx0.push_back(channel_context("depth_channel_context." + si, view(yhat_d, 0, c0)));
+            }
+            const Act yr = y_r ? view(*y_r, c0, C) : Act();
+            const Act yd = y_d ? view(*y_d, c0, C) : Act();
+            const Act hr = view(yhat_r, c0, C), hd = view(yhat_d, c0, C);
+            const int64_t part_syms = (int64_t)C * h * (w / 2);
+            auto with = [&](std::initializer_list<Act> head) {
+                std::vector<Act> v(head);
+                v.insert(v.end(), ctx0.begin(), ctx0.end());
+                return v;
+            };
+            // rgb anchor
+            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, with({}));
+            code_part(cd, 0, 1, p_ra, yr, hr, part_off);
+            Act r_loc = conv("rgb_local_context." + si, hr, 1, 2);
+            // depth anchor
+            Act p_da = entropy_params("depth_entropy_parameters_anchor." + si, with({r_loc}));
+            code_part(cd, 1, 1, p_da, yd, hd, part_off);
+            Act d_loc = conv("depth_local_context." + si, hd, 1, 2);
+            // rgb non-anchor
+            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, with({r_loc, d_loc}));
+            code_part(cd, 0, 0, p_rn, yr, hr, part_off + part_syms);
+            Act r_loc2 = conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2);
+            // depth non-anchor
+            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, with({r_loc2, d_loc}));
+            code_part(cd, 1, 0, p_dn, yd, hd, part_off + part_syms);
+            part_off += 2 * part_syms;
+            c0 += C;
+            arena.top = mark;
+        }
+    }
+
+    int run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image);
+    int run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
+                       const int64_t* zlen[2], int B, int zh, int zw, float* xr_dev, float* xd_dev);
+    int ensure_arena(size_t bytes);
+};
+
+int rgbd_elic::ensure_arena(size_t bytes)
+{
+    if (bytes <= arena.cap) return RGBD_OK;
+    if (arena.base) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(arena.base));
+        arena.base = nullptr;
+        arena.cap = 0;
+    }
+    bytes += bytes / 16;
+    HIP_TRY(hipMalloc((void**)&arena.base, bytes));
+    arena.cap = bytes;
+    return RGBD_OK;
+}
+
+int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image)
+{
+    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    const int Ctot = M;
+    const int64_t T = (int64_t)Ctot * h * w;  // y symbols per image per modality
+    const int64_t Tz = (int64_t)N * zh * zw;
+    const int ny = per_image ? B : 1;
+    named.clear();
+    arena.top = 0;
+    rc = 0;
+
+    // ---- persistent buffers of this call
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(8 * B + 64));
+    int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
+    int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
+    int32_t* zsym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
+    int32_t* zidx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
+    const int64_t ycount = per_image ? T : T * B;
+    const int64_t ycap = 5 * ycount + 32, zcap = 5 * Tz + 32;
+    uint32_t* ywords = (uint32_t*)arena.take(sizeof(uint32_t) * (size_t)(2 * ny * ycap));
+    uint32_t* zwords = (uint32_t*)arena.take(sizeof(uint32_t) * (size_t)(2 * B * zcap));
+    int* err = (int*)arena.take(256);
+    dbg_sym = sym;
+    dbg_idx = idx;
+    dbg_per_mod = (int64_t)B * T;
+
+    // meta64 layout: [0,B) y stream_base ; [B,2B) y counts ; [2B,3B) z base ; [3B,4B) z counts ;
+    //                [4B,6B) y out_words (2 mods) ; [6B,8B) z out_words
+    std::vector<int64_t> hmeta((size_t)8 * B + 64, 0);
+    for (int b = 0; b < B; ++b) {
+        hmeta[b] = per_image ? (int64_t)b * T : 0;
+        hmeta[B + b] = ycount;
+        hmeta[2 * B + b] = (int64_t)b * Tz;
+        hmeta[3 * B + b] = Tz;
+    }
+    if (!dry()) {
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(err, 0, 256, s));
+    }
+
+    // ---- analysis
+    Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
+    if (!dry()) {
+        int r = launch_nchw_to_nhwc16(rgb_dev, B, 3, H, W, rgb.p, rgb.cs, s);
+        if (!r) r = launch_nchw_to_nhwc16(depth_dev, B, 1, H, W, depth.p, depth.cs, s);
+        if (r) return r;
+    }
+    Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
+    Act z_r, z_d;
+    {
+        const size_t mark = arena.top;
+        Act yr_t, yd_t;
+        g_a(rgb, depth, &yr_t, &yd_t);
+        copy_ch(yr_t, y_r);
+        copy_ch(yd_t, y_d);
+        arena.top = mark;
+    }
+    h_a(y_r, y_d, &z_r, &z_d);
+    named["y_r"] = y_r;
+    named["y_d"] = y_d;
+    named["z_r"] = z_r;
+    named["z_d"] = z_d;
+
+    // ---- z: quantise, encode, dequantise (entropy_models.py:437-446)
+    Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+    if (!dry() && !rc) {
+        const Act* zz[2] = {&z_r, &z_d};
+        const Act* zo[2] = {&zh_r, &zh_d};
+        const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
+        for (int m = 0; m < 2 && !rc; ++m) {
+            float* md = dense_of(med[m]);
+            if (!md) break;
+            int32_t* zs = zsym + (size_t)m * B * Tz;
+            int32_t* zi = zidx + (size_t)m * B * Tz;
+            int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
+            if (!r)
+                r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, tables[2 + m].d,
+                                       zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
+            if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+            if (r) fail(r);
+        }
+    }
+    named["zhat_r"] = zh_r;
+    named["zhat_d"] = zh_d;
+
+    // ---- hyper synthesis + Bi-CEE
+    Act hyp_r, hyp_d;
+    h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+    named["hyper_r"] = hyp_r;
+    named["hyper_d"] = hyp_d;
+    Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+    named["yhat_r"] = yhat_r;
+    named["yhat_d"] = yhat_d;
+    Coding cd;
+    cd.encode = true;
+    cd.per_image = per_image;
+    cd.per_image_total = T;
+    cd.sym = sym;
+    cd.idx = idx;
+    cd.stream_base = meta64;
+    bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+
+    if (!dry() && !rc) {
+        for (int m = 0; m < 2 && !rc; ++m) {
+            const int r = launch_rans_encode(sym + (size_t)m * B * T, idx + (size_t)m * B * T, meta64, meta64 + B, ny,
+                                             tables[m].d, ywords + (size_t)m * ny * ycap, ycap,
+                                             meta64 + 4 * B + (size_t)m * B, err, s);
+            if (r) fail(r);
+        }
+    }
+    if (rc) return rc;
+    if (dry()) return RGBD_OK;
+
+    // ---- fetch the streams
+    std::vector<int64_t> ow((size_t)4 * B);
+    int herr = 0;
+    HIP_TRY(hipMemcpyAsync(ow.data(), meta64 + 4 * B, sizeof(int64_t) * 4 * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (herr) return RGBD_ENOSPC;
+    for (int m = 0; m < 2; ++m) {
+        streams[m][0].assign(ny, {});
+        streams[m][1].assign(B, {});
+        for (int i = 0; i < ny; ++i) {
+            const int64_t nw = ow[(size_t)m * B + i];
+            streams[m][0][i].resize((size_t)nw * 4);
+            const uint32_t* src = ywords + ((size_t)m * ny + i) * ycap + (ycap - nw);
+            HIP_TRY(hipMemcpyAsync(streams[m][0][i].data(), src, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
+        }
+        for (int i = 0; i < B; ++i) {
+            const int64_t nw = ow[(size_t)2 * B + (size_t)m * B + i];
+            streams[m][1][i].resize((size_t)nw * 4);
+            const uint32_t* src = zwords + ((size_t)m * B + i) * zcap + (zcap - nw);
+            HIP_TRY(hipMemcpyAsync(streams[m][1][i].data(), src, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return RGBD_OK;
+}
+
+int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
+                              const int64_t* zlen[2], int B, int zh, int zw, float* xr_dev, float* xd_dev)
+{
+    const int h = zh * 4, w = zw * 4, H = zh * 64, W = zw * 64;
+    const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
+    const int per_image = (n_y == B && !(B == 1)) ? 1 : (n_y == 1 ? (B == 1 ? 1 : 0) : -1);
+    if (per_image < 0) return RGBD_EINVAL;
+    named.clear();
+    arena.top = 0;
+    rc = 0;
+
+    // ---- upload streams: words region = [y rgb | y depth | z rgb | z depth]
+    const int ns_y = n_y, ns_z = B;
+    std::vector<int64_t> hmeta;  // y: off[2][ns_y], len[2][ns_y]; z: off[2][B], len[2][B]; y base[B]; z base[B]
+    std::vector<uint32_t> hwords;
+    auto push_streams = [&](const uint8_t* const* arr, const int64_t* len, int n, std::vector<int64_t>& off,
+                            std::vector<int64_t>& ln) -> int {
+        for (int i = 0; i < n; ++i) {
+            if (len[i] < 8 || (len[i] & 3)) return RGBD_EINVAL;
+            off.push_back((int64_t)hwords.size());
+            ln.push_back(len[i] / 4);
+            const size_t o = hwords.size();
+            hwords.resize(o + (size_t)len[i] / 4);
+            memcpy(hwords.data() + o, arr[i], (size_t)len[i]);
+        }
+        return RGBD_OK;
+    };
+    std::vector<int64_t> yoff, ylen_w, zoff, zlen_w;
+    for (int m = 0; m < 2; ++m) {
+        const int r = push_streams(ys[m], ylen[m], ns_y, yoff, ylen_w);
+        if (r) return r;
+    }
+    for (int m = 0; m < 2; ++m) {
+        const int r = push_streams(zs[m], zlen[m], ns_z, zoff, zlen_w);
+        if (r) return r;
+    }
+    hmeta.insert(hmeta.end(), yoff.begin(), yoff.end());
+    hmeta.insert(hmeta.end(), ylen_w.begin(), ylen_w.end());
+    hmeta.insert(hmeta.end(), zoff.begin(), zoff.end());
+    hmeta.insert(hmeta.end(), zlen_w.begin(), zlen_w.end());
+    const size_t o_ybase = hmeta.size();
+    for (int b = 0; b < B; ++b) hmeta.push_back(per_image ? (int64_t)b * T : 0);
+    const size_t o_zbase = hmeta.size();
+    for (int b = 0; b < B; ++b) hmeta.push_back((int64_t)b * Tz);
+
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * hmeta.size());
+    uint32_t* words = (uint32_t*)arena.take(sizeof(uint32_t) * (hwords.size() + 4));
+    uint64_t* state = (uint64_t*)arena.take(sizeof(uint64_t) * (size_t)(4 * (ns_y + ns_z)));
+    int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
+    int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
+    int32_t* zsym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
+    int32_t* zidx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
+    dbg_sym = sym;
+    dbg_idx = idx;
+    dbg_per_mod = (int64_t)B * T;
+    if (!dry()) {
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(words, hwords.data(), sizeof(uint32_t) * hwords.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope at return; keep it simple
+    }
+    const int64_t* d_yoff = meta64;
+    const int64_t* d_ylen = meta64 + 2 * ns_y;
+    const int64_t* d_zoff = meta64 + 4 * ns_y;
+    const int64_t* d_zlen = meta64 + 4 * ns_y + 2 * ns_z;
+    const int64_t* d_ybase = meta64 + o_ybase;
+    const int64_t* d_zbase = meta64 + o_zbase;
+
+    // ---- z decode (entropy_models.py:442-446)
+    Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+    if (!dry()) {
+        const Act* zo[2] = {&zh_r, &zh_d};
+        const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
+        for (int m = 0; m < 2 && !rc; ++m) {
+            float* md = dense_of(med[m]);
+            if (!md) break;
+            int32_t* zs_ = zsym + (size_t)m * B * Tz;
+            int32_t* zi_ = zidx + (size_t)m * B * Tz;
+            // indexes = channel id in (c, row, col) order: the quantiser's index writer on a zeroed tensor
+            int r = launch_fill_zero(zo[m]->p, zo[m]->elems(), s);
+            if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s);
+            if (!r)
+                r = launch_rans_decode(words, d_zoff + (size_t)m * ns_z, d_zlen + (size_t)m * ns_z, ns_z,
+                                       state + (size_t)4 * ns_y + (size_t)m * ns_z * 2, 1, zi_, zs_, d_zbase, 0, Tz,
+                                       tables[2 + m].d, s);
+            if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+            if (r) fail(r);
+        }
+    }
+    named["zhat_r"] = zh_r;
+    named["zhat_d"] = zh_d;
+
+    Act hyp_r, hyp_d;
+    h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+    named["hyper_r"] = hyp_r;
+    named["hyper_d"] = hyp_d;
+    Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+    named["yhat_r"] = yhat_r;
+    named["yhat_d"] = yhat_d;
+    Coding cd;
+    cd.encode = false;
+    cd.per_image = per_image;
+    cd.per_image_total = T;
+    cd.sym = sym;
+    cd.idx = idx;
+    cd.stream_base = d_ybase;
+    cd.words = words;
+    cd.stream_off = d_yoff;
+    cd.stream_len = d_ylen;
+    cd.state = state;
+    cd.nstreams = ns_y;
+    bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
+
+    Act xr, xd;
+    g_s(yhat_r, yhat_d, &xr, &xd);
+    if (rc) return rc;
+    if (dry()) return RGBD_OK;
+    int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 1, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 1, s);
+    return r;
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int rgbd_abi_version(void) { return RGBD_AMD_ABI_VERSION; }
+
+// ops.cpp:24-81 restated (host, one-off table construction)
+int rgbd_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, uint32_t* cdf_out)
+{
+    if (!pmf || !cdf_out || n <= 0 || precision < 1 || precision > 16) return RGBD_EINVAL;
+    std::vector<uint32_t> c((size_t)n + 1);
+    c[0] = 0;
+    const float scale = (float)(1 << precision);
+    for (int i = 0; i < n; ++i) c[(size_t)i + 1] = (uint32_t)std::round(pmf[i] * scale);
+    uint32_t total = 0;
+    for (uint32_t v : c) total += v;
+    if (!total) return RGBD_EINVAL;
+    for (uint32_t& v : c) v = (uint32_t)((((uint64_t)1 << precision) * v) / total);
+    for (size_t i = 1; i < c.size(); ++i) c[i] += c[i - 1];
+    c.back() = 1u << precision;
+    const int m = n + 1;
+    for (int i = 0; i < m - 1; ++i) {
+        if (c[i] != c[i + 1]) continue;
+        uint32_t best = ~0u;
+        int donor = -1;
+        for (int j = 0; j < m - 1; ++j) {
+            const uint32_t f = c[j + 1] - c[j];
+            if (f > 1 && f < best) {
+                best = f;
+                donor = j;
+            }
+        }
+        if (donor < 0) return RGBD_EINVAL;
+        if (donor < i)
+            for (int j = donor + 1; j <= i; ++j) c[j]--;
+        else
+            for (int j = i + 1; j <= donor; ++j) c[j]++;
+    }
+    memcpy(cdf_out, c.data(), sizeof(uint32_t) * c.size());
+    return RGBD_OK;
+}
+
+int rgbd_tables_create(const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                       int32_t n_cdf, rgbd_tables** out)
+{
+    if (!out) return RGBD_EINVAL;
+    std::unique_ptr<rgbd_tables> t(new rgbd_tables());
+    const int r = build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &t->ts);
+    if (r) return r;
+    *out = t.release();
+    return RGBD_OK;
+}
+
+void rgbd_tables_destroy(rgbd_tables* t)
+{
+    if (!t) return;
+    if (t->ts.blob) (void)hipFree(t->ts.blob);
+    delete t;
+}
+
+int64_t rgbd_rans_max_bytes(int64_t n) { return 4 * (5 * n + 32); }
+
+int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t* indexes, int64_t n, uint8_t* out,
+                     int64_t cap, int64_t* out_len)
+{
+    if (!t || !t->ts.ready || n < 0 || !out || !out_len || (n && (!symbols || !indexes))) return RGBD_EINVAL;
+    for (int64_t i = 0; i < n; ++i)
+        if (indexes[i] < 0 || indexes[i] >= t->ts.d.nrows) return RGBD_EINVAL;
+    const int64_t capw = 5 * n + 32;
+    int32_t *dsym = nullptr, *didx = nullptr;
+    uint32_t* dout = nullptr;
+    int64_t* dmeta = nullptr;
+    int* derr = nullptr;
+    int rc = RGBD_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(dsym);
+        (void)hipFree(didx);
+        (void)hipFree(dout);
+        (void)hipFree(dmeta);
+        (void)hipFree(derr);
+    };
+    HIP_TRY(hipMalloc((void**)&dsym, sizeof(int32_t) * (size_t)(n + 1)));
+    HIP_TRY(hipMalloc((void**)&didx, sizeof(int32_t) * (size_t)(n + 1)));
+    HIP_TRY(hipMalloc((void**)&dout, sizeof(uint32_t) * (size_t)capw));
+    HIP_TRY(hipMalloc((void**)&dmeta, sizeof(int64_t) * 4));
+    HIP_TRY(hipMalloc((void**)&derr, sizeof(int)));
+    const int64_t hmeta[4] = {0, n, 0, 0};
+    hipError_t e = hipSuccess;
+    if (n) {
+        e = hipMemcpy(dsym, symbols, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(didx, indexes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemcpy(dmeta, hmeta, sizeof(hmeta), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(derr, 0, sizeof(int));
+    if (e != hipSuccess) {
+        cleanup();
+        return RGBD_EHIP;
+    }
+    rc = launch_rans_encode(dsym, didx, dmeta, dmeta + 1, 1, t->ts.d, dout, capw, dmeta + 2, derr, nullptr);
+    int64_t nw = 0;
+    int herr = 0;
+    if (!rc) {
+        e = hipMemcpy(&nw, dmeta + 2, sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&herr, derr, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = RGBD_EHIP;
+        else if (herr) rc = RGBD_ENOSPC;
+        else if (nw * 4 > cap) rc = RGBD_ENOSPC;
+        else {
+            e = hipMemcpy(out, dout + (capw - nw), (size_t)nw * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = RGBD_EHIP;
+            *out_len = nw * 4;
+        }
+    }
+    cleanup();
+    return rc;
+}
+
+struct rgbd_rans_decoder {
+    uint32_t* words = nullptr;
+    int64_t nwords = 0;
+    int64_t* meta = nullptr;   // [off, len, base]
+    uint64_t* state = nullptr;  // [x, pos]
+    bool fresh = false;
+};
+
+int rgbd_rans_decoder_create(rgbd_rans_decoder** out)
+{
+    if (!out) return RGBD_EINVAL;
+    std::unique_ptr<rgbd_rans_decoder> d(new rgbd_rans_decoder());
+    HIP_TRY(hipMalloc((void**)&d->meta, sizeof(int64_t) * 4));
+    HIP_TRY(hipMalloc((void**)&d->state, sizeof(uint64_t) * 2));
+    *out = d.release();
+    return RGBD_OK;
+}
+
+int rgbd_rans_decoder_set_stream(rgbd_rans_decoder* d, const uint8_t* stream, int64_t nbytes)
+{
+    if (!d || !stream || nbytes < 8 || (nbytes & 3)) return RGBD_EINVAL;
+    if (d->words) (void)hipFree(d->words);
+    d->words = nullptr;
+    HIP_TRY(hipMalloc((void**)&d->words, (size_t)nbytes));
+    HIP_TRY(hipMemcpy(d->words, stream, (size_t)nbytes, hipMemcpyHostToDevice));
+    d->nwords = nbytes / 4;
+    const int64_t hm[4] = {0, d->nwords, 0, 0};
+    HIP_TRY(hipMemcpy(d->meta, hm, sizeof(hm), hipMemcpyHostToDevice));
+    d->fresh = true;
+    return RGBD_OK;
+}
+
+int rgbd_rans_decoder_decode(rgbd_rans_decoder* d, const rgbd_tables* t, const int32_t* indexes, int64_t n,
+                             int32_t* symbols_out)
+{
+    if (!d || !d->words || !t || !t->ts.ready || n < 0 || (n && (!indexes || !symbols_out))) return RGBD_EINVAL;
+    if (!n) return RGBD_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (indexes[i] < 0 || indexes[i] >= t->ts.d.nrows) return RGBD_EINVAL;
+    int32_t *didx = nullptr, *dsym = nullptr;
+    HIP_TRY(hipMalloc((void**)&didx, sizeof(int32_t) * (size_t)n));
+    HIP_TRY(hipMalloc((void**)&dsym, sizeof(int32_t) * (size_t)n));
+    int rc = RGBD_OK;
+    if (hipMemcpy(didx, indexes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = RGBD_EHIP;
+    if (!rc)
+        rc = launch_rans_decode(d->words, d->meta, d->meta + 1, 1, d->state, d->fresh ? 1 : 0, didx, dsym, d->meta + 2, 0, n,
+                                t->ts.d, nullptr);
+    if (!rc && hipMemcpy(symbols_out, dsym, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = RGBD_EHIP;
+    if (!rc) d->fresh = false;
+    (void)hipFree(didx);
+    (void)hipFree(dsym);
+    return rc;
+}
+
+void rgbd_rans_decoder_destroy(rgbd_rans_decoder* d)
+{
+    if (!d) return;
+    (void)hipFree(d->words);
+    (void)hipFree(d->meta);
+    (void)hipFree(d->state);
+    delete d;
+}
+
+int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
+                     const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
+                     int32_t act, const float* residual_dev, float* y_dev, void* stream)
+{
+    if (!x_dev || !weight || !y_dev || n <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k > 5 || stride < 1 || stride > 2)
+        return RGBD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    HostTensor hw, hb;
+    hw.shape = transposed ? std::vector<int64_t>{cin, cout, k, k} : std::vector<int64_t>{cout, cin, k, k};
+    hw.v.assign(weight, weight + (size_t)cin * cout * k * k);
+    if (bias) {
+        hb.shape = {cout};
+        hb.v.assign(bias, bias + cout);
+    }
+    PackedConv pc;
+    int rc = pack_conv(hw, bias ? &hb : nullptr, transposed != 0, &pc);
+    if (rc) return rc;
+    int OH, OW;
+    if (!transposed) {
+        OH = (h + 2 * pad - k) / stride + 1;
+        OW = (w + 2 * pad - k) / stride + 1;
+    } else {
+        OH = (h - 1) * stride - 2 * pad + k + (stride - 1);
+        OW = (w - 1) * stride - 2 * pad + k + (stride - 1);
+    }
+    float *xin = nullptr, *yout = nullptr, *res = nullptr;
+    const size_t xb = (size_t)n * h * w * pc.cin_pad * sizeof(float), yb = (size_t)n * OH * OW * pc.cout_pad * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&xin, xb));
+    HIP_TRY(hipMalloc((void**)&yout, yb));
+    rc = launch_nchw_to_nhwc16(x_dev, n, cin, h, w, xin, pc.cin_pad, s);
+    if (!rc && residual_dev) {
+        HIP_TRY(hipMalloc((void**)&res, yb));
+        rc = launch_nchw_to_nhwc16(residual_dev, n, cout, OH, OW, res, pc.cout_pad, s);
+    }
+    if (!rc) {
+        ConvArgs a{};
+        a.x = xin;
+        a.N = n;
+        a.H = h;
+        a.W = w;
+        a.xcs = pc.cin_pad;
+        a.cin_pad = pc.cin_pad;
+        a.w = pc.w;
+        a.ntaps_total = k * k;
+        a.bias = pc.bias;
+        a.y = yout;
+        a.OH = OH;
+        a.OW = OW;
+        a.ycs = pc.cout_pad;
+        a.cout_pad = pc.cout_pad;
+        make_taps(pc, stride, pad, &a);
+        a.GH = transposed ? h : OH;
+        a.GW = transposed ? w : OW;
+        a.act = act;
+        if (res) {
+            a.res1 = res;
+            a.r1cs = pc.cout_pad;
+        }
+        rc = launch_conv(a, s);
+    }
+    if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, cout, OH, OW, pc.cout_pad, y_dev, 0, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) rc = RGBD_EHIP;
+    (void)hipFree(xin);
+    (void)hipFree(yout);
+    (void)hipFree(res);
+    (void)hipFree(pc.w);
+    (void)hipFree(pc.bias);
+    return rc;
+}
+
+// ---- codec ------------------------------------------------------------------------------------
+int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out)
+{
+    if (!out || !slice_ch || n_slices <= 0 || N % 16 || M % 16) return RGBD_EINVAL;
+    int sum = 0;
+    for (int i = 0; i < n_slices; ++i) {
+        if (slice_ch[i] <= 0 || slice_ch[i] % 16) return RGBD_EINVAL;
+        sum += slice_ch[i];
+    }
+    if (sum != M) return RGBD_EINVAL;
+    rgbd_elic* m = new rgbd_elic();
+    m->N = N;
+    m->M = M;
+    m->slice_ch.assign(slice_ch, slice_ch + n_slices);
+    *out = m;
+    return RGBD_OK;
+}
+
+void rgbd_elic_destroy(rgbd_elic* m)
+{
+    if (!m) return;
+    for (auto& kv : m->convs) {
+        (void)hipFree(kv.second.w);
+        (void)hipFree(kv.second.bias);
+    }
+    for (auto& kv : m->dense) (void)hipFree(kv.second);
+    for (auto& t : m->tables)
+        if (t.blob) (void)hipFree(t.blob);
+    if (m->scale_table) (void)hipFree(m->scale_table);
+    if (m->arena.base) (void)hipFree(m->arena.base);
+    delete m;
+}
+
+int rgbd_elic_set_tensor(rgbd_elic* m, const char* name, const float* data, const int64_t* shape, int32_t ndim)
+{
+    if (!m || !name || !data || !shape || ndim < 1 || ndim > 4) return RGBD_EINVAL;
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0) return RGBD_EINVAL;
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.v.assign(data, data + n);
+    m->raw[name] = std::move(t);
+    m->finalized = false;
+    return RGBD_OK;
+}
+
+int rgbd_elic_set_tables(rgbd_elic* m, int32_t which, const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes,
+                         const int32_t* offsets, int32_t n_cdf)
+{
+    if (!m || which < 0 || which > 3) return RGBD_EINVAL;
+    return build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &m->tables[which]);
+}
+
+int rgbd_elic_set_scale_table(rgbd_elic* m, const float* table, int32_t n)
+{
+    if (!m || !table || n != 64) return RGBD_EINVAL;
+    if (!m->scale_table) HIP_TRY(hipMalloc((void**)&m->scale_table, 64 * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->scale_table, table, 64 * sizeof(float), hipMemcpyHostToDevice));
+    return RGBD_OK;
+}
+
+static bool ends_with(const std::string& s, const char* suf)
+{
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int rgbd_elic_finalize(rgbd_elic* m)
+{
+    if (!m) return RGBD_EINVAL;
+    for (auto& kv : m->convs) {
+        (void)hipFree(kv.second.w);
+        (void)hipFree(kv.second.bias);
+    }
+    m->convs.clear();
+    for (auto& kv : m->dense) (void)hipFree(kv.second);
+    m->dense.clear();
+    for (auto& kv : m->raw) {
+        const std::string& name = kv.first;
+        const HostTensor& t = kv.second;
+        if (ends_with(name, ".weight") && t.shape.size() == 4) {
+            // ConvTranspose2d layers of this model: g_s stages 1/6/12/17 and the h_s deconvs
+            const bool transposed = name.find(".deconv.") != std::string::npos ||
+                                    (name.rfind("g_s.", 0) == 0 &&
+                                     (ends_with(name, "_transform.1.weight") || ends_with(name, "_transform.6.weight") ||
+                                      ends_with(name, "_transform.12.weight") || ends_with(name, "_transform.17.weight")));
+            const std::string bname = name.substr(0, name.size() - 6) + "bias";
+            auto bit = m->raw.find(bname);
+            PackedConv pc;
+            const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc);
+            if (r) return r;
+            m->convs[name] = pc;
+        } else if (ends_with(name, ".weight") && t.shape.size() == 2) {
+            float* d = nullptr;
+            HIP_TRY(hipMalloc((void**)&d, t.v.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(d, t.v.data(), t.v.size() * sizeof(float), hipMemcpyHostToDevice));
+            m->dense[name] = d;
+        } else if (ends_with(name, "_entropy_bottleneck.quantiles")) {
+            // medians = quantiles[:, 0, 1]  (entropy_models.py:316-318)
+            const int C = (int)t.shape[0];
+            std::vector<float> med(C);
+            for (int c = 0; c < C; ++c) med[c] = t.v[(size_t)c * 3 + 1];
+            float* d = nullptr;
+            HIP_TRY(hipMalloc((void**)&d, C * sizeof(float)));
+            HIP_TRY(hipMemcpy(d, med.data(), C * sizeof(float), hipMemcpyHostToDevice));
+            m->dense[name.substr(0, name.size() - 9) + "medians"] = d;
+        }
+    }
+    m->finalized = true;
+    return RGBD_OK;
+}
+
+static int check_ready(const rgbd_elic* m)
+{
+    if (!m || !m->finalized || !m->scale_table) return RGBD_ESTATE;
+    for (const auto& t : m->tables)
+        if (!t.ready) return RGBD_ESTATE;
+    return RGBD_OK;
+}
+
+int rgbd_elic_compress(rgbd_elic* m, const float* rgb_dev, const float* depth_dev, int32_t B, int32_t H, int32_t W,
+                       int32_t per_image_streams, void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (!rgb_dev || !depth_dev || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64) return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    const int per_image = (per_image_streams || B == 1) ? 1 : 0;
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    return m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
+}
+
+int rgbd_elic_stream_count(const rgbd_elic* m, int32_t modality, int32_t kind)
+{
+    if (!m || modality < 0 || modality > 1 || kind < 0 || kind > 1) return RGBD_EINVAL;
+    return (int)m->streams[modality][kind].size();
+}
+
+int rgbd_elic_stream(const rgbd_elic* m, int32_t modality, int32_t kind, int32_t index, const uint8_t** data,
+                     int64_t* nbytes)
+{
+    if (!m || !data || !nbytes || modality < 0 || modality > 1 || kind < 0 || kind > 1) return RGBD_EINVAL;
+    const auto& v = m->streams[modality][kind];
+    if (index < 0 || index >= (int)v.size()) return RGBD_EINVAL;
+    *data = v[index].data();
+    *nbytes = (int64_t)v[index].size();
+    return RGBD_OK;
+}
+
+int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_t* y_rgb_len, int32_t n_y,
+                         const uint8_t* const* y_depth, const int64_t* y_depth_len, const uint8_t* const* z_rgb,
+                         const int64_t* z_rgb_len, const uint8_t* const* z_depth, const int64_t* z_depth_len, int32_t B,
+                         int32_t zh, int32_t zw, float* xr_dev, float* xd_dev, void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (!y_rgb || !y_depth || !z_rgb || !z_depth || !xr_dev || !xd_dev || B <= 0 || zh <= 0 || zw <= 0) return RGBD_EINVAL;
+    if (n_y != 1 && n_y != B) return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    const uint8_t* const* ys[2] = {y_rgb, y_depth};
+    const int64_t* yl[2] = {y_rgb_len, y_depth_len};
+    const uint8_t* const* zs[2] = {z_rgb, z_depth};
+    const int64_t* zl[2] = {z_rgb_len, z_depth_len};
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    return m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
+}
+
+int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t cap_floats, int32_t* shape_out)
+{
+    if (!m || !name || !shape_out) return RGBD_EINVAL;
+    auto it = m->named.find(name);
+    if (it == m->named.end()) return RGBD_EINVAL;
+    const Act& a = it->second;
+    shape_out[0] = a.n;
+    shape_out[1] = a.c;
+    shape_out[2] = a.h;
+    shape_out[3] = a.w;
+    if (!data) return RGBD_OK;
+    const int64_t need = (int64_t)a.n * a.c * a.h * a.w;
+    if (cap_floats < need) return RGBD_ENOSPC;
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (size_t)need * sizeof(float)));
+    int r = launch_nhwc_to_nchw_clamp(a.p, a.n, a.c, a.h, a.w, a.cs, tmp, 0, m->s);
+    if (!r && hipMemcpy(data, tmp, (size_t)need * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) r = RGBD_EHIP;
+    (void)hipFree(tmp);
+    return r;
+}
+
+int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n)
+{
+    if (!m || !n || modality < 0 || modality > 1 || !m->dbg_sym) return RGBD_EINVAL;
+    *n = m->dbg_per_mod;
+    if (!symbols || !indexes) return RGBD_OK;
+    if (cap < m->dbg_per_mod) return RGBD_ENOSPC;
+    HIP_TRY(hipStreamSynchronize(m->s));
+    HIP_TRY(hipMemcpy(symbols, m->dbg_sym + (size_t)modality * m->dbg_per_mod, sizeof(int32_t) * (size_t)m->dbg_per_mod,
+                      hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(indexes, m->dbg_idx + (size_t)modality * m->dbg_per_mod, sizeof(int32_t) * (size_t)m->dbg_per_mod,
+                      hipMemcpyDeviceToHost));
+    return RGBD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,451 @@
+// Entropy stage of the ELIC_united path on gfx950: checkerboard quantise/index/scatter (utils/ckbd.py:83-125,
+// entropy_models.py:118-146,561-568), the factorised-prior z path (entropy_models.py:195-266,431-446) and the
+// 64-bit-state rANS coder (cpp_exts/rans/rans_interface.cpp:99-351 + third_party/ryg_rans/rans64.h:59-142).
+//
+// Symbols, indexes and bitstreams stay in HBM: the reference's 44 device<->host round trips per image disappear.
+// The coder is integer work and bit-exact against the oracle by construction; streams are little-endian u32 words.
+// One wavefront serves one stream: all 64 lanes expand symbols to (start, freq) pairs / fetch table metadata for a
+// chunk in parallel, then lane 0 walks the serial state recurrence out of LDS.
+#include "common.h"
+
+#define PROB_BITS 16
+#define ESC_BITS 4
+#define ESC_MAX 15u
+#define RANS_LOW (1ull << 31)
+#define CHUNK 512
+#define LUT_BITS 8
+#define LUT_N ((1 << LUT_BITS) + 1)
+
+// ---------------------------------------------------------------------------------------------
+// checkerboard helpers: column of packed index k on a given row (utils/ckbd.py:51-64)
+__device__ __forceinline__ int ckbd_col(int row, int k, int anchor)
+{
+    return 2 * k + (anchor ? (1 - (row & 1)) : (row & 1));
+}
+
+__device__ __forceinline__ int scale_to_index(const float* tbl, float s)
+{
+    // #{i < 63 : table[i] < max(s, 0.11)}  ==  63 - #{i < 63 : max(s, 0.11) <= table[i]}
+    s = fmaxf(s, 0.11f);
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tbl[mid] < s) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int64_t sym_pos(const PartGeom& g, const int64_t* stream_base, int64_t part_off, int b,
+                                           int c, int row, int k)
+{
+    const int64_t w2 = g.w / 2;
+    if (g.per_image) return stream_base[b] + part_off + ((int64_t)c * g.h + row) * w2 + k;
+    return stream_base[0] + part_off * g.B + (((int64_t)b * g.C + c) * g.h + row) * w2 + k;
+}
+
+// mode 0: encode (quantise + index + scatter yhat), 1: index only, 2: decode (yhat = sym + mean)
+template <int MODE>
+__global__ void ckbd_part_kernel(const float* __restrict__ y, int ycs, const float* __restrict__ params, int pcs,
+                                 float* __restrict__ yhat, int yhcs, const float* __restrict__ table, PartGeom g,
+                                 int32_t* __restrict__ sym, int32_t* __restrict__ idx,
+                                 const int64_t* __restrict__ stream_base, int64_t part_off)
+{
+    __shared__ float tbl[64];
+    if (threadIdx.x < 64) tbl[threadIdx.x] = table[threadIdx.x];
+    __syncthreads();
+    const int w2 = g.w / 2;
+    const size_t total = (size_t)g.B * g.h * w2 * g.C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.C);
+        size_t t = i / g.C;
+        const int k = (int)(t % w2);
+        t /= w2;
+        const int row = (int)(t % g.h);
+        const int b = (int)(t / g.h);
+        const int col = ckbd_col(row, k, g.anchor);
+        const size_t pix = ((size_t)b * g.h + row) * g.w + col;
+        const float scale = params[pix * pcs + c];
+        const float mean = params[pix * pcs + g.C + c];
+        const int64_t pos = sym_pos(g, stream_base, part_off, b, c, row, k);
+        if (MODE == 0) {
+            const float r = rintf(y[pix * ycs + c] - mean);  // round half to even, like torch.round
+            const int s = (int)r;
+            sym[pos] = s;
+            idx[pos] = scale_to_index(tbl, scale);
+            yhat[pix * yhcs + c] = (float)s + mean;
+        } else if (MODE == 1) {
+            idx[pos] = scale_to_index(tbl, scale);
+        } else {
+            yhat[pix * yhcs + c] = (float)sym[pos] + mean;
+        }
+        if (MODE != 1 && g.anchor) {
+            // the anchor pass defines the whole slice: off-parity positions start at zero (ckbd.py:66-72)
+            const size_t opix = ((size_t)b * g.h + row) * g.w + (col ^ 1);
+            yhat[opix * yhcs + c] = 0.f;
+        }
+    }
+}
+
+static inline unsigned part_grid(const PartGeom& g)
+{
+    size_t work = (size_t)g.B * g.h * (g.w / 2) * g.C;
+    size_t n = (work + 255) / 256;
+    return (unsigned)(n < 1 ? 1 : (n > 2048 ? 2048 : n));
+}
+
+int launch_ckbd_encode_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs,
+                            const float* table, PartGeom g, int32_t* sym, int32_t* idx, const int64_t* stream_base,
+                            int64_t part_off, hipStream_t s)
+{
+    if (g.w % 2) return RGBD_EINVAL;
+    hipLaunchKernelGGL(ckbd_part_kernel<0>, dim3(part_grid(g)), dim3(256), 0, s, y, ycs, params, pcs, yhat, yhcs, table,
+                       g, sym, idx, stream_base, part_off);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+int launch_ckbd_index_part(const float* params, int pcs, const float* table, PartGeom g, int32_t* idx,
+                           const int64_t* stream_base, int64_t part_off, hipStream_t s)
+{
+    if (g.w % 2) return RGBD_EINVAL;
+    hipLaunchKernelGGL(ckbd_part_kernel<1>, dim3(part_grid(g)), dim3(256), 0, s, (const float*)nullptr, 0, params, pcs,
+                       (float*)nullptr, 0, table, g, (int32_t*)nullptr, idx, stream_base, part_off);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs, PartGeom g, const int32_t* sym,
+                            const int64_t* stream_base, int64_t part_off, hipStream_t s)
+{
+    if (g.w % 2) return RGBD_EINVAL;
+    hipLaunchKernelGGL(ckbd_part_kernel<2>, dim3(part_grid(g)), dim3(256), 0, s, (const float*)nullptr, 0, params, pcs,
+                       yhat, yhcs, params /*unused table*/, g, const_cast<int32_t*>(sym), (int32_t*)nullptr, stream_base,
+                       part_off);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// z path: sym = round(z - median_c), index = c, per-image streams in (c, row, col) order
+__global__ void z_quant_kernel(const float* __restrict__ z, int zcs, int B, int h, int w, int C,
+                               const float* __restrict__ med, int32_t* __restrict__ sym, int32_t* __restrict__ idx)
+{
+    const size_t total = (size_t)B * h * w * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t pix = i / C;
+        const size_t hw = pix % ((size_t)h * w);
+        const size_t b = pix / ((size_t)h * w);
+        const size_t pos = (b * C + c) * (size_t)h * w + hw;
+        sym[pos] = (int)rintf(z[pix * zcs + c] - med[c]);
+        idx[pos] = c;
+    }
+}
+
+int launch_z_quant(const float* z, int zcs, int B, int h, int w, int C, const float* medians, int32_t* sym, int32_t* idx,
+                   hipStream_t s)
+{
+    const size_t work = (size_t)B * h * w * C;
+    hipLaunchKernelGGL(z_quant_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, z, zcs, B, h, w, C, medians,
+                       sym, idx);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+__global__ void z_dequant_kernel(const int32_t* __restrict__ sym, int B, int h, int w, int C,
+                                 const float* __restrict__ med, float* __restrict__ zhat, int zcs)
+{
+    const size_t total = (size_t)B * h * w * zcs;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % zcs);
+        const size_t pix = i / zcs;
+        const size_t hw = pix % ((size_t)h * w);
+        const size_t b = pix / ((size_t)h * w);
+        float v = 0.f;
+        if (c < C) v = (float)sym[(b * C + c) * (size_t)h * w + hw] + med[c];
+        zhat[pix * zcs + c] = v;
+    }
+}
+
+int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float* medians, float* zhat, int zcs,
+                     hipStream_t s)
+{
+    const size_t work = (size_t)B * h * w * zcs;
+    hipLaunchKernelGGL(z_dequant_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, sym, B, h, w, C, medians,
+                       zhat, zcs);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rANS encoder.  Lanes expand a chunk of symbols to coded items in parallel; lane 0 then runs the state recurrence
+// over the chunk in reverse (rans_interface.cpp:167-185 pops from the back).
+struct EncItem {
+    uint32_t sf;   // start | freq << 16
+    uint32_t raw;  // escape payload
+    uint32_t esc;  // 1 if the symbol hit the escape slot
+    uint32_t pad;
+};
+
+__device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t freq, uint32_t* out, int64_t& w)
+{
+    const uint64_t lim = ((RANS_LOW >> PROB_BITS) << 32) * (uint64_t)freq;  // rans64.h:82-83
+    if (x >= lim) {
+        out[--w] = (uint32_t)x;
+        x >>= 32;
+    }
+    // exact x / freq through an fp64 estimate (|error| <= 1) and an integer fix-up
+    uint64_t qn = (uint64_t)(__ull2double_rz(x) * (1.0 / (double)freq));
+    int64_t r = (int64_t)(x - qn * (uint64_t)freq);
+    while (r < 0) {
+        --qn;
+        r += freq;
+    }
+    while (r >= (int64_t)freq) {
+        ++qn;
+        r -= freq;
+    }
+    x = (qn << PROB_BITS) + (uint64_t)r + start;
+}
+
+__device__ __forceinline__ void enc_put_bits(uint64_t& x, uint32_t val, uint32_t* out, int64_t& w)
+{
+    const uint64_t lim = ((RANS_LOW >> 16) << 32) * (uint64_t)(1u << (16 - ESC_BITS));  // rans_interface.cpp:67-68
+    if (x >= lim) {
+        out[--w] = (uint32_t)x;
+        x >>= 32;
+    }
+    x = (x << ESC_BITS) | val;
+}
+
+__global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
+                                                         const int64_t* __restrict__ sym_base,
+                                                         const int64_t* __restrict__ counts, DevTables t,
+                                                         uint32_t* __restrict__ out, int64_t cap_words,
+                                                         int64_t* __restrict__ out_words, int* __restrict__ err)
+{
+    __shared__ EncItem items[CHUNK];
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t n = counts[s];
+    const int64_t base = sym_base[s];
+    uint32_t* o = out + (size_t)s * cap_words;
+    uint64_t x = RANS_LOW;
+    int64_t w = cap_words;
+    int bad = 0;
+    for (int64_t hi = n; hi > 0; hi -= CHUNK) {
+        const int64_t lo = hi > CHUNK ? hi - CHUNK : 0;
+        const int cnt = (int)(hi - lo);
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) {
+            const int ti = idx[base + lo + i];
+            const int top = t.sizes[ti] - 2;
+            const int ro = t.row_off[ti];
+            int v = sym[base + lo + i] - t.offsets[ti];
+            uint32_t raw = 0;
+            if (v < 0) {
+                raw = (uint32_t)(-2 * v - 1);
+                v = top;
+            } else if (v >= top) {
+                raw = (uint32_t)(2 * (v - top));
+                v = top;
+            }
+            const uint32_t start = t.cdf[ro + v];
+            const uint32_t next = (v + 1 == top + 1) ? 65536u : (uint32_t)t.cdf[ro + v + 1];
+            EncItem it;
+            it.sf = start | ((next - start) << 16);
+            it.raw = raw;
+            it.esc = (v == top);
+            it.pad = 0;
+            items[i] = it;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = cnt - 1; i >= 0; --i) {
+                const EncItem it = items[i];
+                if (w < 24) {  // worst case for one symbol: 1 + 1 + 8 items + flush
+                    bad = 1;
+                    break;
+                }
+                if (it.esc) {
+                    int nn = 0;
+                    while (nn < 8 && (it.raw >> (nn * ESC_BITS)) != 0) ++nn;
+                    for (int j = nn - 1; j >= 0; --j) enc_put_bits(x, (it.raw >> (j * ESC_BITS)) & ESC_MAX, o, w);
+                    // count items were pushed as [15]*k + [rem]; reverse order = rem first (nn <= 8 -> k == 0)
+                    enc_put_bits(x, (uint32_t)nn, o, w);
+                }
+                enc_put(x, it.sf & 0xFFFFu, it.sf >> 16, o, w);
+            }
+        }
+        if (__shfl(bad, 0, 64)) break;
+    }
+    if (lane == 0) {
+        if (bad) {
+            *err = 1;
+            out_words[s] = 0;
+        } else {
+            w -= 2;  // rans64.h:96-103
+            o[w] = (uint32_t)x;
+            o[w + 1] = (uint32_t)(x >> 32);
+            out_words[s] = cap_words - w;
+        }
+    }
+}
+
+int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sym_base, const int64_t* counts,
+                       int nstreams, DevTables t, uint32_t* out, int64_t cap_words, int64_t* out_words, int* err,
+                       hipStream_t s)
+{
+    if (nstreams <= 0) return RGBD_OK;
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), 0, s, sym, idx, sym_base, counts, t, out, cap_words,
+                       out_words, err);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rANS decoder.  The packed u16 CDF rows and a per-row 2^LUT_BITS-bucket search accelerator live in LDS; lane 0
+// runs the state recurrence, the other lanes stage indexes in and symbols out.  The (x, pos) state persists in HBM
+// between the 20 per-part launches of one stream (RansDecoder::decode_stream semantics).
+struct DecMeta {
+    int32_t ro;    // row start in the packed table
+    int32_t len;   // reference cdf_length
+    int32_t off;   // symbol offset
+    int32_t row;   // table row
+};
+
+__device__ __forceinline__ uint32_t dec_word(const uint32_t* st, int64_t nwords, int64_t& pos)
+{
+    const uint32_t v = pos < nwords ? st[pos] : 0u;
+    ++pos;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t dec_bits(uint64_t& x, const uint32_t* st, int64_t nwords, int64_t& pos)
+{
+    const uint32_t val = (uint32_t)(x & ESC_MAX);  // rans_interface.cpp:80-96
+    x >>= ESC_BITS;
+    if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos);
+    return val;
+}
+
+__global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __restrict__ streams,
+                                                          const int64_t* __restrict__ stream_off,
+                                                          const int64_t* __restrict__ stream_len,
+                                                          uint64_t* __restrict__ state, int init,
+                                                          const int32_t* __restrict__ idx, int32_t* __restrict__ sym,
+                                                          const int64_t* __restrict__ sym_base, int64_t part_off,
+                                                          int64_t count, DevTables t)
+{
+    const uint16_t* __restrict__ lut = t.lut;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    uint16_t* cdf = reinterpret_cast<uint16_t*>(dsm);                         // [t.total (+pad)]
+    uint16_t* sl = cdf + ((t.total + 7) & ~7);                                // [nrows][LUT_N]
+    DecMeta* meta = reinterpret_cast<DecMeta*>(sl + ((t.nrows * LUT_N + 7) & ~7));  // [CHUNK]
+    int32_t* osym = reinterpret_cast<int32_t*>(meta + CHUNK);                 // [CHUNK]
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < t.total; i += 256) cdf[i] = t.cdf[i];
+    for (int i = tid; i < t.nrows * LUT_N; i += 256) sl[i] = lut[i];
+
+    const uint32_t* st = streams + stream_off[s];
+    const int64_t nwords = stream_len[s];
+    uint64_t x = 0;
+    int64_t pos = 0;
+    if (tid == 0) {
+        if (init) {
+            x = (uint64_t)(nwords > 0 ? st[0] : 0u) | ((uint64_t)(nwords > 1 ? st[1] : 0u) << 32);  // rans64.h:107-115
+            pos = 2;
+        } else {
+            x = state[2 * s];
+            pos = (int64_t)state[2 * s + 1];
+        }
+    }
+    const int64_t base = sym_base[s] + part_off;
+    for (int64_t lo = 0; lo < count; lo += CHUNK) {
+        const int cnt = (int)((count - lo) < CHUNK ? (count - lo) : CHUNK);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) {
+            const int ti = idx[base + lo + i];
+            DecMeta m;
+            m.ro = t.row_off[ti];
+            m.len = t.sizes[ti];
+            m.off = t.offsets[ti];
+            m.row = ti;
+            meta[i] = m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < cnt; ++i) {
+                const DecMeta m = meta[i];
+                const uint32_t cum = (uint32_t)(x & 0xFFFFu);
+                const uint16_t* row = cdf + m.ro;
+                const uint16_t* lr = sl + m.row * LUT_N + (cum >> (16 - LUT_BITS));
+                int a = lr[0];      // largest j with row[j] <= bucket start
+                int b = lr[1] + 1;  // one past the largest j with row[j] <= next bucket start - 1 ... (exclusive bound)
+                while (b - a > 1) {
+                    const int mid = (a + b) >> 1;
+                    if (row[mid] <= cum) a = mid;
+                    else b = mid;
+                }
+                const uint32_t start = row[a];
+                const uint32_t next = (a + 1 == m.len - 1) ? 65536u : (uint32_t)row[a + 1];
+                const uint32_t freq = next - start;
+                x = (uint64_t)freq * (x >> PROB_BITS) + cum - start;  // rans64.h:131-133
+                if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos);
+                int v = a;
+                const int top = m.len - 2;
+                if (v == top) {  // escape: rans_interface.cpp:323-345
+                    int nib = (int)dec_bits(x, st, nwords, pos);
+                    int nn = nib;
+                    while (nib == (int)ESC_MAX) {
+                        nib = (int)dec_bits(x, st, nwords, pos);
+                        nn += nib;
+                    }
+                    int raw = 0;
+                    for (int j = 0; j < nn; ++j) {
+                        nib = (int)dec_bits(x, st, nwords, pos);
+                        if (j < 8) raw |= nib << (j * ESC_BITS);
+                    }
+                    v = raw >> 1;
+                    if (raw & 1) v = -v - 1;
+                    else v += top;
+                }
+                osym[i] = v + m.off;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) sym[base + lo + i] = osym[i];
+    }
+    if (tid == 0) {
+        state[2 * s] = x;
+        state[2 * s + 1] = (uint64_t)pos;
+    }
+}
+
+size_t rans_decode_lds_bytes(const DevTables& t)
+{
+    return (size_t)((t.total + 7) & ~7) * 2 + (size_t)((t.nrows * LUT_N + 7) & ~7) * 2 + CHUNK * sizeof(DecMeta) +
+           CHUNK * sizeof(int32_t);
+}
+
+int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,
+                       int nstreams, uint64_t* state, int init, const int32_t* idx, int32_t* sym,
+                       const int64_t* sym_base, int64_t part_off, int64_t count, DevTables t, hipStream_t s)
+{
+    if (nstreams <= 0 || count <= 0) return RGBD_OK;
+    const size_t lds = rans_decode_lds_bytes(t);
+    if (lds > 160 * 1024) return RGBD_ENOSPC;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL(rans_decode_kernel, dim3(nstreams), dim3(256), lds, s, streams, stream_off_words, stream_len_words,
+                       state, init, idx, sym, sym_base, part_off, count, t);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}

@@ -1,0 +1,272 @@
+// HBM-bound helper kernels of the ELIC_united path (gfx950): layout conversion at the API boundary, the ESA pooled
+// branch (max_pool2d 7/3 + bilinear upsample, modules/transform/attention.py:87-92), SE_Block (global average pool
+// -> 2 bias-free FCs -> sigmoid, attention.py:63-67) and channel scaling / concatenation.
+// All tensors are NHWC with channel stride cs (multiple of 4 floats): every access is a 16-byte vector per lane and
+// consecutive lanes walk consecutive channels, so each wave instruction touches contiguous 1 KiB runs.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline unsigned grid_for(size_t work, int block = 256, unsigned cap = 256 * 8)
+{
+    size_t g = (work + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc16_kernel(const float* __restrict__ src, int N, int C, int H, int W, float* __restrict__ dst,
+                                      int cs)
+{
+    const size_t npix = (size_t)N * H * W;
+    const int c4n = cs / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix * c4n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / c4n;
+        const int c4 = (int)(i - pix * c4n);
+        const size_t hw = pix % ((size_t)H * W);
+        const size_t n = pix / ((size_t)H * W);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 * 4 + e;
+            v[e] = c < C ? src[(n * C + c) * (size_t)H * W + hw] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dst + pix * cs + c4 * 4) = v;
+    }
+}
+
+int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s)
+{
+    const size_t work = (size_t)N * H * W * (cs / 4);
+    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, N, C, H, W, dst, cs);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int N, int C, int H, int W, int cs,
+                                    float* __restrict__ dst, int clamp01)
+{
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t hw = i % ((size_t)H * W);
+        const size_t nc = i / ((size_t)H * W);
+        const int c = (int)(nc % C);
+        const size_t n = nc / C;
+        float v = src[(n * H * W + hw) * cs + c];
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        dst[i] = v;
+    }
+}
+
+int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int cs, float* dst, int clamp01,
+                              hipStream_t s)
+{
+    const size_t work = (size_t)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, N, C, H, W, cs, dst, clamp01);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.max_pool2d(kernel=7, stride=3), no padding, floor mode (attention.py:87)
+__global__ void maxpool7s3_kernel(const float* __restrict__ x, int N, int H, int W, int cs, float* __restrict__ y,
+                                  int OH, int OW)
+{
+    const int c4n = cs / 4;
+    const size_t total = (size_t)N * OH * OW * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t t = i / c4n;
+        const int ox = (int)(t % OW);
+        t /= OW;
+        const int oy = (int)(t % OH);
+        const size_t n = t / OH;
+        f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int ky = 0; ky < 7; ++ky)
+            for (int kx = 0; kx < 7; ++kx) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(
+                    x + ((n * H + (oy * 3 + ky)) * (size_t)W + (ox * 3 + kx)) * cs + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        *reinterpret_cast<f32x4*>(y + ((n * OH + oy) * (size_t)OW + ox) * cs + c4 * 4) = m;
+    }
+}
+
+int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s)
+{
+    if (OH != (H - 7) / 3 + 1 || OW != (W - 7) / 3 + 1 || H < 7 || W < 7) return RGBD_EINVAL;
+    const size_t work = (size_t)N * OH * OW * (cs / 4);
+    hipLaunchKernelGGL(maxpool7s3_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, N, H, W, cs, y, OH, OW);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// F.interpolate(mode="bilinear", align_corners=False) to (H, W) (attention.py:91):
+// src = max(0, scale*(dst+0.5)-0.5), i0 = floor(src), i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1
+__global__ void bilinear_kernel(const float* __restrict__ x, int N, int h, int w, int cs, float* __restrict__ y, int H,
+                                int W, float sy, float sx)
+{
+    const int c4n = cs / 4;
+    const size_t total = (size_t)N * H * W * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t t = i / c4n;
+        const int ox = (int)(t % W);
+        t /= W;
+        const int oy = (int)(t % H);
+        const size_t n = t / H;
+        float fy = __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
+        float fx = __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* b = x + n * (size_t)h * w * cs + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x0) * cs);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * w + x1) * cs);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x0) * cs);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * w + x1) * cs);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float top = __fadd_rn(__fmul_rn(lx0, v00[e]), __fmul_rn(lx1, v01[e]));
+            const float bot = __fadd_rn(__fmul_rn(lx0, v10[e]), __fmul_rn(lx1, v11[e]));
+            o[e] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+        }
+        *reinterpret_cast<f32x4*>(y + ((n * H + oy) * (size_t)W + ox) * cs + c4 * 4) = o;
+    }
+}
+
+int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s)
+{
+    const size_t work = (size_t)N * H * W * (cs / 4);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, N, h, w, cs, y, H, W, sy, sx);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global average pool per (n, c): fixed reduction order (per-thread strided partial sums, then a fixed LDS tree),
+// so the result does not depend on scheduling.  grid = (ceil(C/64), N), block = 256 = 64 channels x 4 pixel lanes.
+__global__ void channel_mean_kernel(const float* __restrict__ x, int HW, int cs, int C, float* __restrict__ mean)
+{
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = threadIdx.x >> 6;
+    const size_t n = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const float* b = x + n * (size_t)HW * cs + c;
+        for (int p = r; p < HW; p += 4) s += b[(size_t)p * cs];
+    }
+    part[r][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        mean[n * C + c] = t / (float)HW;
+    }
+}
+
+int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s)
+{
+    hipLaunchKernelGGL(channel_mean_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, x, HW, cs, C, mean);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// scale[n][c] = sigmoid(W1 @ relu(W0 @ mean[n]))   W0: [hidden][C], W1: [C][hidden]; one workgroup per image.
+__global__ void se_fc_kernel(const float* __restrict__ mean, int C, int hidden, const float* __restrict__ w0,
+                             const float* __restrict__ w1, float* __restrict__ scale)
+{
+    extern __shared__ float sh[];  // [C] means + [hidden]
+    float* m = sh;
+    float* hbuf = sh + C;
+    const size_t n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) m[c] = mean[n * C + c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wave; j < hidden; j += nw) {  // one wave per hidden unit, lanes stride the dot product
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], m[c], s);
+#pragma unroll
+        for (int off = 32; off; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) hbuf[j] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < hidden; ++j) s = fmaf(w1[(size_t)c * hidden + j], hbuf[j], s);
+        scale[n * C + c] = 1.0f / (1.0f + expf(-s));
+    }
+}
+
+int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, float* scale,
+                 hipStream_t s)
+{
+    const size_t lds = (size_t)(C + hidden) * sizeof(float);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), lds, s, mean, C, hidden, w0, w1, scale);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+__global__ void channel_scale_kernel(const float* __restrict__ x, int HW, int cs, int C, const float* __restrict__ scale,
+                                     int mode, float* __restrict__ y, size_t total4)
+{
+    const int c4n = cs / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t pix = i / c4n;
+        const size_t n = pix / HW;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * cs + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c4 * 4 + e;
+            const float sc = c < C ? scale[n * C + c] : 0.f;
+            const float t = __fmul_rn(v[e], sc);
+            o[e] = mode ? __fadd_rn(v[e], t) : t;
+        }
+        *reinterpret_cast<f32x4*>(y + pix * cs + c4 * 4) = o;
+    }
+}
+
+int launch_channel_scale(const float* x, int N, int HW, int cs, int C, const float* scale, int mode, float* y,
+                         hipStream_t s)
+{
+    const size_t total4 = (size_t)N * HW * (cs / 4);
+    hipLaunchKernelGGL(channel_scale_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, HW, cs, C, scale, mode, y,
+                       total4);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ src, int scs, float* __restrict__ dst, int dcs,
+                                     size_t npix, int c4n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix * c4n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t pix = i / c4n;
+        *reinterpret_cast<f32x4*>(dst + pix * dcs + c4 * 4) = *reinterpret_cast<const f32x4*>(src + pix * scs + c4 * 4);
+    }
+}
+
+int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s)
+{
+    if (C % 4 || scs % 4 || dcs % 4) return RGBD_EINVAL;
+    const size_t work = (size_t)npix * (C / 4);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, scs, dst, dcs, (size_t)npix,
+                       C / 4);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+int launch_fill_zero(float* p, size_t n, hipStream_t s)
+{
+    HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(float), s));
+    return RGBD_OK;
+}

@@ -1,0 +1,292 @@
+"""`ELIC_united` on MI355X: the reference's model API (models/elic_united.py) over the HIP engine.
+
+Drop-in surface for testing/tester.py:55-108 and testing/tester_united.py:141-195:
+    net = ELIC_united(config=model_config(), channel=4).eval()
+    net.load_state_dict(checkpoint["state_dict"]); net.update(force=True); net = net.to("cuda")
+    out = net.compress(rgb, depth)          -> {"r_strings": [[y], [z]*B], "d_strings": ..., "shape": (H/64, W/64)}
+    rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])  -> {"x_hat": {"r","d"}, "cost_time"}
+
+The network, the checkerboard entropy model and the rANS coder all run inside librgbd_amd.so (hand-written gfx950
+kernels); this class only holds the checkpoint, builds the integer tables once (update()) and marshals pointers.
+There is no CPU execution path: compress()/decompress() raise if the HIP library or a GPU is missing.
+"""
+import ctypes
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import synth
+from ._lib import RgbdError, check, lib
+from .arch import elic_united_entries, model_config
+from .entropy_models import EntropyBottleneck, GaussianConditional, get_scale_table
+
+_TABLE_KEYS = ("_offset", "_quantized_cdf", "_cdf_length")
+
+
+class ELIC_united:
+    def __init__(self, config=None, channel=4, init_seed=0, **kwargs):
+        self.config = model_config() if config is None else config
+        self.channel = channel
+        self.N, self.M = int(self.config["N"]), int(self.config["M"])
+        self.slice_ch = list(self.config["slice_ch"])
+        self.slice_num = len(self.slice_ch)
+        self.quant = self.config.get("quant", "ste") if hasattr(self.config, "get") else "ste"
+        self.training = False
+        self.per_image_streams = False  # False = reference format: one y-stream per modality for the whole batch
+        self._entries = elic_united_entries(self.config)
+        self._init_seed = init_seed
+        self._params = None  # name -> torch CPU tensor (parameters and float buffers)
+        self.rgb_gaussian_conditional = GaussianConditional(None)
+        self.depth_gaussian_conditional = GaussianConditional(None)
+        self._store = _LazyStore(self)
+        self.rgb_entropy_bottleneck = EntropyBottleneck(self._store, "rgb_entropy_bottleneck")
+        self.depth_entropy_bottleneck = EntropyBottleneck(self._store, "depth_entropy_bottleneck")
+        self._h = None
+        self._device = None
+        self._dirty = True
+
+    # ---- torch.nn.Module-like surface ------------------------------------------------------------------
+    def _materialize(self):
+        if self._params is None:
+            self._params = synth.synthetic_state_dict(self._init_seed, self.config, stress=False)
+        return self._params
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("the MI355X path is inference-only (training is out of scope, DESIGN.md)")
+        return self
+
+    def parameters(self):
+        p = self._materialize()
+        for name, e in self._entries.items():
+            if e.is_param:
+                yield p[name]
+
+    def count_parameters(self, only_trainable=False):
+        return sum(p.numel() for p in self.parameters())
+
+    def state_dict(self):
+        p = self._materialize()
+        out = OrderedDict()
+        holders = {"rgb_gaussian_conditional": self.rgb_gaussian_conditional,
+                   "depth_gaussian_conditional": self.depth_gaussian_conditional,
+                   "rgb_entropy_bottleneck": self.rgb_entropy_bottleneck,
+                   "depth_entropy_bottleneck": self.depth_entropy_bottleneck}
+        for name in self._entries:
+            mod, _, leaf = name.rpartition(".")
+            if mod in holders and leaf in _TABLE_KEYS:
+                out[name] = getattr(holders[mod], leaf)
+            elif mod in holders and leaf == "scale_table":
+                out[name] = holders[mod].scale_table
+            else:
+                out[name] = p[name]
+        return out
+
+    def load_state_dict(self, state_dict, strict=False):
+        """Accepts the reference's key set; unknown / missing keys raise when strict."""
+        missing = [k for k in self._entries if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._entries]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        params = self._materialize() if missing else OrderedDict()
+        holders = {"rgb_gaussian_conditional": self.rgb_gaussian_conditional,
+                   "depth_gaussian_conditional": self.depth_gaussian_conditional,
+                   "rgb_entropy_bottleneck": self.rgb_entropy_bottleneck,
+                   "depth_entropy_bottleneck": self.depth_entropy_bottleneck}
+        for name, e in self._entries.items():
+            if name not in state_dict:
+                continue
+            v = state_dict[name]
+            v = v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            mod, _, leaf = name.rpartition(".")
+            if mod in holders and leaf in _TABLE_KEYS:
+                setattr(holders[mod], leaf, v.to(torch.int32).clone())
+                continue
+            if mod in holders and leaf == "scale_table":
+                holders[mod].scale_table = v.float().clone()
+                continue
+            if e.shape and tuple(v.shape) != tuple(e.shape) and e.kind != "buffer":
+                raise RuntimeError(f"size mismatch for {name}: checkpoint {tuple(v.shape)} vs model {tuple(e.shape)}")
+            params[name] = v.float().contiguous().clone() if v.is_floating_point() else v.clone()
+        self._params = params
+        self._dirty = True
+        return None
+
+    def update(self, scale_table=None, force=False):
+        """models/elic_united.py:580-586 + compressai/models/priors.py:73-92."""
+        self._materialize()
+        if scale_table is None:
+            scale_table = get_scale_table()
+        r = self.rgb_gaussian_conditional.update_scale_table(scale_table, force=force)
+        d = self.depth_gaussian_conditional.update_scale_table(scale_table, force=force)
+        eb = False
+        for m in (self.rgb_entropy_bottleneck, self.depth_entropy_bottleneck):
+            eb |= bool(m.update(force=force))
+        self._dirty = True
+        return (r & d) | eb
+
+    def to(self, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RgbdError("ELIC_united (rgbd_amd) runs on the GPU only: use .to('cuda'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RgbdError("no HIP device visible to torch")
+        self._device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
+        self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else f"cuda:{int(device)}")
+
+    # ---- engine ------------------------------------------------------------------------------------
+    def _upload(self):
+        L = lib()
+        torch.cuda.set_device(self._device)
+        if self._h is None:
+            h = ctypes.c_void_p()
+            sl = (ctypes.c_int32 * len(self.slice_ch))(*self.slice_ch)
+            check(L.rgbd_elic_create(self.N, self.M, sl, len(self.slice_ch), ctypes.byref(h)), "elic_create")
+            self._h = h
+        p = self._materialize()
+        for name, e in self._entries.items():
+            if not e.is_param:
+                continue
+            t = p[name].detach().float().contiguous()
+            a = t.numpy()
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            check(L.rgbd_elic_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shape,
+                                         a.ndim), f"set_tensor({name})")
+        for which, holder in enumerate((self.rgb_gaussian_conditional, self.depth_gaussian_conditional,
+                                        self.rgb_entropy_bottleneck, self.depth_entropy_bottleneck)):
+            cdf, sizes, offs = holder.numpy_tables()  # raises "Uninitialized CDFs. Run update() first"
+            i32p = ctypes.POINTER(ctypes.c_int32)
+            check(L.rgbd_elic_set_tables(self._h, which, cdf.ctypes.data_as(i32p), int(cdf.shape[1]),
+                                         sizes.ctypes.data_as(i32p), offs.ctypes.data_as(i32p), int(cdf.shape[0])),
+                  f"set_tables({which})")
+        st = self.rgb_gaussian_conditional.scale_table.float().contiguous().numpy()
+        check(L.rgbd_elic_set_scale_table(self._h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(st.shape[0])),
+              "set_scale_table")
+        check(L.rgbd_elic_finalize(self._h), "finalize")
+        self._dirty = False
+
+    def _ready(self):
+        if self._h is None or self._device is None:
+            raise RgbdError("call .to('cuda') before compress()/decompress()")
+        if self._dirty:
+            self._upload()
+        torch.cuda.set_device(self._device)
+
+    @staticmethod
+    def _stream_ptr():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def compress(self, rgb, depth):
+        self._ready()
+        if rgb.dim() != 4 or depth.dim() != 4 or rgb.size(1) != 3 or depth.size(1) != 1:
+            raise ValueError("expected rgb [B,3,H,W] and depth [B,1,H,W]")
+        B, _, H, W = rgb.shape
+        if depth.shape[0] != B or depth.shape[-2:] != rgb.shape[-2:]:
+            raise ValueError("rgb and depth must have the same batch and spatial size")
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64 (pad first: dataset/utils.py:58-67)")
+        rgb = rgb.to(self._device, torch.float32).contiguous()
+        depth = depth.to(self._device, torch.float32).contiguous()
+        L = lib()
+        check(L.rgbd_elic_compress(self._h, ctypes.c_void_p(rgb.data_ptr()), ctypes.c_void_p(depth.data_ptr()), B, H, W,
+                                   1 if self.per_image_streams else 0, self._stream_ptr()), "compress")
+        out = []
+        for mod in (0, 1):
+            lists = []
+            for kind in (0, 1):
+                n = L.rgbd_elic_stream_count(self._h, mod, kind)
+                strings = []
+                for i in range(n):
+                    p = ctypes.POINTER(ctypes.c_uint8)()
+                    ln = ctypes.c_int64(0)
+                    check(L.rgbd_elic_stream(self._h, mod, kind, i, ctypes.byref(p), ctypes.byref(ln)), "stream")
+                    strings.append(ctypes.string_at(p, ln.value))
+                lists.append(strings)
+            out.append(lists)
+        return {"r_strings": out[0], "d_strings": out[1], "shape": torch.Size((H // 64, W // 64))}
+
+    def decompress(self, rgb_strings, depth_strings, shape):
+        self._ready()
+        torch.cuda.synchronize()
+        t0 = time.process_time()
+        y_r, z_r = list(rgb_strings[0]), list(rgb_strings[1])
+        y_d, z_d = list(depth_strings[0]), list(depth_strings[1])
+        B = len(z_r)
+        if len(z_d) != B or len(y_r) != len(y_d) or len(y_r) not in (1, B):
+            raise ValueError("Invalid strings parameters")
+        zh, zw = int(shape[0]), int(shape[1])
+        xr = torch.empty((B, 3, zh * 64, zw * 64), dtype=torch.float32, device=self._device)
+        xd = torch.empty((B, 1, zh * 64, zw * 64), dtype=torch.float32, device=self._device)
+
+        def pack(strings):
+            bufs = [np.frombuffer(bytes(s), dtype=np.uint8) for s in strings]
+            u8p = ctypes.POINTER(ctypes.c_uint8)
+            ptrs = (u8p * len(bufs))(*[b.ctypes.data_as(u8p) for b in bufs])
+            lens = (ctypes.c_int64 * len(bufs))(*[int(b.shape[0]) for b in bufs])
+            return bufs, ptrs, lens
+
+        k1, pyr, lyr = pack(y_r)
+        k2, pyd, lyd = pack(y_d)
+        k3, pzr, lzr = pack(z_r)
+        k4, pzd, lzd = pack(z_d)
+        check(lib().rgbd_elic_decompress(self._h, pyr, lyr, len(y_r), pyd, lyd, pzr, lzr, pzd, lzd, B, zh, zw,
+                                         ctypes.c_void_p(xr.data_ptr()), ctypes.c_void_p(xd.data_ptr()),
+                                         self._stream_ptr()), "decompress")
+        torch.cuda.synchronize()
+        del k1, k2, k3, k4
+        return {"x_hat": {"r": xr, "d": xd}, "cost_time": time.process_time() - t0}
+
+    def forward(self, rgb, depth):
+        raise NotImplementedError("eval-mode forward()/likelihoods is a 'next' row (SURVEY.md §8f rank 2)")
+
+    __call__ = forward
+
+    # ---- parity hooks --------------------------------------------------------------------------------
+    def debug_tensor(self, name: str) -> np.ndarray:
+        shp = (ctypes.c_int32 * 4)()
+        check(lib().rgbd_elic_debug_tensor(self._h, name.encode(), None, 0, shp), f"debug_tensor({name})")
+        out = np.empty(tuple(shp), dtype=np.float32)
+        check(lib().rgbd_elic_debug_tensor(self._h, name.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                           out.size, shp), f"debug_tensor({name})")
+        return out
+
+    def debug_symbols(self, modality: int):
+        n = ctypes.c_int64(0)
+        check(lib().rgbd_elic_debug_symbols(self._h, modality, None, None, 0, ctypes.byref(n)), "debug_symbols")
+        sym = np.empty(n.value, dtype=np.int32)
+        idx = np.empty(n.value, dtype=np.int32)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        check(lib().rgbd_elic_debug_symbols(self._h, modality, sym.ctypes.data_as(i32p), idx.ctypes.data_as(i32p),
+                                            n.value, ctypes.byref(n)), "debug_symbols")
+        return sym, idx
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().rgbd_elic_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class _LazyStore:
+    """Mapping view used by the EntropyBottleneck table builders (parameters may be (re)loaded later)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def __getitem__(self, k):
+        return self._o._materialize()[k]
+
+
+modelZoo = {"ELIC_united": ELIC_united}

@@ -1,0 +1,105 @@
+"""GPU rANS coder (through the C ABI / the compressai.ans look-alike classes) vs the oracle coder: bit-exact."""
+import numpy as np
+import pytest
+
+from gpu_utils import require_gpu
+from oracle import coder
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_tables(kat):
+    require_gpu()
+    from rgbd_amd import ans
+
+    return ans.Tables(kat["gc_cdf"], kat["gc_sizes"], kat["gc_offsets"])
+
+
+def test_tiny_and_b2(kat, gc_tables, gpu_tables):
+    from rgbd_amd import ans
+
+    s = ans._encode(gpu_tables, kat["tiny_sym"], kat["tiny_idx"])
+    assert s == kat["tiny_stream"].tobytes()
+    rng = np.random.RandomState(1234)
+    n = 49152
+    idx = rng.randint(0, 64, n)
+    sym = np.rint(rng.standard_normal(n) * kat["scale_table"][idx]).astype(np.int64)
+    sym[::97] *= 8
+    sym[5::193] = -sym[5::193] - 3
+    sym, idx = sym.astype(np.int32), idx.astype(np.int32)
+    s = ans._encode(gpu_tables, sym, idx)
+    assert s == kat["b2_stream"].tobytes()
+    assert s == coder.rans_encode(sym, idx, gc_tables)
+
+
+def test_list_api_like_reference(kat):
+    require_gpu()
+    from rgbd_amd import ans
+
+    cdf_l, sz_l, off_l = kat["gc_cdf"].tolist(), kat["gc_sizes"].tolist(), kat["gc_offsets"].tolist()
+    sym, idx = kat["tiny_sym"].tolist(), kat["tiny_idx"].tolist()
+    want = kat["tiny_stream"].tobytes()
+    assert ans.RansEncoder().encode_with_indexes(sym, idx, cdf_l, sz_l, off_l) == want
+    enc = ans.BufferedRansEncoder()
+    enc.encode_with_indexes(sym[:5], idx[:5], cdf_l, sz_l, off_l)
+    enc.encode_with_indexes(sym[5:], idx[5:], cdf_l, sz_l, off_l)
+    assert enc.flush() == want
+    dec = ans.RansDecoder()
+    dec.set_stream(want)
+    got = dec.decode_stream(idx[:4], cdf_l, sz_l, off_l) + dec.decode_stream(idx[4:9], cdf_l, sz_l, off_l) \
+        + dec.decode_stream(idx[9:], cdf_l, sz_l, off_l)
+    assert got == sym
+    assert ans.RansDecoder().decode_with_indexes(want, idx, cdf_l, sz_l, off_l) == sym
+    assert ans.pmf_to_quantized_cdf([0.1, 0.2, 0.7], 16) == [0, 6554, 19661, 65536]
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1), (1, 2), (2, 511), (3, 512), (4, 513), (5, 30000), (6, 200000)])
+def test_random_roundtrip_vs_oracle(seed, n, kat, gc_tables, gpu_tables):
+    from rgbd_amd import ans
+
+    rng = np.random.RandomState(seed)
+    idx = rng.randint(0, 64, n).astype(np.int32)
+    sym = np.rint(rng.standard_normal(n) * kat["scale_table"][idx] * (1 + 3 * (rng.rand(n) < 0.02))).astype(np.int32)
+    esc = rng.rand(n) < 0.01
+    sym[esc] = rng.randint(-100000, 100000, int(esc.sum()))
+    s = ans._encode(gpu_tables, sym, idx)
+    assert s == coder.rans_encode(sym, idx, gc_tables)
+    import ctypes
+
+    from rgbd_amd._lib import check, lib
+
+    d = ans.RansDecoder()
+    d.set_stream(s)
+    cuts = sorted(set([0, n // 3, n // 2, n]))
+    got = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out = np.empty(b - a, dtype=np.int32)
+        ii = np.ascontiguousarray(idx[a:b])
+        check(lib().rgbd_rans_decoder_decode(d._h, gpu_tables.handle, ii.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                             b - a, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))), "decode")
+        got.append(out)
+    assert np.array_equal(np.concatenate(got), sym)
+
+
+def test_empty_and_escape_only(kat, gc_tables, gpu_tables):
+    from rgbd_amd import ans
+
+    assert ans._encode(gpu_tables, [], []) == (1 << 31).to_bytes(8, "little")
+    s = ans._encode(gpu_tables, kat["esc_sym"], np.zeros_like(kat["esc_sym"]))
+    assert s == kat["esc_stream"].tobytes()
+
+
+def test_bottleneck_tables(kat):
+    require_gpu()
+    from rgbd_amd import ans
+
+    t = ans.Tables(kat["rgb_eb_cdf"], kat["rgb_eb_sizes"], kat["rgb_eb_offsets"])
+    ot = coder.Tables(kat["rgb_eb_cdf"], kat["rgb_eb_sizes"], kat["rgb_eb_offsets"])
+    rng = np.random.RandomState(7)
+    idx = np.repeat(np.arange(192, dtype=np.int32), 24)
+    sym = np.rint(rng.standard_normal(idx.shape[0]) * 4).astype(np.int32)
+    sym[::50] = 60
+    s = ans._encode(t, sym, idx)
+    assert s == coder.rans_encode(sym, idx, ot)
+    assert np.array_equal(coder.rans_decode(s, idx, ot), sym)

@@ -1,0 +1,92 @@
+"""MFMA conv / transposed-conv kernel (via the C ABI) vs torch CPU fp32 convolution.  Tolerance: the kernel is an
+exact-fp32 fma chain; against oneDNN's different summation order the error is ~1e-6 relative to sum|a.b|, so we allow
+2e-5 * (max|ref| + 1e-3) absolute."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_utils import require_gpu
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, cin, h, w, cout, k, stride, pad, transposed, act, residual
+    (2, 3, 64, 64, 192, 5, 2, 2, 0, 0, 0),
+    (1, 1, 64, 96, 192, 5, 2, 2, 0, 0, 0),
+    (2, 96, 32, 48, 96, 3, 1, 1, 0, 1, 0),
+    (1, 192, 32, 32, 96, 1, 1, 0, 0, 1, 0),
+    (1, 96, 32, 32, 192, 1, 1, 0, 0, 0, 1),
+    (1, 384, 32, 48, 192, 5, 2, 2, 0, 0, 0),
+    (1, 48, 33, 47, 48, 3, 2, 0, 0, 0, 0),
+    (2, 48, 9, 11, 48, 3, 1, 1, 0, 1, 0),
+    (1, 320, 8, 12, 192, 5, 2, 2, 1, 0, 0),
+    (1, 192, 16, 24, 3, 5, 2, 2, 1, 0, 0),
+    (1, 192, 16, 16, 1, 5, 2, 2, 1, 0, 0),
+    (1, 960, 8, 12, 640, 3, 1, 1, 1, 0, 0),
+    (2, 384, 2, 3, 320, 5, 2, 2, 1, 2, 0),
+    (1, 1344, 8, 12, 224, 1, 1, 0, 0, 1, 0),
+    (1, 213, 8, 12, 42, 3, 1, 1, 0, 1, 0),
+    (1, 42, 8, 12, 32, 5, 1, 2, 0, 0, 0),
+    (1, 128, 16, 16, 224, 5, 1, 2, 0, 1, 0),
+    (1, 320, 8, 40, 160, 1, 1, 0, 0, 3, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_conv_vs_torch(case):
+    dev = require_gpu()
+    from rgbd_amd._lib import check, lib
+
+    n, cin, h, w, cout, k, stride, pad, tr, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2**31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    wt = torch.randn(*wshape, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    if tr:
+        ref = F.conv_transpose2d(x, wt, b, stride=stride, padding=pad, output_padding=stride - 1)
+    else:
+        ref = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res
+    ref = [lambda t: t, torch.relu, lambda t: F.leaky_relu(t, 0.01), torch.sigmoid][act](ref)
+    xd = x.to(dev).contiguous()
+    yd = torch.empty(ref.shape, device=dev)
+    rd = res.to(dev).contiguous() if res is not None else None
+    f32p = ctypes.POINTER(ctypes.c_float)
+    wn, bn = wt.contiguous().numpy(), b.numpy()
+    check(lib().rgbd_conv2d_nchw(ctypes.c_void_p(xd.data_ptr()), n, cin, h, w, wn.ctypes.data_as(f32p),
+                                 bn.ctypes.data_as(f32p), cout, k, stride, pad, tr, act,
+                                 ctypes.c_void_p(rd.data_ptr()) if rd is not None else None,
+                                 ctypes.c_void_p(yd.data_ptr()), None), "conv2d")
+    got = yd.cpu()
+    tol = 2e-5 * (ref.abs().max().item() + 1e-3)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"max abs err {err} > {tol}"
+
+
+def test_conv_deterministic_and_batch_invariant():
+    dev = require_gpu()
+    from rgbd_amd._lib import check, lib
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 96, 16, 24, generator=g)
+    wt = (torch.randn(96, 96, 3, 3, generator=g) / 30).contiguous()
+    b = torch.randn(96, generator=g)
+    f32p = ctypes.POINTER(ctypes.c_float)
+
+    def run(xx):
+        xd = xx.to(dev).contiguous()
+        yd = torch.empty((xx.shape[0], 96, 16, 24), device=dev)
+        check(lib().rgbd_conv2d_nchw(ctypes.c_void_p(xd.data_ptr()), xx.shape[0], 96, 16, 24,
+                                     wt.numpy().ctypes.data_as(f32p), b.numpy().ctypes.data_as(f32p), 96, 3, 1, 1, 0, 0,
+                                     None, ctypes.c_void_p(yd.data_ptr()), None), "conv2d")
+        return yd.cpu()
+
+    full = run(x)
+    assert torch.equal(full, run(x))
+    assert torch.equal(full[1:2], run(x[1:2]))  # same bits whatever the batch the image rides in

@@ -1,0 +1,143 @@
+"""End-to-end ELIC_united on the GPU (through librgbd_amd.so) vs the CPU oracle and the committed goldens.
+
+Layered contract:
+  * integer stages are bit-exact: the oracle coder reproduces the GPU streams from the GPU's own symbols/indexes,
+    the oracle's z quantiser reproduces the GPU z-streams from the GPU's z floats, and the GPU decoder reproduces the
+    encoder's y_hat bit for bit;
+  * float stages agree with the oracle to 2e-5 relative (different fp32 summation order than oneDNN);
+  * symbol flips against the oracle's float path are counted and bounded; PSNR within 1e-4 dB of the oracle whenever
+    the streams coincide, bpp identical then.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_utils import require_gpu
+from oracle import coder
+from oracle import elic_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net(synth_sd):
+    require_gpu()
+    import rgbd_amd
+    from rgbd_amd import ELIC_united
+
+    m = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    m.load_state_dict(synth_sd)
+    assert m.update(force=True)
+    return m.to("cuda")
+
+
+@pytest.fixture(scope="module")
+def orc(synth_sd):
+    c = eo.OracleCodec(synth_sd)
+    c.update()
+    return c
+
+
+def _inputs(B, H, W, cid):
+    from rgbd_amd import synth
+
+    r, d = synth.synthetic_batch(B, H, W, config_id=cid)
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    return r, d, eo.pad_replicate0(r), eo.pad_replicate0(d)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_case_a_layers_and_streams(net, orc):
+    g = load_golden("a_128x192")
+    r, d, rp, dp = _inputs(1, 128, 192, 9)
+    out = net.compress(rp.cuda(), dp.cuda())
+    assert tuple(out["shape"]) == (2, 3)
+    orc.trace = {}
+    ref = orc.compress(rp, dp)
+    tr, orc.trace = orc.trace, None
+    # float stages vs oracle (and vs the reference's own tensors in the golden file)
+    for name in ("y_r", "y_d", "z_r", "z_d", "hyper_r", "hyper_d"):
+        got = net.debug_tensor(name)
+        assert _rel(got, tr[name].numpy()) < 2e-5, name
+        assert _rel(got, g[name]) < 2e-5, name
+    # integer stage 1: z streams from the GPU's own z floats
+    for mod, key, zname in (("rgb", "r_strings", "z_r"), ("depth", "d_strings", "z_d")):
+        strings, _ = orc._z_compress(mod, torch.from_numpy(net.debug_tensor(zname)))
+        assert strings == out[key][1]
+    # integer stage 2: y streams from the GPU's own symbols / indexes
+    flips = 0
+    total = 0
+    for mod, key in ((0, "r_strings"), (1, "d_strings")):
+        sym, idx = net.debug_symbols(mod)
+        assert coder.rans_encode(sym, idx, orc.gc) == out[key][0][0]
+        osym = np.concatenate([p["symbols"].reshape(-1).numpy() for p in tr["parts"] if p["mod"] == ("rgb", "depth")[mod]])
+        oidx = np.concatenate([p["indexes"].reshape(-1).numpy() for p in tr["parts"] if p["mod"] == ("rgb", "depth")[mod]])
+        flips += int((sym != osym).sum() + (idx != oidx).sum())
+        total += sym.size
+    print(f"symbol/index flips vs oracle float path: {flips} of {total}")
+    assert flips <= max(8, total // 2000)
+    same = out["r_strings"] == ref["r_strings"] and out["d_strings"] == ref["d_strings"]
+    print("streams identical to oracle:", same, "| identical to reference golden:",
+          out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes())
+    # decoder reproduces the encoder's reconstruction of the latents bit for bit
+    yhat_enc = [net.debug_tensor("yhat_r").copy(), net.debug_tensor("yhat_d").copy()]
+    rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert np.array_equal(net.debug_tensor("yhat_r"), yhat_enc[0]) and np.array_equal(net.debug_tensor("yhat_d"), yhat_enc[1])
+    xr, xd = rec["x_hat"]["r"].cpu(), rec["x_hat"]["d"].cpu()
+    assert xr.shape == (1, 3, 128, 192) and xd.shape == (1, 1, 128, 192)
+    assert float(xr.min()) >= 0 and float(xr.max()) <= 1
+    # x_hat vs the oracle decoding the GPU's streams (same symbols => only float error remains)
+    dec = orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert (xr - dec["x_hat"]["r"]).abs().max() < 1e-4 and (xd - dec["x_hat"]["d"]).abs().max() < 1e-4
+    assert abs(eo.psnr(xr, r) - eo.psnr(dec["x_hat"]["r"], r)) < 1e-4
+    assert abs(eo.psnr(xd, d) - eo.psnr(dec["x_hat"]["d"], d)) < 1e-4
+    if same:
+        assert abs(eo.psnr(xr, r) - g["psnr"][0]) < 1e-4 and abs(eo.psnr(xd, d) - g["psnr"][1]) < 1e-4
+
+
+def test_batch_formats_and_invariance(net, orc):
+    """B=2: reference format (one interleaved y-stream) and per-image streams; per-image == B=1 calls."""
+    r, d, rp, dp = _inputs(2, 128, 128, 7)
+    net.per_image_streams = False
+    out = net.compress(rp.cuda(), dp.cuda())
+    assert len(out["r_strings"][0]) == 1 and len(out["r_strings"][1]) == 2
+    for mod, key in ((0, "r_strings"), (1, "d_strings")):
+        sym, idx = net.debug_symbols(mod)
+        assert coder.rans_encode(sym, idx, orc.gc) == out[key][0][0]
+    rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    net.per_image_streams = True
+    try:
+        out2 = net.compress(rp.cuda(), dp.cuda())
+        assert len(out2["r_strings"][0]) == 2
+        rec2 = net.decompress(out2["r_strings"], out2["d_strings"], out2["shape"])
+        assert torch.equal(rec["x_hat"]["r"], rec2["x_hat"]["r"]) and torch.equal(rec["x_hat"]["d"], rec2["x_hat"]["d"])
+        for i in range(2):
+            one = net.compress(rp[i:i + 1].cuda(), dp[i:i + 1].cuda())
+            assert one["r_strings"][0][0] == out2["r_strings"][0][i] and one["d_strings"][0][0] == out2["d_strings"][0][i]
+            assert one["r_strings"][1][0] == out2["r_strings"][1][i]
+    finally:
+        net.per_image_streams = False
+
+
+def test_roundtrip_256_and_container(net, orc):
+    g = load_golden("d_256x256")
+    r, d, rp, dp = _inputs(1, 256, 256, 2)
+    out = net.compress(rp.cuda(), dp.cuda())
+    rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    dec = orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert (rec["x_hat"]["r"].cpu() - dec["x_hat"]["r"]).abs().max() < 1e-4
+    bpp = [len(eo.container_bytes(256, 256, out["shape"], out[k])) * 8.0 / (256 * 256) for k in ("r_strings", "d_strings")]
+    print("bpp gpu", bpp, "golden", g["bpp"].tolist(), "psnr gpu", eo.psnr(rec["x_hat"]["r"].cpu(), r), "golden", g["psnr"][0])
+    assert abs(bpp[0] - g["bpp"][0]) < 0.01 and abs(bpp[1] - g["bpp"][1]) < 0.01
+    assert abs(eo.psnr(rec["x_hat"]["r"].cpu(), r) - g["psnr"][0]) < 1e-2
+
+
+def test_errors(net):
+    with pytest.raises(ValueError):
+        net.compress(torch.zeros(1, 3, 100, 128).cuda(), torch.zeros(1, 1, 100, 128).cuda())
+    with pytest.raises(ValueError):
+        net.compress(torch.zeros(1, 3, 128, 128).cuda(), torch.zeros(2, 1, 128, 128).cuda())
