@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RGB-D Mpixels/s, encode+decode, ELIC_united q=2_2 on MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = compress() + decompress() of one batch of synthetic RGB-D pairs per rank (weak scaling: every rank codes
+its own batch; no collective on the data path, only the gather of the finished streams).  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (batch per GPU, H, W, synthetic config id)
+    "c2_8x256x256": (8, 256, 256, 2),
+    "c3_4x480x640": (4, 480, 640, 3),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (dense f32 matrix)
+
+
+def cpu_baseline(sd, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path: PyTorch-CPU eager + C coder) timed on this host, B=1."""
+    import torch
+
+    from oracle import elic_oracle as eo
+    from rgbd_amd import synth
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    orc = eo.OracleCodec(sd)
+    orc.update()
+    H = W = 256
+    done, spent, best = 0, 0.0, None
+    while spent < seconds_budget and done < 6:
+        r, d = synth.synthetic_batch(1, H, W, config_id=2, start=done)
+        r, d = torch.from_numpy(r), torch.from_numpy(d)
+        t0 = time.time()
+        out = orc.compress(r, d)
+        orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
+        dt = time.time() - t0
+        spent += dt
+        done += 1
+        best = dt if best is None else min(best, dt)
+    return {"value": round(H * W / best / 1e6, 5), "unit": "Mpx/s", "cores": cores, "kind": "port",
+            "sample": f"best of {done} single 256x256 pairs, enc+dec, B=1 (tester semantics), torch CPU {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import rgbd_amd
+    from rgbd_amd import ELIC_united, distributed, synth
+
+    rank, world, local = distributed.init_from_env()
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B, H, W, cid = WORKLOADS[args.workload]
+    sd = synth.synthetic_state_dict(0)
+    net = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    net.load_state_dict(sd)
+    net.update(force=True)
+    net = net.to(dev)
+    net.per_image_streams = True  # one stream set per image: the unit that shards across GPUs
+
+    r, d = synth.synthetic_batch(B, H, W, config_id=cid, start=rank * B)
+    rgb, depth = torch.from_numpy(r).to(dev), torch.from_numpy(d).to(dev)
+    ph, pw = (-H) % 64, (-W) % 64
+    if ph or pw:  # dataset/utils.py:58-67 "replicate0"
+        rgb = torch.nn.functional.pad(rgb, (0, pw, 0, ph), mode="replicate")
+        depth = torch.nn.functional.pad(depth, (0, pw, 0, ph), mode="replicate")
+    rgb, depth = rgb.contiguous(), depth.contiguous()
+
+    def step():
+        out = net.compress(rgb, depth)
+        rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+        if world > 1:  # the job's only exchange: finished streams to every rank (RCCL all_gather)
+            distributed.gather_streams(out["r_strings"][0] + out["d_strings"][0])
+        return out, rec
+
+    for _ in range(args.warmup):
+        step()
+    net.set_profile(True)
+    distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, rec = step()
+    torch.cuda.synchronize()
+    distributed.barrier()
+    elapsed = distributed.max_over_ranks(time.perf_counter() - t0)
+    prof = net.profile_read()
+    net.set_profile(False)
+
+    if rank == 0:
+        px = world * B * H * W * args.steps
+        bytes_y = sum(len(s) for s in out["r_strings"][0] + out["d_strings"][0])
+        conv_s = prof["conv_ms"] / 1e3
+        achieved = prof["flops"] / conv_s / 1e12 if conv_s > 0 else 0.0
+        res = {
+            "metric": "RGB-D Mpixels/s encode+decode",
+            "value": round(px / elapsed / 1e6, 4),
+            "unit": "Mpx/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)", "images_per_gpu": B,
+                       "image": [H, W], "padded": [H + ph, W + pw], "weights": "synthetic seed 0 (stress recipe)",
+                       "streams": "per image", "y_bytes_last_batch": bytes_y},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv/deconv layers)",
+                         "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": prof["launches"] // max(args.steps, 1),
+                         "avg_launch_us": round(prof["conv_ms"] * 1e3 / max(prof["launches"], 1), 2),
+                         "conv_ms_per_step": round(prof["conv_ms"] / max(args.steps, 1), 3),
+                         "gflop_per_step": round(prof["flops"] / max(args.steps, 1) / 1e9, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

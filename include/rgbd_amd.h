@@ -118,6 +118,12 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
 /* Symbols / indexes of the last compress() in stream order (modality 0/1), total count in *n. */
 int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n);
 
+/* Measurement hook (bench.py): when on, every convolution launch is bracketed by HIP events on the launch stream.
+ * profile_read returns the summed kernel time (ms), the launch count and the algorithmic FLOPs (2*MACs, unpadded)
+ * accumulated since set_profile(). */
+int rgbd_elic_set_profile(rgbd_elic* m, int32_t on);
+int rgbd_elic_profile_read(rgbd_elic* m, double* conv_ms, int64_t* launches, double* flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,9 @@ def lib():
                                                 c_i32, c_i32, c_vp, c_vp, c_vp]),
         "rgbd_elic_debug_tensor": (ctypes.c_int, [c_vp, ctypes.c_char_p, f32p, c_i64, i32p]),
         "rgbd_elic_debug_symbols": (ctypes.c_int, [c_vp, c_i32, i32p, i32p, c_i64, i64p]),
+        "rgbd_elic_set_profile": (ctypes.c_int, [c_vp, c_i32]),
+        "rgbd_elic_profile_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), i64p,
+                                                  ctypes.POINTER(ctypes.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export what include/rgbd_amd.h declares
@@ -91,4 +94,5 @@ EXPORTS = ["rgbd_abi_version", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create"
            "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_stream_count", "rgbd_elic_stream",
-           "rgbd_elic_decompress", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols"]
+           "rgbd_elic_decompress", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_profile",
+           "rgbd_elic_profile_read"]

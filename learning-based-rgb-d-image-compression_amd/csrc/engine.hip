@@ -229,6 +229,14 @@ struct rgbd_elic {
     int32_t* dbg_idx = nullptr;
     int64_t dbg_per_mod = 0;
 
+    // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;   // algorithmic (unpadded) FLOPs of the recorded launches
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+
     // --- small helpers -------------------------------------------------------------------------
     bool dry() const { return arena.dry; }
     void fail(int code)
@@ -327,12 +335,44 @@ struct rgbd_elic {
             a.res2 = ep.res2->p;
             a.r2cs = ep.res2->cs;
         }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) {
+            if (ev_used + 2 > ev_pool.size()) {
+                for (int i = 0; i < 256; ++i) {
+                    hipEvent_t e;
+                    if (hipEventCreate(&e) != hipSuccess) {
+                        fail(RGBD_EHIP);
+                        return y;
+                    }
+                    ev_pool.push_back(e);
+                }
+            }
+            e0 = ev_pool[ev_used++];
+            e1 = ev_pool[ev_used++];
+            (void)hipEventRecord(e0, s);
+        }
         const int r = launch_conv(a, s);
+        if (profile) {
+            (void)hipEventRecord(e1, s);
+            prof_flops += 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
+                          (pc->transposed ? (double)(stride * stride) : 1.0);
+            ++prof_launches;
+        }
         if (r) {
             fprintf(stderr, "[rgbd_amd] conv launch failed at %s (%d)\n", name.c_str(), r);
             fail(r);
         }
         return y;
+    }
+
+    // drain recorded event pairs into prof_ms (call after the stream has been synchronised)
+    void profile_collect()
+    {
+        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) prof_ms += ms;
+        }
+        ev_used = 0;
     }
 
     void copy_ch(const Act& src, const Act& dst)
@@ -1309,6 +1349,7 @@ void rgbd_elic_destroy(rgbd_elic* m)
         if (t.blob) (void)hipFree(t.blob);
     if (m->scale_table) (void)hipFree(m->scale_table);
     if (m->arena.base) (void)hipFree(m->arena.base);
+    for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -1417,7 +1458,9 @@ int rgbd_elic_compress(rgbd_elic* m, const float* rgb_dev, const float* depth_de
     if (r) return r;
     r = m->ensure_arena(m->arena.peak);
     if (r) return r;
-    return m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
+    r = m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
+    if (m->profile) m->profile_collect();  // run_compress ends with a stream synchronise
+    return r;
 }
 
 int rgbd_elic_stream_count(const rgbd_elic* m, int32_t modality, int32_t kind)
@@ -1458,7 +1501,32 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
     if (r) return r;
     r = m->ensure_arena(m->arena.peak);
     if (r) return r;
-    return m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
+    r = m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
+    if (m->profile && !r) {
+        if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
+        m->profile_collect();
+    }
+    return r;
+}
+
+int rgbd_elic_set_profile(rgbd_elic* m, int32_t on)
+{
+    if (!m) return RGBD_EINVAL;
+    m->profile = on != 0;
+    m->ev_used = 0;
+    m->prof_flops = 0.0;
+    m->prof_ms = 0.0;
+    m->prof_launches = 0;
+    return RGBD_OK;
+}
+
+int rgbd_elic_profile_read(rgbd_elic* m, double* conv_ms, int64_t* launches, double* flops)
+{
+    if (!m || !conv_ms || !launches || !flops) return RGBD_EINVAL;
+    *conv_ms = m->prof_ms;
+    *launches = m->prof_launches;
+    *flops = m->prof_flops;
+    return RGBD_OK;
 }
 
 int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t cap_floats, int32_t* shape_out)

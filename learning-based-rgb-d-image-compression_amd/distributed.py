@@ -1,0 +1,99 @@
+"""Image-sharded data parallelism for the codec: one process per GPU, no collective on the data path.
+
+Each image pair is coded independently, so rank r takes images r, r+world, ... and runs the whole
+encode/decode locally on its own weight replica.  The only exchange is the gather of the finished per-image bitstreams
+and metrics: an all_gather of int64 lengths followed by an all_gather of the zero-padded uint8 payload (RCCL when the
+backend is "nccl", gloo on CPU for the tests).  The reference has no multi-GPU inference path at all.
+"""
+import os
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard(n_items: int, rank: int, world: int) -> List[int]:
+    """Indices of the items this rank owns (round-robin, so ranks stay balanced for any n)."""
+    return list(range(rank, n_items, world))
+
+
+def _comm_device():
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_streams(streams: Sequence[bytes]) -> List[List[bytes]]:
+    """All ranks receive every rank's list of byte strings.  Ranks may hold different numbers of strings."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(streams)]
+    world = dist.get_world_size()
+    dev = _comm_device()
+    count = torch.tensor([len(streams), sum(len(s) for s in streams)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    max_n = max(int(c[0]) for c in counts)
+    max_b = max(int(c[1]) for c in counts)
+    lens = torch.zeros(max(max_n, 1), dtype=torch.int64)
+    lens[: len(streams)] = torch.tensor([len(s) for s in streams], dtype=torch.int64)
+    payload = torch.zeros(max(max_b, 1), dtype=torch.uint8)
+    if streams:
+        flat = np.frombuffer(b"".join(streams), dtype=np.uint8)
+        payload[: flat.shape[0]] = torch.from_numpy(flat.copy())
+    lens, payload = lens.to(dev), payload.to(dev)
+    all_lens = [torch.zeros_like(lens) for _ in range(world)]
+    all_payload = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(all_lens, lens)
+    dist.all_gather(all_payload, payload)
+    out = []
+    for r in range(world):
+        n = int(counts[r][0])
+        ls = all_lens[r][:n].cpu().tolist()
+        buf = all_payload[r].cpu().numpy().tobytes()
+        res, o = [], 0
+        for ln in ls:
+            res.append(buf[o:o + ln])
+            o += ln
+        out.append(res)
+    return out
+
+
+def gather_metrics(values: torch.Tensor) -> torch.Tensor:
+    """values: float64 [n_local, k] (same n_local on every rank) -> [world, n_local, k]."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return values.unsqueeze(0)
+    dev = _comm_device()
+    v = values.to(dev, torch.float64).contiguous()
+    outs = [torch.zeros_like(v) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, v)
+    return torch.stack([o.cpu() for o in outs])
+
+
+def max_over_ranks(x: float) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(x)
+    t = torch.tensor([x], dtype=torch.float64, device=_comm_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

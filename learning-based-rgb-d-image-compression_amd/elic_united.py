@@ -270,6 +270,14 @@ class ELIC_united:
                                             n.value, ctypes.byref(n)), "debug_symbols")
         return sym, idx
 
+    def set_profile(self, on: bool):
+        check(lib().rgbd_elic_set_profile(self._h, 1 if on else 0), "set_profile")
+
+    def profile_read(self):
+        ms, n, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+        check(lib().rgbd_elic_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
+        return {"conv_ms": ms.value, "launches": n.value, "flops": fl.value}
+
     def __del__(self):
         try:
             if self._h is not None:
