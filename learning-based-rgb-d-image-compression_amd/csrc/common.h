@@ -73,8 +73,9 @@ int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int 
 int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s);
 int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s);
 int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s);
-int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, float* scale,
-                 hipStream_t s);
+// w1t is fc.2.weight transposed to [hidden][C]; hid is a [N][hidden] scratch buffer
+int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
+                 float* scale, hipStream_t s);
 // mode 0: y = x*s ; mode 1: y = x + x*s   (s per (n, c))
 int launch_channel_scale(const float* x, int N, int HW, int cs, int C, const float* scale, int mode, float* y,
                          hipStream_t s);
@@ -87,7 +88,8 @@ struct DevTables {  // packed CDF rows for the device coder
     const int32_t* row_off;  // [nrows] start of each row in cdf
     const int32_t* sizes;  // [nrows] reference cdf_length (= pmf_length + 2)
     const int32_t* offsets;  // [nrows]
-    const uint16_t* lut;  // [nrows][257] decoder search accelerator: largest j with row[j] <= (b << 8)
+    const uint32_t* lut;  // [nrows][2^lut_bits + 1]: (j | row[j] << 16), j = largest index with row[j] <= bucket start
+    int lut_bits;
     int nrows;
     int total;  // total packed entries
 };
@@ -113,9 +115,10 @@ int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float
 
 // One wave per stream.  counts[s] symbols starting at sym_base[s]; writes words backwards into
 // out + s*cap_words; out_words[s] receives the number of 32-bit words produced (stream = last out_words words).
+// Streams [0, split) use tables t0, streams [split, nstreams) use t1 (rgb / depth in one launch).
 int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sym_base, const int64_t* counts,
-                       int nstreams, DevTables t, uint32_t* out, int64_t cap_words, int64_t* out_words, int* err,
-                       hipStream_t s);
+                       int nstreams, int split, DevTables t0, DevTables t1, uint32_t* out, int64_t cap_words,
+                       int64_t* out_words, int* err, hipStream_t s);
 // Stateful decode: state[s] = {x, pos}; init=1 loads the state from the first two words of each stream.
 int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,
                        int nstreams, uint64_t* state, int init, const int32_t* idx, int32_t* sym,

@@ -16,14 +16,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define KC 16  // channels per LDS stage
-
-template <int WM, int WN, int MT, int NT>
+// KC = channels per LDS stage (16 or 64).  LDS rows are padded by one 16-byte slot when KC > 16 so that the 16 rows a
+// ds_read_b128 lane group touches fall on different banks (row stride 272 B instead of 256 B).
+template <int WM, int WN, int MT, int NT, int KC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
                                                          int taps_per_stage)
 {
     constexpr int TM = 16 * MT * WM;
     constexpr int TP = 16 * NT * WN;
+    constexpr int RS = KC > 16 ? KC + 4 : KC;  // LDS row stride in floats
+    constexpr int C4 = KC / 4;                  // 16-byte slots per row
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -47,8 +49,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 
     const int PH = (TH - 1) * a.IS + a.span_y;
     const int PW = (TW - 1) * a.IS + a.span_x;
-    float* patch = smem;                      // [PH*PW][KC]
-    float* wl = smem + (size_t)PH * PW * KC;  // [taps_per_stage][TM][KC]
+    float* patch = smem;                      // [PH*PW][RS]
+    float* wl = smem + (size_t)PH * PW * RS;  // [taps_per_stage][TM][RS]
 
     const int ntaps = a.taps.n[phase];
     const int iy0 = ty0 * a.IS + a.min_dy;
@@ -69,56 +71,63 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         ppx[j] = p & (TW - 1);
     }
 
-    const int npatch4 = PH * PW * (KC / 4);
+    const int npatch4 = PH * PW * C4;
     const size_t img_base = (size_t)n * a.H * a.W;
 
     for (int ci0 = 0; ci0 < a.cin_pad; ci0 += KC) {
         __syncthreads();  // previous chunk's readers are done with patch and wl
         for (int f = tid; f < npatch4; f += 256) {
-            const int row = f >> 2, c4 = f & 3;
+            const int row = f / C4, c4 = f - row * C4;
             const int pr = row / PW, pc = row - pr * PW;
             const int iy = iy0 + pr, ix = ix0 + pc;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + c4 * 4 < a.cin_pad)
                 v = *reinterpret_cast<const f32x4*>(a.x + (img_base + (size_t)iy * a.W + ix) * a.xcs + ci0 + c4 * 4);
-            *reinterpret_cast<f32x4*>(patch + (size_t)row * KC + c4 * 4) = v;
+            *reinterpret_cast<f32x4*>(patch + (size_t)row * RS + c4 * 4) = v;
         }
         for (int t0 = 0; t0 < ntaps; t0 += taps_per_stage) {
             const int tg = min(taps_per_stage, ntaps - t0);
             if (t0) __syncthreads();  // readers of the previous tap group are done with wl
-            const int nw4 = tg * TM * (KC / 4);
+            const int nw4 = tg * TM * C4;
             for (int f = tid; f < nw4; f += 256) {
-                const int c4 = f & 3;
-                const int m = (f >> 2) % TM;
-                const int j = (f >> 2) / TM;
+                const int c4 = f % C4;
+                const int m = (f / C4) % TM;
+                const int j = (f / C4) / TM;
                 const int co = co0 + m;
                 f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (co < a.cout_pad)
+                if (co < a.cout_pad && ci0 + c4 * 4 < a.cin_pad)
                     v = *reinterpret_cast<const f32x4*>(
                         a.w + ((size_t)co * a.ntaps_total + a.taps.wt[phase][t0 + j]) * a.cin_pad + ci0 + c4 * 4);
-                *reinterpret_cast<f32x4*>(wl + ((size_t)j * TM + m) * KC + c4 * 4) = v;
+                *reinterpret_cast<f32x4*>(wl + ((size_t)j * TM + m) * RS + c4 * 4) = v;
             }
             __syncthreads();
-            for (int j = 0; j < tg; ++j) {
-                const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
-                const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
-                f32x4 af[MT], bf[NT];
+            // canonical accumulation order: 16-channel chunk -> tap -> channel.  A 64-channel stage therefore walks
+            // its four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so
+            // the fma chain of each output is the same for every KC / tile choice.
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    af[i] = *reinterpret_cast<const f32x4*>(
-                        wl + ((size_t)j * TM + (wm * MT + i) * 16 + l15) * KC + q * 4);
-#pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    const int row = (ppy[k] * a.IS + dy) * PW + ppx[k] * a.IS + dx;
-                    bf[k] = *reinterpret_cast<const f32x4*>(patch + (size_t)row * KC + q * 4);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int kk = 0; kk < KC / 16; ++kk) {
+                for (int j = 0; j < tg; ++j) {
+                    const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
+                    const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
+                    f32x4 af[MT], bf[NT];
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
+                        af[i] = *reinterpret_cast<const f32x4*>(
+                            wl + ((size_t)j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
 #pragma unroll
-                        for (int k = 0; k < NT; ++k)
-                            acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
+                    for (int k = 0; k < NT; ++k) {
+                        const int row = (ppy[k] * a.IS + dy) * PW + ppx[k] * a.IS + dx;
+                        bf[k] = *reinterpret_cast<const f32x4*>(patch + (size_t)row * RS + kk * 16 + q * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+                                acc[i][k] =
+                                    __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
+                }
             }
         }
     }
@@ -159,48 +168,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 
 namespace {
 
-struct TileCfg {
-    int wm, mt;  // WM in {1,2}; TM = 16*mt*wm
-};
-
-TileCfg pick_tile(int cout_pad)
-{
-    // candidates (TM): WM=1: 16,32,48 ; WM=2: 64,96,128,160 -- minimise padded couts, prefer the larger tile
-    static const TileCfg cands[] = {{2, 5}, {2, 4}, {2, 3}, {2, 2}, {1, 3}, {1, 2}, {1, 1}};
-    TileCfg best = cands[0];
-    long best_pad = -1;
-    for (const TileCfg& c : cands) {
-        const int tm = 16 * c.mt * c.wm;
-        const long padded = (long)((cout_pad + tm - 1) / tm) * tm;
-        if (best_pad < 0 || padded < best_pad) {
-            best = c;
-            best_pad = padded;
-        }
-    }
-    return best;
-}
-
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
-template <int WM, int WN, int MT, int NT>
-int launch_cfg(const ConvArgs& a, hipStream_t s)
+template <int WM, int WN, int MT, int NT, int KC>
+int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
 {
     constexpr int TM = 16 * MT * WM;
     constexpr int TP = 16 * NT * WN;
-    const int tw_log2 = (a.GW <= 8 || (a.GW % 16 != 0 && a.GW % 16 <= 8 && a.GW < 64)) ? 3 : 4;
+    constexpr int RS = KC > 16 ? KC + 4 : KC;
     const int TW = 1 << tw_log2, TH = TP / TW;
     const int tiles_x = (a.GW + TW - 1) / TW, tiles_y = (a.GH + TH - 1) / TH;
     const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
-    const size_t patch_bytes = (size_t)PH * PW * KC * sizeof(float);
-    const size_t tap_bytes = (size_t)TM * KC * sizeof(float);
+    const size_t patch_bytes = (size_t)PH * PW * RS * sizeof(float);
+    const size_t tap_bytes = (size_t)TM * RS * sizeof(float);
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
     if (patch_bytes + tap_bytes > 150 * 1024) return RGBD_ENOSPC;
     long room = ((long)LDS_BUDGET - (long)patch_bytes) / (long)tap_bytes;
     if (room < 1) room = 1;
-    int tps = (int)(room < max_taps ? room : max_taps);
+    const int tps = (int)(room < max_taps ? room : max_taps);
+    if (KC > 16 && tps < max_taps) return RGBD_ENOSPC;  // would break the canonical accumulation order
     const size_t lds = patch_bytes + (size_t)tps * tap_bytes;
-    auto kern = conv_mfma_kernel<WM, WN, MT, NT>;
+    auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC>;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -213,25 +202,94 @@ int launch_cfg(const ConvArgs& a, hipStream_t s)
     return RGBD_OK;
 }
 
+// tile-width choice for a TP-pixel tile: avoid ragged last tiles on narrow feature maps
+int pick_tw_log2(int GW, int GH, int TP)
+{
+    int best = 4;
+    long best_cost = -1;
+    for (int l = 2; l <= 4; ++l) {
+        const int TW = 1 << l, TH = TP / TW;
+        if (TH < 1) continue;
+        const long cost = (long)((GW + TW - 1) / TW) * ((GH + TH - 1) / TH);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && l > best)) {
+            best = l;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+struct Choice {
+    int wm, mt, nt, kc, tw_log2;
+};
+
+Choice choose(const ConvArgs& a)
+{
+    // 1. cout tile: minimise padded couts, prefer the larger tile
+    static const int cand[][2] = {{2, 5}, {2, 4}, {2, 3}, {2, 2}, {2, 1}, {1, 3}, {1, 2}, {1, 1}};
+    int wm = 2, mt = 4;
+    long best_pad = -1;
+    for (const auto& c : cand) {
+        const int tm = 16 * c[1] * c[0];
+        const long padded = (long)((a.cout_pad + tm - 1) / tm) * tm;
+        if (best_pad < 0 || padded < best_pad) {
+            wm = c[0];
+            mt = c[1];
+            best_pad = padded;
+        }
+    }
+    // 2. pixel tile: the largest of 128/64/32 that still fills the chip (>= 256 workgroups), else the smallest
+    const int nts[2][3] = {{2, 1, 1}, {4, 2, 1}};  // NT options for WM=1 (WN=4: TP=128,64,64) and WM=2 (WN=2: 128,64,32)
+    int nt = nts[wm - 1][0];
+    int tw = 4;
+    auto blocks_for = [&](int wm_, int mt_, int nt_, int* twl) {
+        const int tp = 16 * nt_ * (wm_ == 2 ? 2 : 4);
+        *twl = pick_tw_log2(a.GW, a.GH, tp);
+        const int TW = 1 << *twl, TH = tp / TW;
+        const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
+        const int tm = 16 * mt_ * wm_;
+        return tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase;
+    };
+    for (int o = 0; o < 3; ++o) {
+        nt = nts[wm - 1][o];
+        if (blocks_for(wm, mt, nt, &tw) >= 256) break;
+    }
+    // 3. still starved: halve the cout tile (keeps every output's fma chain unchanged -- only the tiling moves)
+    while (blocks_for(wm, mt, nt, &tw) < 192 && wm == 2 && mt > 1 && (a.cout_pad % (16 * ((mt + 1) / 2) * wm) == 0 || mt > 2))
+        mt = (mt + 1) / 2;
+    blocks_for(wm, mt, nt, &tw);
+    // 4. channels per stage: 64 when a stage would otherwise hold too few MFMAs between barriers
+    int max_taps = 1;
+    for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
+    int kc = 16;
+    if (a.cin_pad >= 64) {
+        const int tp = 16 * nt * (wm == 2 ? 2 : 4);
+        const int TW = 1 << tw, TH = tp / TW;
+        const size_t patch64 = (size_t)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 68 * 4;
+        const size_t tap64 = (size_t)16 * mt * wm * 68 * 4;
+        const long mfma_per_stage16 = (long)max_taps * 4 * mt * nt;
+        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400) kc = 64;
+    }
+    return Choice{wm, mt, nt, kc, tw};
+}
+
+#define RGBD_CASE(WM_, WN_, MT_, NT_)                                              \
+    if (c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                                 \
+        return c.kc == 64 ? launch_cfg<WM_, WN_, MT_, NT_, 64>(a, c.tw_log2, s)    \
+                          : launch_cfg<WM_, WN_, MT_, NT_, 16>(a, c.tw_log2, s);
+
 }  // namespace
 
 int launch_conv(const ConvArgs& a, hipStream_t s)
 {
-    if (a.cin_pad % KC || a.cout_pad % 16 || a.xcs % 4 || a.ycs % 4) return RGBD_EINVAL;
+    if (a.cin_pad % 16 || a.cout_pad % 16 || a.xcs % 4 || a.ycs % 4) return RGBD_EINVAL;
     if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;
     if (a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
-    const TileCfg c = pick_tile(a.cout_pad);
-    if (c.wm == 2) {
-        switch (c.mt) {
-        case 5: return launch_cfg<2, 2, 5, 4>(a, s);
-        case 4: return launch_cfg<2, 2, 4, 4>(a, s);
-        case 3: return launch_cfg<2, 2, 3, 4>(a, s);
-        default: return launch_cfg<2, 2, 2, 4>(a, s);
-        }
-    }
-    switch (c.mt) {
-    case 3: return launch_cfg<1, 4, 3, 2>(a, s);
-    case 2: return launch_cfg<1, 4, 2, 2>(a, s);
-    default: return launch_cfg<1, 4, 1, 2>(a, s);
-    }
+    const Choice c = choose(a);
+    RGBD_CASE(2, 2, 5, 4) RGBD_CASE(2, 2, 4, 4) RGBD_CASE(2, 2, 3, 4) RGBD_CASE(2, 2, 2, 4) RGBD_CASE(2, 2, 1, 4)
+    RGBD_CASE(2, 2, 5, 2) RGBD_CASE(2, 2, 4, 2) RGBD_CASE(2, 2, 3, 2) RGBD_CASE(2, 2, 2, 2) RGBD_CASE(2, 2, 1, 2)
+    RGBD_CASE(2, 2, 5, 1) RGBD_CASE(2, 2, 4, 1) RGBD_CASE(2, 2, 3, 1) RGBD_CASE(2, 2, 2, 1) RGBD_CASE(2, 2, 1, 1)
+    RGBD_CASE(1, 4, 3, 2) RGBD_CASE(1, 4, 2, 2) RGBD_CASE(1, 4, 1, 2)
+    RGBD_CASE(1, 4, 3, 1) RGBD_CASE(1, 4, 2, 1) RGBD_CASE(1, 4, 1, 1)
+    return RGBD_EINVAL;
 }

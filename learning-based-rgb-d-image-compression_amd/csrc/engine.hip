@@ -36,8 +36,11 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
         total += sizes[r] - 1;  // final 65536 entry is implicit
     }
     std::vector<uint16_t> packed(total);
-    const int LN = 257;
-    std::vector<uint16_t> lut((size_t)nrows * LN);
+    // bucket-table resolution: as fine as fits next to the packed rows in one CU's LDS (160 KiB)
+    int bits = 8;
+    while (bits > 4 && (size_t)nrows * ((1u << bits) + 1) * 4 + (size_t)total * 2 > 118 * 1024) --bits;
+    const int LN = (1 << bits) + 1;
+    std::vector<uint32_t> lut((size_t)nrows * LN);
     for (int r = 0; r < nrows; ++r) {
         const int32_t* row = cdf + (size_t)r * stride;
         const int len = sizes[r];
@@ -48,13 +51,13 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
         }
         int j = 0;
         for (int b = 0; b < LN; ++b) {
-            const int64_t lim = (int64_t)b << 8;
+            const int64_t lim = (int64_t)b << (16 - bits);
             while (j + 1 <= len - 2 && row[j + 1] <= lim) ++j;
-            lut[(size_t)r * LN + b] = (uint16_t)j;
+            lut[(size_t)r * LN + b] = (uint32_t)j | ((uint32_t)row[j] << 16);
         }
     }
     const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
-    const size_t b_lut = ((size_t)nrows * LN * 2 + 15) & ~(size_t)15;
+    const size_t b_lut = ((size_t)nrows * LN * 4 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
     const size_t bytes = b_cdf + b_lut + 3 * b_i32;
     if (ts->blob) (void)hipFree(ts->blob);
@@ -63,14 +66,15 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     std::vector<unsigned char> host(bytes, 0);
     unsigned char* p = host.data();
     memcpy(p, packed.data(), (size_t)total * 2);
-    memcpy(p + b_cdf, lut.data(), (size_t)nrows * LN * 2);
+    memcpy(p + b_cdf, lut.data(), (size_t)nrows * LN * 4);
     memcpy(p + b_cdf + b_lut, row_off.data(), (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + b_i32, sizes, (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);
     HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
     unsigned char* dp = (unsigned char*)ts->blob;
     ts->d.cdf = (const uint16_t*)dp;
-    ts->d.lut = (const uint16_t*)(dp + b_cdf);
+    ts->d.lut = (const uint32_t*)(dp + b_cdf);
+    ts->d.lut_bits = bits;
     ts->d.row_off = (const int32_t*)(dp + b_cdf + b_lut);
     ts->d.sizes = (const int32_t*)(dp + b_cdf + b_lut + b_i32);
     ts->d.offsets = (const int32_t*)(dp + b_cdf + b_lut + 2 * b_i32);
@@ -500,9 +504,10 @@ struct rgbd_elic {
         float* w1 = dense_of(p + ".fc.2.weight");
         float* mean = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
         float* sc = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
+        float* hid = (float*)arena.take((size_t)x.n * (x.c / 16 + 1) * sizeof(float));
         if (dry() || rc || !w0 || !w1) return sc;
         int r = launch_channel_mean(x.p, x.n, x.h * x.w, x.cs, x.c, mean, s);
-        if (!r) r = launch_se_fc(mean, x.n, x.c, x.c / 16, w0, w1, sc, s);
+        if (!r) r = launch_se_fc(mean, x.n, x.c, x.c / 16, w0, w1, hid, sc, s);
         if (r) fail(r);
         return sc;
     }
@@ -817,7 +822,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     rc = 0;
 
     // ---- persistent buffers of this call
-    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(8 * B + 64));
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(14 * B + 64));
     int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
     int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
     int32_t* zsym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
@@ -831,15 +836,19 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     dbg_idx = idx;
     dbg_per_mod = (int64_t)B * T;
 
-    // meta64 layout: [0,B) y stream_base ; [B,2B) y counts ; [2B,3B) z base ; [3B,4B) z counts ;
-    //                [4B,6B) y out_words (2 mods) ; [6B,8B) z out_words
-    std::vector<int64_t> hmeta((size_t)8 * B + 64, 0);
+    // meta64 layout: [0,B) y stream_base inside a modality region (checkerboard kernels) ; [2B,3B) z base ;
+    //   [3B,4B) z counts ; [6B,8B) z out_words ; from 8B: y encoder bases [2ny] (absolute), counts [2ny], out_words [2ny]
+    std::vector<int64_t> hmeta((size_t)14 * B + 64, 0);
     for (int b = 0; b < B; ++b) {
         hmeta[b] = per_image ? (int64_t)b * T : 0;
-        hmeta[B + b] = ycount;
         hmeta[2 * B + b] = (int64_t)b * Tz;
         hmeta[3 * B + b] = Tz;
     }
+    for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < ny; ++i) {
+            hmeta[(size_t)8 * B + (size_t)m * ny + i] = (int64_t)m * B * T + (per_image ? (int64_t)i * T : 0);
+            hmeta[(size_t)8 * B + 2 * ny + (size_t)m * ny + i] = ycount;
+        }
     if (!dry()) {
         HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(err, 0, 256, s));
@@ -881,7 +890,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
             int32_t* zi = zidx + (size_t)m * B * Tz;
             int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
             if (!r)
-                r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, tables[2 + m].d,
+                r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
                                        zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
             if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
             if (r) fail(r);
@@ -908,20 +917,20 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
 
     if (!dry() && !rc) {
-        for (int m = 0; m < 2 && !rc; ++m) {
-            const int r = launch_rans_encode(sym + (size_t)m * B * T, idx + (size_t)m * B * T, meta64, meta64 + B, ny,
-                                             tables[m].d, ywords + (size_t)m * ny * ycap, ycap,
-                                             meta64 + 4 * B + (size_t)m * B, err, s);
-            if (r) fail(r);
-        }
+        // both modalities in one launch: streams [0, ny) are rgb, [ny, 2ny) depth; bases are relative to `sym`
+        const int r = launch_rans_encode(sym, idx, meta64 + 8 * B, meta64 + 8 * B + 2 * ny, 2 * ny, ny, tables[0].d,
+                                         tables[1].d, ywords, ycap, meta64 + 8 * B + 4 * ny, err, s);
+        if (r) fail(r);
     }
     if (rc) return rc;
     if (dry()) return RGBD_OK;
 
     // ---- fetch the streams
-    std::vector<int64_t> ow((size_t)4 * B);
+    std::vector<int64_t> ow((size_t)4 * B, 0);  // [y rgb | y depth | z rgb | z depth], B slots each
     int herr = 0;
-    HIP_TRY(hipMemcpyAsync(ow.data(), meta64 + 4 * B, sizeof(int64_t) * 4 * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ow.data(), meta64 + 8 * B + 4 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ow.data() + B, meta64 + 8 * B + 5 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ow.data() + 2 * B, meta64 + 6 * B, sizeof(int64_t) * 2 * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (herr) return RGBD_ENOSPC;
@@ -1165,7 +1174,7 @@ int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t
         cleanup();
         return RGBD_EHIP;
     }
-    rc = launch_rans_encode(dsym, didx, dmeta, dmeta + 1, 1, t->ts.d, dout, capw, dmeta + 2, derr, nullptr);
+    rc = launch_rans_encode(dsym, didx, dmeta, dmeta + 1, 1, 1, t->ts.d, t->ts.d, dout, capw, dmeta + 2, derr, nullptr);
     int64_t nw = 0;
     int herr = 0;
     if (!rc) {
@@ -1416,9 +1425,16 @@ int rgbd_elic_finalize(rgbd_elic* m)
             if (r) return r;
             m->convs[name] = pc;
         } else if (ends_with(name, ".weight") && t.shape.size() == 2) {
+            // SE_Block linears; fc.2 ([C][hidden]) is kept transposed so the gate kernel reads it coalesced
+            std::vector<float> hv = t.v;
+            if (ends_with(name, ".fc.2.weight")) {
+                const size_t C = (size_t)t.shape[0], Hd = (size_t)t.shape[1];
+                for (size_t c = 0; c < C; ++c)
+                    for (size_t j = 0; j < Hd; ++j) hv[j * C + c] = t.v[c * Hd + j];
+            }
             float* d = nullptr;
-            HIP_TRY(hipMalloc((void**)&d, t.v.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(d, t.v.data(), t.v.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void**)&d, hv.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(d, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
             m->dense[name] = d;
         } else if (ends_with(name, "_entropy_bottleneck.quantiles")) {
             // medians = quantiles[:, 0, 1]  (entropy_models.py:316-318)

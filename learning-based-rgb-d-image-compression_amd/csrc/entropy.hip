@@ -12,9 +12,8 @@
 #define ESC_BITS 4
 #define ESC_MAX 15u
 #define RANS_LOW (1ull << 31)
-#define CHUNK 512
-#define LUT_BITS 8
-#define LUT_N ((1 << LUT_BITS) + 1)
+#define CHUNK 512    // decoder symbols per staging round
+#define ECHUNK 1024  // encoder symbols per staging round
 
 // ---------------------------------------------------------------------------------------------
 // checkerboard helpers: column of packed index k on a given row (utils/ckbd.py:51-64)
@@ -179,24 +178,25 @@ int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// rANS encoder.  Lanes expand a chunk of symbols to coded items in parallel; lane 0 then runs the state recurrence
-// over the chunk in reverse (rans_interface.cpp:167-185 pops from the back).
+// rANS encoder.  Lanes expand a chunk of symbols to coded items in parallel (table lookups, escape split and the
+// fp64 reciprocal of the frequency); lane 0 then runs the state recurrence over the chunk in reverse
+// (rans_interface.cpp:167-185 pops from the back).
 struct EncItem {
-    uint32_t sf;   // start | freq << 16
-    uint32_t raw;  // escape payload
-    uint32_t esc;  // 1 if the symbol hit the escape slot
-    uint32_t pad;
+    uint32_t sf;    // start | freq << 16
+    uint32_t raw;   // escape payload
+    uint64_t rcpb;  // bits of (double)1/freq, bit 63 set when the symbol hit the escape slot
 };
 
-__device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t freq, uint32_t* out, int64_t& w)
+__device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t freq, double rcp, uint32_t* out,
+                                        int64_t& w)
 {
-    const uint64_t lim = ((RANS_LOW >> PROB_BITS) << 32) * (uint64_t)freq;  // rans64.h:82-83
+    const uint64_t lim = (uint64_t)freq << 47;  // ((RANS_LOW >> 16) << 32) * freq, rans64.h:82-83
     if (x >= lim) {
         out[--w] = (uint32_t)x;
         x >>= 32;
     }
-    // exact x / freq through an fp64 estimate (|error| <= 1) and an integer fix-up
-    uint64_t qn = (uint64_t)(__ull2double_rz(x) * (1.0 / (double)freq));
+    // exact x / freq: fp64 estimate (|error| <= 1 since x < 2^63, q < 2^47) and an integer fix-up
+    uint64_t qn = (uint64_t)((double)x * rcp);
     int64_t r = (int64_t)(x - qn * (uint64_t)freq);
     while (r < 0) {
         --qn;
@@ -219,26 +219,28 @@ __device__ __forceinline__ void enc_put_bits(uint64_t& x, uint32_t val, uint32_t
     x = (x << ESC_BITS) | val;
 }
 
-__global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
-                                                         const int64_t* __restrict__ sym_base,
-                                                         const int64_t* __restrict__ counts, DevTables t,
-                                                         uint32_t* __restrict__ out, int64_t cap_words,
-                                                         int64_t* __restrict__ out_words, int* __restrict__ err)
+__global__ __launch_bounds__(256) void rans_encode_kernel(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
+                                                          const int64_t* __restrict__ sym_base,
+                                                          const int64_t* __restrict__ counts, int split, DevTables t0,
+                                                          DevTables t1, uint32_t* __restrict__ out, int64_t cap_words,
+                                                          int64_t* __restrict__ out_words, int* __restrict__ err)
 {
-    __shared__ EncItem items[CHUNK];
+    __shared__ EncItem items[ECHUNK];
+    __shared__ int s_bad;
     const int s = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const DevTables& t = s < split ? t0 : t1;
     const int64_t n = counts[s];
     const int64_t base = sym_base[s];
     uint32_t* o = out + (size_t)s * cap_words;
     uint64_t x = RANS_LOW;
     int64_t w = cap_words;
-    int bad = 0;
-    for (int64_t hi = n; hi > 0; hi -= CHUNK) {
-        const int64_t lo = hi > CHUNK ? hi - CHUNK : 0;
+    if (tid == 0) s_bad = 0;
+    for (int64_t hi = n; hi > 0; hi -= ECHUNK) {
+        const int64_t lo = hi > ECHUNK ? hi - ECHUNK : 0;
         const int cnt = (int)(hi - lo);
         __syncthreads();
-        for (int i = lane; i < cnt; i += 64) {
+        for (int i = tid; i < cnt; i += 256) {
             const int ti = idx[base + lo + i];
             const int top = t.sizes[ti] - 2;
             const int ro = t.row_off[ti];
@@ -252,36 +254,37 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                 v = top;
             }
             const uint32_t start = t.cdf[ro + v];
-            const uint32_t next = (v + 1 == top + 1) ? 65536u : (uint32_t)t.cdf[ro + v + 1];
+            const uint32_t next = (v == top) ? 65536u : (uint32_t)t.cdf[ro + v + 1];
+            const uint32_t freq = next - start;
             EncItem it;
-            it.sf = start | ((next - start) << 16);
+            it.sf = start | (freq << 16);
             it.raw = raw;
-            it.esc = (v == top);
-            it.pad = 0;
+            it.rcpb = (uint64_t)__double_as_longlong(1.0 / (double)freq) | ((uint64_t)(v == top) << 63);
             items[i] = it;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             for (int i = cnt - 1; i >= 0; --i) {
                 const EncItem it = items[i];
                 if (w < 24) {  // worst case for one symbol: 1 + 1 + 8 items + flush
-                    bad = 1;
+                    s_bad = 1;
                     break;
                 }
-                if (it.esc) {
+                if (it.rcpb >> 63) {
                     int nn = 0;
                     while (nn < 8 && (it.raw >> (nn * ESC_BITS)) != 0) ++nn;
                     for (int j = nn - 1; j >= 0; --j) enc_put_bits(x, (it.raw >> (j * ESC_BITS)) & ESC_MAX, o, w);
                     // count items were pushed as [15]*k + [rem]; reverse order = rem first (nn <= 8 -> k == 0)
                     enc_put_bits(x, (uint32_t)nn, o, w);
                 }
-                enc_put(x, it.sf & 0xFFFFu, it.sf >> 16, o, w);
+                enc_put(x, it.sf & 0xFFFFu, it.sf >> 16, __longlong_as_double((long long)(it.rcpb & ~(1ull << 63))), o, w);
             }
         }
-        if (__shfl(bad, 0, 64)) break;
+        __syncthreads();
+        if (s_bad) break;
     }
-    if (lane == 0) {
-        if (bad) {
+    if (tid == 0) {
+        if (s_bad) {
             *err = 1;
             out_words[s] = 0;
         } else {
@@ -294,39 +297,47 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
 }
 
 int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sym_base, const int64_t* counts,
-                       int nstreams, DevTables t, uint32_t* out, int64_t cap_words, int64_t* out_words, int* err,
-                       hipStream_t s)
+                       int nstreams, int split, DevTables t0, DevTables t1, uint32_t* out, int64_t cap_words,
+                       int64_t* out_words, int* err, hipStream_t s)
 {
     if (nstreams <= 0) return RGBD_OK;
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), 0, s, sym, idx, sym_base, counts, t, out, cap_words,
-                       out_words, err);
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(256), 0, s, sym, idx, sym_base, counts, split, t0, t1, out,
+                       cap_words, out_words, err);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// rANS decoder.  The packed u16 CDF rows and a per-row 2^LUT_BITS-bucket search accelerator live in LDS; lane 0
-// runs the state recurrence, the other lanes stage indexes in and symbols out.  The (x, pos) state persists in HBM
-// between the 20 per-part launches of one stream (RansDecoder::decode_stream semantics).
+// rANS decoder.  The packed u16 CDF rows and a per-row bucket table (cum >> (16 - lut_bits) -> first candidate symbol
+// and its start) live in LDS, as does a window of the stream's words; lane 0 runs the state recurrence, the other
+// lanes stage indexes / stream words in and symbols out.  The (x, pos) state persists in HBM between the 20 per-part
+// launches of one stream (RansDecoder::decode_stream semantics).
 struct DecMeta {
     int32_t ro;    // row start in the packed table
     int32_t len;   // reference cdf_length
     int32_t off;   // symbol offset
-    int32_t row;   // table row
+    int32_t lb;    // start of the row's bucket table
 };
 
-__device__ __forceinline__ uint32_t dec_word(const uint32_t* st, int64_t nwords, int64_t& pos)
+#define WWIN 1024  // stream words staged per chunk
+
+__device__ __forceinline__ uint32_t dec_word(const uint32_t* st, int64_t nwords, int64_t& pos, const uint32_t* win,
+                                             int64_t win0)
 {
-    const uint32_t v = pos < nwords ? st[pos] : 0u;
+    uint32_t v = 0u;
+    const int64_t rel = pos - win0;
+    if (rel >= 0 && rel < WWIN) v = win[rel];  // staged (zero beyond the end of the stream)
+    else if (pos < nwords) v = st[pos];
     ++pos;
     return v;
 }
 
-__device__ __forceinline__ uint32_t dec_bits(uint64_t& x, const uint32_t* st, int64_t nwords, int64_t& pos)
+__device__ __forceinline__ uint32_t dec_bits(uint64_t& x, const uint32_t* st, int64_t nwords, int64_t& pos,
+                                             const uint32_t* win, int64_t win0)
 {
     const uint32_t val = (uint32_t)(x & ESC_MAX);  // rans_interface.cpp:80-96
     x >>= ESC_BITS;
-    if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos);
+    if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos, win, win0);
     return val;
 }
 
@@ -338,17 +349,19 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                                                           const int64_t* __restrict__ sym_base, int64_t part_off,
                                                           int64_t count, DevTables t)
 {
-    const uint16_t* __restrict__ lut = t.lut;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    uint16_t* cdf = reinterpret_cast<uint16_t*>(dsm);                         // [t.total (+pad)]
-    uint16_t* sl = cdf + ((t.total + 7) & ~7);                                // [nrows][LUT_N]
-    DecMeta* meta = reinterpret_cast<DecMeta*>(sl + ((t.nrows * LUT_N + 7) & ~7));  // [CHUNK]
-    int32_t* osym = reinterpret_cast<int32_t*>(meta + CHUNK);                 // [CHUNK]
+    const int lut_n = (1 << t.lut_bits) + 1;
+    int64_t& s_pos = *reinterpret_cast<int64_t*>(dsm);                                // 16-byte header slot
+    uint32_t* sl = reinterpret_cast<uint32_t*>(dsm + 16);                             // [nrows][lut_n] (+pad to 16 B)
+    uint32_t* win = sl + ((t.nrows * lut_n + 3) & ~3);                                // [WWIN]
+    DecMeta* meta = reinterpret_cast<DecMeta*>(win + WWIN);                           // [CHUNK]
+    int32_t* osym = reinterpret_cast<int32_t*>(meta + CHUNK);                         // [CHUNK]
+    uint16_t* cdf = reinterpret_cast<uint16_t*>(osym + CHUNK);                        // [t.total]
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     for (int i = tid; i < t.total; i += 256) cdf[i] = t.cdf[i];
-    for (int i = tid; i < t.nrows * LUT_N; i += 256) sl[i] = lut[i];
+    for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = t.lut[i];
 
     const uint32_t* st = streams + stream_off[s];
     const int64_t nwords = stream_len[s];
@@ -362,59 +375,65 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
             x = state[2 * s];
             pos = (int64_t)state[2 * s + 1];
         }
+        s_pos = pos;
     }
     const int64_t base = sym_base[s] + part_off;
+    const int shift = 16 - t.lut_bits;
     for (int64_t lo = 0; lo < count; lo += CHUNK) {
         const int cnt = (int)((count - lo) < CHUNK ? (count - lo) : CHUNK);
         __syncthreads();
+        const int64_t win0 = s_pos;
+        for (int i = tid; i < WWIN; i += 256) win[i] = (win0 + i < nwords) ? st[win0 + i] : 0u;
         for (int i = tid; i < cnt; i += 256) {
             const int ti = idx[base + lo + i];
             DecMeta m;
             m.ro = t.row_off[ti];
             m.len = t.sizes[ti];
             m.off = t.offsets[ti];
-            m.row = ti;
+            m.lb = ti * lut_n;
             meta[i] = m;
         }
         __syncthreads();
         if (tid == 0) {
+            DecMeta mn = meta[0];
             for (int i = 0; i < cnt; ++i) {
-                const DecMeta m = meta[i];
+                const DecMeta m = mn;
+                if (i + 1 < cnt) mn = meta[i + 1];  // independent of the state: overlaps the dependent chain below
                 const uint32_t cum = (uint32_t)(x & 0xFFFFu);
                 const uint16_t* row = cdf + m.ro;
-                const uint16_t* lr = sl + m.row * LUT_N + (cum >> (16 - LUT_BITS));
-                int a = lr[0];      // largest j with row[j] <= bucket start
-                int b = lr[1] + 1;  // one past the largest j with row[j] <= next bucket start - 1 ... (exclusive bound)
-                while (b - a > 1) {
-                    const int mid = (a + b) >> 1;
-                    if (row[mid] <= cum) a = mid;
-                    else b = mid;
+                const uint32_t e = sl[m.lb + (cum >> shift)];
+                int a = (int)(e & 0xFFFFu);
+                uint32_t start = e >> 16;
+                const int last = m.len - 2;  // escape slot; row[last + 1] is the implicit 65536
+                uint32_t next = (a == last) ? 65536u : (uint32_t)row[a + 1];
+                while (cum >= next) {  // walk forward inside the bucket (usually 0 or 1 step)
+                    ++a;
+                    start = next;
+                    next = (a == last) ? 65536u : (uint32_t)row[a + 1];
                 }
-                const uint32_t start = row[a];
-                const uint32_t next = (a + 1 == m.len - 1) ? 65536u : (uint32_t)row[a + 1];
                 const uint32_t freq = next - start;
                 x = (uint64_t)freq * (x >> PROB_BITS) + cum - start;  // rans64.h:131-133
-                if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos);
+                if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos, win, win0);
                 int v = a;
-                const int top = m.len - 2;
-                if (v == top) {  // escape: rans_interface.cpp:323-345
-                    int nib = (int)dec_bits(x, st, nwords, pos);
+                if (v == last) {  // escape: rans_interface.cpp:323-345
+                    int nib = (int)dec_bits(x, st, nwords, pos, win, win0);
                     int nn = nib;
                     while (nib == (int)ESC_MAX) {
-                        nib = (int)dec_bits(x, st, nwords, pos);
+                        nib = (int)dec_bits(x, st, nwords, pos, win, win0);
                         nn += nib;
                     }
                     int raw = 0;
                     for (int j = 0; j < nn; ++j) {
-                        nib = (int)dec_bits(x, st, nwords, pos);
+                        nib = (int)dec_bits(x, st, nwords, pos, win, win0);
                         if (j < 8) raw |= nib << (j * ESC_BITS);
                     }
                     v = raw >> 1;
                     if (raw & 1) v = -v - 1;
-                    else v += top;
+                    else v += last;
                 }
                 osym[i] = v + m.off;
             }
+            s_pos = pos;
         }
         __syncthreads();
         for (int i = tid; i < cnt; i += 256) sym[base + lo + i] = osym[i];
@@ -427,8 +446,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 
 size_t rans_decode_lds_bytes(const DevTables& t)
 {
-    return (size_t)((t.total + 7) & ~7) * 2 + (size_t)((t.nrows * LUT_N + 7) & ~7) * 2 + CHUNK * sizeof(DecMeta) +
-           CHUNK * sizeof(int32_t);
+    const size_t lut_n = ((size_t)1 << t.lut_bits) + 1;
+    return 16 + (((size_t)t.nrows * lut_n + 3) & ~(size_t)3) * 4 + WWIN * 4 + CHUNK * sizeof(DecMeta) +
+           CHUNK * sizeof(int32_t) + (((size_t)t.total * 2 + 15) & ~(size_t)15);
 }
 
 int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,
@@ -437,7 +457,7 @@ int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words,
 {
     if (nstreams <= 0 || count <= 0) return RGBD_OK;
     const size_t lds = rans_decode_lds_bytes(t);
-    if (lds > 160 * 1024) return RGBD_ENOSPC;
+    if (lds > 158 * 1024) return RGBD_ENOSPC;
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel),

@@ -179,37 +179,43 @@ int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mea
     return RGBD_OK;
 }
 
-// scale[n][c] = sigmoid(W1 @ relu(W0 @ mean[n]))   W0: [hidden][C], W1: [C][hidden]; one workgroup per image.
-__global__ void se_fc_kernel(const float* __restrict__ mean, int C, int hidden, const float* __restrict__ w0,
-                             const float* __restrict__ w1, float* __restrict__ scale)
+// SE gate: scale[n][c] = sigmoid(W1 @ relu(W0 @ mean[n])).  W0: [hidden][C]; W1 is stored TRANSPOSED, [hidden][C],
+// so both passes read weights with consecutive lanes on consecutive addresses.
+// pass 1: one wavefront per (hidden unit, image); lanes stride the dot product, fixed shuffle-tree reduction.
+__global__ __launch_bounds__(64) void se_hidden_kernel(const float* __restrict__ mean, int C, int hidden,
+                                                       const float* __restrict__ w0, float* __restrict__ hid)
 {
-    extern __shared__ float sh[];  // [C] means + [hidden]
-    float* m = sh;
-    float* hbuf = sh + C;
-    const size_t n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) m[c] = mean[n * C + c];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int j = wave; j < hidden; j += nw) {  // one wave per hidden unit, lanes stride the dot product
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], m[c], s);
+    const int j = blockIdx.x;
+    const size_t n = blockIdx.y;
+    const int lane = threadIdx.x;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], mean[n * C + c], s);
 #pragma unroll
-        for (int off = 32; off; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) hbuf[j] = fmaxf(s, 0.f);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int j = 0; j < hidden; ++j) s = fmaf(w1[(size_t)c * hidden + j], hbuf[j], s);
-        scale[n * C + c] = 1.0f / (1.0f + expf(-s));
-    }
+    for (int off = 32; off; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) hid[n * hidden + j] = fmaxf(s, 0.f);
 }
 
-int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, float* scale,
-                 hipStream_t s)
+// pass 2: one thread per (image, channel), sequential over the hidden units.
+__global__ void se_gate_kernel(const float* __restrict__ hid, int C, int hidden, const float* __restrict__ w1t,
+                               float* __restrict__ scale)
 {
-    const size_t lds = (size_t)(C + hidden) * sizeof(float);
-    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), lds, s, mean, C, hidden, w0, w1, scale);
+    extern __shared__ float hsh[];
+    const size_t n = blockIdx.y;
+    for (int j = threadIdx.x; j < hidden; j += blockDim.x) hsh[j] = hid[n * hidden + j];
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int j = 0; j < hidden; ++j) s = fmaf(w1t[(size_t)j * C + c], hsh[j], s);
+    scale[n * C + c] = 1.0f / (1.0f + expf(-s));
+}
+
+int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
+                 float* scale, hipStream_t s)
+{
+    hipLaunchKernelGGL(se_hidden_kernel, dim3(hidden, N), dim3(64), 0, s, mean, C, hidden, w0, hid);
+    hipLaunchKernelGGL(se_gate_kernel, dim3((C + 255) / 256, N), dim3(256), (size_t)hidden * sizeof(float), s, hid, C,
+                       hidden, w1t, scale);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
