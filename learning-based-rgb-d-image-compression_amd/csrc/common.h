@@ -88,7 +88,7 @@ struct DevTables {  // packed CDF rows for the device coder
     const int32_t* row_off;  // [nrows] start of each row in cdf
     const int32_t* sizes;  // [nrows] reference cdf_length (= pmf_length + 2)
     const int32_t* offsets;  // [nrows]
-    const uint32_t* lut;  // [nrows][2^lut_bits + 1]: (j | row[j] << 16), j = largest index with row[j] <= bucket start
+    const uint32_t* lut;  // [nrows][2^lut_bits + 1][2]: {j | row[j] << 16, freq_j}, j = largest index with row[j] <= bucket start
     int lut_bits;
     int nrows;
     int total;  // total packed entries

@@ -225,52 +225,47 @@ struct Choice {
 
 Choice choose(const ConvArgs& a)
 {
-    // 1. cout tile: minimise padded couts, prefer the larger tile
-    static const int cand[][2] = {{2, 5}, {2, 4}, {2, 3}, {2, 2}, {2, 1}, {1, 3}, {1, 2}, {1, 1}};
-    int wm = 2, mt = 4;
-    long best_pad = -1;
-    for (const auto& c : cand) {
-        const int tm = 16 * c[1] * c[0];
-        const long padded = (long)((a.cout_pad + tm - 1) / tm) * tm;
-        if (best_pad < 0 || padded < best_pad) {
-            wm = c[0];
-            mt = c[1];
-            best_pad = padded;
-        }
-    }
-    // 2. pixel tile: the largest of 128/64/32 that still fills the chip (>= 256 workgroups), else the smallest
-    const int nts[2][3] = {{2, 1, 1}, {4, 2, 1}};  // NT options for WM=1 (WN=4: TP=128,64,64) and WM=2 (WN=2: 128,64,32)
-    int nt = nts[wm - 1][0];
-    int tw = 4;
-    auto blocks_for = [&](int wm_, int mt_, int nt_, int* twl) {
-        const int tp = 16 * nt_ * (wm_ == 2 ? 2 : 4);
-        *twl = pick_tw_log2(a.GW, a.GH, tp);
-        const int TW = 1 << *twl, TH = tp / TW;
-        const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
-        const int tm = 16 * mt_ * wm_;
-        return tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase;
-    };
-    for (int o = 0; o < 3; ++o) {
-        nt = nts[wm - 1][o];
-        if (blocks_for(wm, mt, nt, &tw) >= 256) break;
-    }
-    // 3. still starved: halve the cout tile (keeps every output's fma chain unchanged -- only the tiling moves)
-    while (blocks_for(wm, mt, nt, &tw) < 192 && wm == 2 && mt > 1 && (a.cout_pad % (16 * ((mt + 1) / 2) * wm) == 0 || mt > 2))
-        mt = (mt + 1) / 2;
-    blocks_for(wm, mt, nt, &tw);
-    // 4. channels per stage: 64 when a stage would otherwise hold too few MFMAs between barriers
+    // Pick the tile by a small cost model (cycles per CU): MFMA time of the workgroups a CU has to run vs the bytes
+    // each workgroup pulls from L2 (its weight slab K*TM plus the input patch per channel chunk).  Multi-tap layers on
+    // small feature maps are weight-traffic bound, so narrow cout tiles x wide pixel tiles win there; big feature maps
+    // pick the large square-ish tiles.  The choice never changes results: every output keeps its fma chain.
+    static const int cand[][3] = {{2, 5, 4}, {2, 4, 4}, {2, 3, 4}, {2, 2, 4}, {2, 1, 4}, {2, 5, 2}, {2, 4, 2},
+                                  {2, 3, 2}, {2, 2, 2}, {2, 1, 2}, {2, 5, 1}, {2, 4, 1}, {2, 3, 1}, {2, 2, 1},
+                                  {2, 1, 1}, {1, 3, 2}, {1, 2, 2}, {1, 1, 2}, {1, 3, 1}, {1, 2, 1}, {1, 1, 1}};
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
-    int kc = 16;
-    if (a.cin_pad >= 64) {
-        const int tp = 16 * nt * (wm == 2 ? 2 : 4);
-        const int TW = 1 << tw, TH = tp / TW;
-        const size_t patch64 = (size_t)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 68 * 4;
-        const size_t tap64 = (size_t)16 * mt * wm * 68 * 4;
-        const long mfma_per_stage16 = (long)max_taps * 4 * mt * nt;
-        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400) kc = 64;
+    const double K = (double)max_taps * a.cin_pad;
+    Choice best{2, 4, 4, 16, 4};
+    double best_cost = -1.0;
+    for (const auto& c : cand) {
+        const int wm = c[0], mt = c[1], nt = c[2];
+        const int tm = 16 * mt * wm, tp = 16 * nt * (wm == 2 ? 2 : 4);
+        const int twl = pick_tw_log2(a.GW, a.GH, tp);
+        const int TW = 1 << twl, TH = tp / TW;
+        const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
+        const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase;
+        const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
+        if ((size_t)PH * PW * 64 + (size_t)tm * 64 > (size_t)LDS_BUDGET) continue;
+        const double mfma = (double)mt * nt * (K / 4.0) * 32.0 + 3000.0;             // cycles per workgroup (+ prologue)
+        const double load = (K * tm * 4.0 + (double)PH * PW * a.cin_pad * 4.0) / 12.0;  // ~12 B/clk/CU from L2
+        const long nb = (blocks + 255) / 256;
+        const double cost = nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load);
+        if (best_cost < 0 || cost < best_cost * 0.999) {
+            best_cost = cost;
+            best = Choice{wm, mt, nt, 16, twl};
+        }
     }
-    return Choice{wm, mt, nt, kc, tw};
+    // channels per stage: 64 when one stage can hold every tap (keeps the canonical order) and a 16-channel stage
+    // would hold too few MFMAs between barriers
+    if (a.cin_pad >= 64) {
+        const int tp = 16 * best.nt * (best.wm == 2 ? 2 : 4);
+        const int TW = 1 << best.tw_log2, TH = tp / TW;
+        const size_t patch64 = (size_t)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 68 * 4;
+        const size_t tap64 = (size_t)16 * best.mt * best.wm * 68 * 4;
+        const long mfma_per_stage16 = (long)max_taps * 4 * best.mt * best.nt;
+        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400) best.kc = 64;
+    }
+    return best;
 }
 
 #define RGBD_CASE(WM_, WN_, MT_, NT_)                                              \

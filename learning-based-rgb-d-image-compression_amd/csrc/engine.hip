@@ -38,9 +38,9 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     std::vector<uint16_t> packed(total);
     // bucket-table resolution: as fine as fits next to the packed rows in one CU's LDS (160 KiB)
     int bits = 8;
-    while (bits > 4 && (size_t)nrows * ((1u << bits) + 1) * 4 + (size_t)total * 2 > 118 * 1024) --bits;
+    while (bits > 4 && (size_t)nrows * ((1u << bits) + 1) * 8 + (size_t)total * 2 > 124 * 1024) --bits;
     const int LN = (1 << bits) + 1;
-    std::vector<uint32_t> lut((size_t)nrows * LN);
+    std::vector<uint32_t> lut((size_t)nrows * LN * 2);  // {j | row[j] << 16, freq_j}
     for (int r = 0; r < nrows; ++r) {
         const int32_t* row = cdf + (size_t)r * stride;
         const int len = sizes[r];
@@ -53,11 +53,12 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
         for (int b = 0; b < LN; ++b) {
             const int64_t lim = (int64_t)b << (16 - bits);
             while (j + 1 <= len - 2 && row[j + 1] <= lim) ++j;
-            lut[(size_t)r * LN + b] = (uint32_t)j | ((uint32_t)row[j] << 16);
+            lut[((size_t)r * LN + b) * 2] = (uint32_t)j | ((uint32_t)row[j] << 16);
+            lut[((size_t)r * LN + b) * 2 + 1] = (uint32_t)(row[j + 1] - row[j]);
         }
     }
     const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
-    const size_t b_lut = ((size_t)nrows * LN * 4 + 15) & ~(size_t)15;
+    const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
     const size_t bytes = b_cdf + b_lut + 3 * b_i32;
     if (ts->blob) (void)hipFree(ts->blob);
@@ -66,7 +67,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     std::vector<unsigned char> host(bytes, 0);
     unsigned char* p = host.data();
     memcpy(p, packed.data(), (size_t)total * 2);
-    memcpy(p + b_cdf, lut.data(), (size_t)nrows * LN * 4);
+    memcpy(p + b_cdf, lut.data(), (size_t)nrows * LN * 8);
     memcpy(p + b_cdf + b_lut, row_off.data(), (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + b_i32, sizes, (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);

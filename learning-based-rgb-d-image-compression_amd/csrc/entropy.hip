@@ -178,8 +178,18 @@ int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// rANS encoder.  Lanes expand a chunk of symbols to coded items in parallel (table lookups, escape split and the
-// fp64 reciprocal of the frequency); lane 0 then runs the state recurrence over the chunk in reverse
+// Serial parts below run in wave 0 with ALL lanes executing the same (uniform) computation: every value loaded from
+// LDS goes through readfirstlane, so the state recurrence lives in SGPRs, its branches are scalar branches (no exec
+// masking), and only the fp64 quotient estimate / LDS traffic use the vector pipe.
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t v)
+{
+    return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rANS encoder.  All threads expand a chunk of symbols to coded items in parallel (table lookups, escape split and the
+// fp64 reciprocal of the frequency); wave 0 then runs the state recurrence over the chunk in reverse
 // (rans_interface.cpp:167-185 pops from the back).
 struct EncItem {
     uint32_t sf;    // start | freq << 16
@@ -187,16 +197,19 @@ struct EncItem {
     uint64_t rcpb;  // bits of (double)1/freq, bit 63 set when the symbol hit the escape slot
 };
 
-__device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t freq, double rcp, uint32_t* out,
-                                        int64_t& w)
+__device__ __forceinline__ void enc_emit(uint64_t& x, uint32_t* out, int64_t& w, int lane)
 {
-    const uint64_t lim = (uint64_t)freq << 47;  // ((RANS_LOW >> 16) << 32) * freq, rans64.h:82-83
-    if (x >= lim) {
-        out[--w] = (uint32_t)x;
-        x >>= 32;
-    }
+    --w;
+    if (lane == 0) out[w] = (uint32_t)x;
+    x >>= 32;
+}
+
+__device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t freq, double rcp, uint32_t* out,
+                                        int64_t& w, int lane)
+{
+    if (x >= ((uint64_t)freq << 47)) enc_emit(x, out, w, lane);  // ((RANS_LOW >> 16) << 32) * freq, rans64.h:82-83
     // exact x / freq: fp64 estimate (|error| <= 1 since x < 2^63, q < 2^47) and an integer fix-up
-    uint64_t qn = (uint64_t)((double)x * rcp);
+    uint64_t qn = rfl64((uint64_t)((double)x * rcp));
     int64_t r = (int64_t)(x - qn * (uint64_t)freq);
     while (r < 0) {
         --qn;
@@ -209,13 +222,10 @@ __device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t fr
     x = (qn << PROB_BITS) + (uint64_t)r + start;
 }
 
-__device__ __forceinline__ void enc_put_bits(uint64_t& x, uint32_t val, uint32_t* out, int64_t& w)
+__device__ __forceinline__ void enc_put_bits(uint64_t& x, uint32_t val, uint32_t* out, int64_t& w, int lane)
 {
-    const uint64_t lim = ((RANS_LOW >> 16) << 32) * (uint64_t)(1u << (16 - ESC_BITS));  // rans_interface.cpp:67-68
-    if (x >= lim) {
-        out[--w] = (uint32_t)x;
-        x >>= 32;
-    }
+    // ((RANS_LOW >> 16) << 32) * (1 << (16 - 4)) = 2^59, rans_interface.cpp:67-68
+    if (x >= (1ull << 59)) enc_emit(x, out, w, lane);
     x = (x << ESC_BITS) | val;
 }
 
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void rans_encode_kernel(const int32_t* __restr
                                                           DevTables t1, uint32_t* __restrict__ out, int64_t cap_words,
                                                           int64_t* __restrict__ out_words, int* __restrict__ err)
 {
-    __shared__ EncItem items[ECHUNK];
+    __shared__ __attribute__((aligned(16))) EncItem items[ECHUNK];
     __shared__ int s_bad;
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -263,22 +273,28 @@ __global__ __launch_bounds__(256) void rans_encode_kernel(const int32_t* __restr
             items[i] = it;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {
+            x = rfl64(x);  // re-assert uniformity (merged with the idle waves' copy at every chunk)
+            w = (int64_t)rfl64((uint64_t)w);
+            int bad = 0;
             for (int i = cnt - 1; i >= 0; --i) {
-                const EncItem it = items[i];
+                const uint4 itv = *reinterpret_cast<const uint4*>(&items[i]);
+                const uint32_t sf = rfl(itv.x), raw = rfl(itv.y), rlo = rfl(itv.z), rhi = rfl(itv.w);
                 if (w < 24) {  // worst case for one symbol: 1 + 1 + 8 items + flush
-                    s_bad = 1;
+                    bad = 1;
                     break;
                 }
-                if (it.rcpb >> 63) {
+                if (rhi >> 31) {
                     int nn = 0;
-                    while (nn < 8 && (it.raw >> (nn * ESC_BITS)) != 0) ++nn;
-                    for (int j = nn - 1; j >= 0; --j) enc_put_bits(x, (it.raw >> (j * ESC_BITS)) & ESC_MAX, o, w);
+                    while (nn < 8 && (raw >> (nn * ESC_BITS)) != 0) ++nn;
+                    for (int j = nn - 1; j >= 0; --j) enc_put_bits(x, (raw >> (j * ESC_BITS)) & ESC_MAX, o, w, tid);
                     // count items were pushed as [15]*k + [rem]; reverse order = rem first (nn <= 8 -> k == 0)
-                    enc_put_bits(x, (uint32_t)nn, o, w);
+                    enc_put_bits(x, (uint32_t)nn, o, w, tid);
                 }
-                enc_put(x, it.sf & 0xFFFFu, it.sf >> 16, __longlong_as_double((long long)(it.rcpb & ~(1ull << 63))), o, w);
+                const double rcp = __longlong_as_double((long long)(((uint64_t)(rhi & 0x7FFFFFFFu) << 32) | rlo));
+                enc_put(x, sf & 0xFFFFu, sf >> 16, rcp, o, w, tid);
             }
+            if (bad && tid == 0) s_bad = 1;
         }
         __syncthreads();
         if (s_bad) break;
@@ -308,38 +324,12 @@ int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sy
 }
 
 // ---------------------------------------------------------------------------------------------
-// rANS decoder.  The packed u16 CDF rows and a per-row bucket table (cum >> (16 - lut_bits) -> first candidate symbol
-// and its start) live in LDS, as does a window of the stream's words; lane 0 runs the state recurrence, the other
-// lanes stage indexes / stream words in and symbols out.  The (x, pos) state persists in HBM between the 20 per-part
-// launches of one stream (RansDecoder::decode_stream semantics).
-struct DecMeta {
-    int32_t ro;    // row start in the packed table
-    int32_t len;   // reference cdf_length
-    int32_t off;   // symbol offset
-    int32_t lb;    // start of the row's bucket table
-};
-
+// rANS decoder.  LDS holds the packed u16 CDF rows, a per-row bucket table (cum >> (16 - lut_bits) -> first candidate
+// symbol, its start and its frequency: one 8-byte read resolves a symbol unless a boundary falls inside the bucket)
+// and a window of the stream's words.  Wave 0 runs the state recurrence (scalar, see above); the other waves stage
+// indexes / stream words in and symbols out.  The (x, pos) state persists in HBM between the 20 per-part launches of
+// one stream (RansDecoder::decode_stream semantics).
 #define WWIN 1024  // stream words staged per chunk
-
-__device__ __forceinline__ uint32_t dec_word(const uint32_t* st, int64_t nwords, int64_t& pos, const uint32_t* win,
-                                             int64_t win0)
-{
-    uint32_t v = 0u;
-    const int64_t rel = pos - win0;
-    if (rel >= 0 && rel < WWIN) v = win[rel];  // staged (zero beyond the end of the stream)
-    else if (pos < nwords) v = st[pos];
-    ++pos;
-    return v;
-}
-
-__device__ __forceinline__ uint32_t dec_bits(uint64_t& x, const uint32_t* st, int64_t nwords, int64_t& pos,
-                                             const uint32_t* win, int64_t win0)
-{
-    const uint32_t val = (uint32_t)(x & ESC_MAX);  // rans_interface.cpp:80-96
-    x >>= ESC_BITS;
-    if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos, win, win0);
-    return val;
-}
 
 __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __restrict__ streams,
                                                           const int64_t* __restrict__ stream_off,
@@ -351,89 +341,110 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int lut_n = (1 << t.lut_bits) + 1;
-    int64_t& s_pos = *reinterpret_cast<int64_t*>(dsm);                                // 16-byte header slot
-    uint32_t* sl = reinterpret_cast<uint32_t*>(dsm + 16);                             // [nrows][lut_n] (+pad to 16 B)
-    uint32_t* win = sl + ((t.nrows * lut_n + 3) & ~3);                                // [WWIN]
-    DecMeta* meta = reinterpret_cast<DecMeta*>(win + WWIN);                           // [CHUNK]
-    int32_t* osym = reinterpret_cast<int32_t*>(meta + CHUNK);                         // [CHUNK]
-    uint16_t* cdf = reinterpret_cast<uint16_t*>(osym + CHUNK);                        // [t.total]
+    int64_t* hdr = reinterpret_cast<int64_t*>(dsm);                                    // 16-byte header: [pos]
+    uint2* sl = reinterpret_cast<uint2*>(dsm + 16);                                    // [nrows][lut_n]
+    uint32_t* win = reinterpret_cast<uint32_t*>(sl + ((t.nrows * lut_n + 1) & ~1));    // [WWIN]
+    uint2* meta = reinterpret_cast<uint2*>(win + WWIN);                                // [CHUNK] packed row info
+    int32_t* osym = reinterpret_cast<int32_t*>(meta + CHUNK);                          // [CHUNK]
+    uint16_t* cdf = reinterpret_cast<uint16_t*>(osym + CHUNK);                         // [t.total]
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     for (int i = tid; i < t.total; i += 256) cdf[i] = t.cdf[i];
-    for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = t.lut[i];
-
+    {
+        const uint2* gl = reinterpret_cast<const uint2*>(t.lut);
+        for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = gl[i];
+    }
     const uint32_t* st = streams + stream_off[s];
     const int64_t nwords = stream_len[s];
-    uint64_t x = 0;
-    int64_t pos = 0;
-    if (tid == 0) {
-        if (init) {
-            x = (uint64_t)(nwords > 0 ? st[0] : 0u) | ((uint64_t)(nwords > 1 ? st[1] : 0u) << 32);  // rans64.h:107-115
-            pos = 2;
-        } else {
-            x = state[2 * s];
-            pos = (int64_t)state[2 * s + 1];
-        }
-        s_pos = pos;
+    uint64_t x;
+    int64_t pos;
+    if (init) {
+        x = (uint64_t)(nwords > 0 ? st[0] : 0u) | ((uint64_t)(nwords > 1 ? st[1] : 0u) << 32);  // rans64.h:107-115
+        pos = 2;
+    } else {
+        x = state[2 * s];
+        pos = (int64_t)state[2 * s + 1];
     }
+    x = rfl64(x);
+    pos = (int64_t)rfl64((uint64_t)pos);
+    if (tid == 0) hdr[0] = pos;
     const int64_t base = sym_base[s] + part_off;
     const int shift = 16 - t.lut_bits;
     for (int64_t lo = 0; lo < count; lo += CHUNK) {
         const int cnt = (int)((count - lo) < CHUNK ? (count - lo) : CHUNK);
         __syncthreads();
-        const int64_t win0 = s_pos;
+        const int64_t win0 = (int64_t)rfl64((uint64_t)hdr[0]);
         for (int i = tid; i < WWIN; i += 256) win[i] = (win0 + i < nwords) ? st[win0 + i] : 0u;
         for (int i = tid; i < cnt; i += 256) {
             const int ti = idx[base + lo + i];
-            DecMeta m;
-            m.ro = t.row_off[ti];
-            m.len = t.sizes[ti];
-            m.off = t.offsets[ti];
-            m.lb = ti * lut_n;
-            meta[i] = m;
+            // {row start : 16 | cdf_length : 16} , {offset (signed) : 16 | row : 16}
+            meta[i] = make_uint2((uint32_t)t.row_off[ti] | ((uint32_t)t.sizes[ti] << 16),
+                                 ((uint32_t)t.offsets[ti] & 0xFFFFu) | ((uint32_t)ti << 16));
         }
         __syncthreads();
-        if (tid == 0) {
-            DecMeta mn = meta[0];
+        if (tid < 64) {
+            x = rfl64(x);  // re-assert uniformity: the state is merged with the idle waves' copy at every chunk
+            pos = (int64_t)rfl64((uint64_t)pos);
+            uint2 mraw = meta[0];
             for (int i = 0; i < cnt; ++i) {
-                const DecMeta m = mn;
-                if (i + 1 < cnt) mn = meta[i + 1];  // independent of the state: overlaps the dependent chain below
-                const uint32_t cum = (uint32_t)(x & 0xFFFFu);
-                const uint16_t* row = cdf + m.ro;
-                const uint32_t e = sl[m.lb + (cum >> shift)];
-                int a = (int)(e & 0xFFFFu);
-                uint32_t start = e >> 16;
-                const int last = m.len - 2;  // escape slot; row[last + 1] is the implicit 65536
-                uint32_t next = (a == last) ? 65536u : (uint32_t)row[a + 1];
-                while (cum >= next) {  // walk forward inside the bucket (usually 0 or 1 step)
+                const uint32_t m0 = rfl(mraw.x), m1 = rfl(mraw.y);
+                if (i + 1 < cnt) mraw = meta[i + 1];  // independent of the state: overlaps the chain below
+                const int ro = (int)(m0 & 0xFFFFu), last = (int)(m0 >> 16) - 2;  // last = escape slot
+                const int off = (int)(int16_t)(m1 & 0xFFFFu);
+                const uint32_t cum = (uint32_t)x & 0xFFFFu;
+                const uint2 ev = sl[(m1 >> 16) * lut_n + (cum >> shift)];
+                const uint32_t e0 = rfl(ev.x), e1 = rfl(ev.y);
+                int a = (int)(e0 & 0xFFFFu);
+                uint32_t start = e0 >> 16, freq = e1;
+                while (cum - start >= freq) {  // a symbol boundary inside the bucket: walk forward (rare, short)
                     ++a;
-                    start = next;
-                    next = (a == last) ? 65536u : (uint32_t)row[a + 1];
+                    start += freq;
+                    const uint32_t next = (a == last) ? 65536u : rfl((uint32_t)cdf[ro + a + 1]);
+                    freq = next - start;
                 }
-                const uint32_t freq = next - start;
-                x = (uint64_t)freq * (x >> PROB_BITS) + cum - start;  // rans64.h:131-133
-                if (x < RANS_LOW) x = (x << 32) | dec_word(st, nwords, pos, win, win0);
+                x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);  // rans64.h:131-133
+                if (x < RANS_LOW) {
+                    const int64_t rel = pos - win0;
+                    uint32_t wv = 0u;
+                    if (rel < WWIN) wv = rfl(win[rel]);
+                    else if (pos < nwords) wv = rfl(st[pos]);
+                    ++pos;
+                    x = (x << 32) | wv;
+                }
                 int v = a;
-                if (v == last) {  // escape: rans_interface.cpp:323-345
-                    int nib = (int)dec_bits(x, st, nwords, pos, win, win0);
+                if (a == last) {  // escape: rans_interface.cpp:323-345 (4-bit nibbles, 80-96)
+                    auto bits = [&]() -> int {
+                        const int val = (int)((uint32_t)x & ESC_MAX);
+                        x >>= ESC_BITS;
+                        if (x < RANS_LOW) {
+                            const int64_t rel = pos - win0;
+                            uint32_t wv = 0u;
+                            if (rel < WWIN) wv = rfl(win[rel]);
+                            else if (pos < nwords) wv = rfl(st[pos]);
+                            ++pos;
+                            x = (x << 32) | wv;
+                        }
+                        return val;
+                    };
+                    int nib = bits();
                     int nn = nib;
                     while (nib == (int)ESC_MAX) {
-                        nib = (int)dec_bits(x, st, nwords, pos, win, win0);
+                        nib = bits();
                         nn += nib;
                     }
                     int raw = 0;
                     for (int j = 0; j < nn; ++j) {
-                        nib = (int)dec_bits(x, st, nwords, pos, win, win0);
+                        nib = bits();
                         if (j < 8) raw |= nib << (j * ESC_BITS);
                     }
                     v = raw >> 1;
                     if (raw & 1) v = -v - 1;
                     else v += last;
                 }
-                osym[i] = v + m.off;
+                osym[i] = v + off;  // uniform value, same address from every lane
             }
-            s_pos = pos;
+            if (tid == 0) hdr[0] = pos;
         }
         __syncthreads();
         for (int i = tid; i < cnt; i += 256) sym[base + lo + i] = osym[i];
@@ -447,8 +458,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 size_t rans_decode_lds_bytes(const DevTables& t)
 {
     const size_t lut_n = ((size_t)1 << t.lut_bits) + 1;
-    return 16 + (((size_t)t.nrows * lut_n + 3) & ~(size_t)3) * 4 + WWIN * 4 + CHUNK * sizeof(DecMeta) +
-           CHUNK * sizeof(int32_t) + (((size_t)t.total * 2 + 15) & ~(size_t)15);
+    return 16 + (((size_t)t.nrows * lut_n + 1) & ~(size_t)1) * 8 + WWIN * 4 + CHUNK * 8 + CHUNK * sizeof(int32_t) +
+           (((size_t)t.total * 2 + 15) & ~(size_t)15);
 }
 
 int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,

@@ -1,0 +1,93 @@
+"""Stream-level pipelining of independent image groups on one GPU.
+
+The entropy stage is a serial chain per stream (rANS state recurrence, 20 decode phases interleaved with the context
+networks) that occupies a handful of CUs, while the transforms want the whole chip.  Image pairs are independent, so a
+`CodecPool` keeps W engine instances (own weights replica, own workspace, own HIP stream) and codes W groups of a batch
+concurrently from W host threads: one group's serial coder phases overlap another group's convolutions.  Results are
+identical to coding each group alone (the kernels are batch-invariant); only the wall clock changes.
+"""
+import threading
+from typing import List
+
+import torch
+
+from .elic_united import ELIC_united
+
+
+class CodecPool:
+    def __init__(self, state_dict, config=None, workers: int = 2, device="cuda", per_image_streams: bool = True):
+        self.device = torch.device(device)
+        self.nets: List[ELIC_united] = []
+        self.streams = []
+        for _ in range(workers):
+            net = ELIC_united(config=config, channel=4).eval()
+            net.load_state_dict(state_dict)
+            net.update(force=True)
+            net = net.to(self.device)
+            net.per_image_streams = per_image_streams
+            self.nets.append(net)
+            self.streams.append(torch.cuda.Stream(device=self.device))
+
+    @property
+    def workers(self):
+        return len(self.nets)
+
+    def _split(self, B):
+        w = min(self.workers, B)
+        base, rem = divmod(B, w)
+        out, o = [], 0
+        for i in range(w):
+            n = base + (1 if i < rem else 0)
+            out.append((o, o + n))
+            o += n
+        return out
+
+    def _run(self, fn, n):
+        res, err = [None] * n, [None] * n
+
+        def work(i):
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.streams[i]):
+                    res[i] = fn(i)
+                self.streams[i].synchronize()
+            except BaseException as e:  # surfaced to the caller below
+                err[i] = e
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return res
+
+    def roundtrip(self, rgb: torch.Tensor, depth: torch.Tensor):
+        """compress() + decompress() of every group; returns (list of compress outputs, x_hat_r, x_hat_d)."""
+        parts = self._split(rgb.shape[0])
+        torch.cuda.current_stream().synchronize()
+
+        def fn(i):
+            a, b = parts[i]
+            out = self.nets[i].compress(rgb[a:b], depth[a:b])
+            rec = self.nets[i].decompress(out["r_strings"], out["d_strings"], out["shape"])
+            return out, rec
+
+        res = self._run(fn, len(parts))
+        xr = torch.cat([r[1]["x_hat"]["r"] for r in res])
+        xd = torch.cat([r[1]["x_hat"]["d"] for r in res])
+        return [r[0] for r in res], xr, xd
+
+    def set_profile(self, on: bool):
+        for n in self.nets:
+            n.set_profile(on)
+
+    def profile_read(self):
+        tot = {"conv_ms": 0.0, "launches": 0, "flops": 0.0}
+        for n in self.nets:
+            p = n.profile_read()
+            for k in tot:
+                tot[k] += p[k]
+        return tot
