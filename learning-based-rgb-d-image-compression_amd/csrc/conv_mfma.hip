@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     constexpr int TP = 16 * NT * WN;
     constexpr int RS = KC > 16 ? KC + 4 : KC;  // LDS row stride in floats
     constexpr int C4 = KC / 4;                  // 16-byte slots per row
+    constexpr int WR = 8;                       // weight float4 per thread per stage (<= 32 KiB of weights per stage)
+    constexpr int PR = 12;                      // patch float4 per thread per chunk (<= 48 KiB patch)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -73,61 +75,105 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 
     const int npatch4 = PH * PW * C4;
     const size_t img_base = (size_t)n * a.H * a.W;
+    const int nchunks = (a.cin_pad + KC - 1) / KC;
+    const int ngroups = (ntaps + taps_per_stage - 1) / taps_per_stage;
+    const int nstages = nchunks * ngroups;
 
-    for (int ci0 = 0; ci0 < a.cin_pad; ci0 += KC) {
-        __syncthreads();  // previous chunk's readers are done with patch and wl
-        for (int f = tid; f < npatch4; f += 256) {
+    // Register staging.  A stage = one tap group of one channel chunk; the input patch is reloaded per chunk.
+    f32x4 pw[WR], pp[PR];
+    auto issue_w = [&](int stage) {
+        const int ci0 = (stage / ngroups) * KC;
+        const int t0 = (stage % ngroups) * taps_per_stage;
+        const int nw4 = min(taps_per_stage, ntaps - t0) * TM * C4;
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+            const int f = tid + u * 256;
+            const int c4 = f % C4;
+            const int m = (f / C4) % TM;
+            const int j = (f / C4) / TM;
+            const int co = co0 + m;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (f < nw4 && co < a.cout_pad && ci0 + c4 * 4 < a.cin_pad)
+                v = *reinterpret_cast<const f32x4*>(
+                    a.w + ((size_t)co * a.ntaps_total + a.taps.wt[phase][t0 + j]) * a.cin_pad + ci0 + c4 * 4);
+            pw[u] = v;
+        }
+    };
+    auto commit_w = [&](int stage) {
+        const int t0 = (stage % ngroups) * taps_per_stage;
+        const int nw4 = min(taps_per_stage, ntaps - t0) * TM * C4;
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+            const int f = tid + u * 256;
+            if (f < nw4) {
+                const int c4 = f % C4;
+                const int r = f / C4;  // j * TM + m
+                *reinterpret_cast<f32x4*>(wl + (size_t)r * RS + c4 * 4) = pw[u];
+            }
+        }
+    };
+    auto issue_p = [&](int chunk) {
+        const int ci0 = chunk * KC;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const int f = tid + u * 256;
             const int row = f / C4, c4 = f - row * C4;
             const int pr = row / PW, pc = row - pr * PW;
             const int iy = iy0 + pr, ix = ix0 + pc;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + c4 * 4 < a.cin_pad)
+            if (f < npatch4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + c4 * 4 < a.cin_pad)
                 v = *reinterpret_cast<const f32x4*>(a.x + (img_base + (size_t)iy * a.W + ix) * a.xcs + ci0 + c4 * 4);
-            *reinterpret_cast<f32x4*>(patch + (size_t)row * RS + c4 * 4) = v;
+            pp[u] = v;
         }
-        for (int t0 = 0; t0 < ntaps; t0 += taps_per_stage) {
-            const int tg = min(taps_per_stage, ntaps - t0);
-            if (t0) __syncthreads();  // readers of the previous tap group are done with wl
-            const int nw4 = tg * TM * C4;
-            for (int f = tid; f < nw4; f += 256) {
-                const int c4 = f % C4;
-                const int m = (f / C4) % TM;
-                const int j = (f / C4) / TM;
-                const int co = co0 + m;
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (co < a.cout_pad && ci0 + c4 * 4 < a.cin_pad)
-                    v = *reinterpret_cast<const f32x4*>(
-                        a.w + ((size_t)co * a.ntaps_total + a.taps.wt[phase][t0 + j]) * a.cin_pad + ci0 + c4 * 4);
-                *reinterpret_cast<f32x4*>(wl + ((size_t)j * TM + m) * RS + c4 * 4) = v;
-            }
-            __syncthreads();
-            // canonical accumulation order: 16-channel chunk -> tap -> channel.  A 64-channel stage therefore walks
-            // its four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so
-            // the fma chain of each output is the same for every KC / tile choice.
+    };
+    auto commit_p = [&]() {
 #pragma unroll
-            for (int kk = 0; kk < KC / 16; ++kk) {
-                for (int j = 0; j < tg; ++j) {
-                    const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
-                    const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
-                    f32x4 af[MT], bf[NT];
+        for (int u = 0; u < PR; ++u) {
+            const int f = tid + u * 256;
+            if (f < npatch4) {
+                const int row = f / C4, c4 = f - row * C4;
+                *reinterpret_cast<f32x4*>(patch + (size_t)row * RS + c4 * 4) = pp[u];
+            }
+        }
+    };
+
+    for (int stage = 0; stage < nstages; ++stage) {
+        const int t0 = (stage % ngroups) * taps_per_stage;
+        const int tg = min(taps_per_stage, ntaps - t0);
+        // all global loads of the stage are issued back to back (one memory round trip per stage), then committed to
+        // LDS; the staging registers are dead during the MFMA phase so two workgroups fit per CU and hide each other's
+        // load phase
+        issue_w(stage);
+        if (t0 == 0) issue_p(stage / ngroups);
+        __syncthreads();  // every wave has finished reading the previous stage from LDS
+        if (t0 == 0) commit_p();
+        commit_w(stage);
+        __syncthreads();
+        // canonical accumulation order: 16-channel chunk -> tap -> channel.  A 64-channel stage therefore walks its
+        // four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so the
+        // fma chain of each output is the same for every KC / tile choice.
+#pragma unroll
+        for (int kk = 0; kk < KC / 16; ++kk) {
+            for (int j = 0; j < tg; ++j) {
+                const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
+                const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(
+                        wl + ((size_t)j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const int row = (ppy[k] * a.IS + dy) * PW + ppx[k] * a.IS + dx;
+                    bf[k] = *reinterpret_cast<const f32x4*>(patch + (size_t)row * RS + kk * 16 + q * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
-                        af[i] = *reinterpret_cast<const f32x4*>(
-                            wl + ((size_t)j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
 #pragma unroll
-                    for (int k = 0; k < NT; ++k) {
-                        const int row = (ppy[k] * a.IS + dy) * PW + ppx[k] * a.IS + dx;
-                        bf[k] = *reinterpret_cast<const f32x4*>(patch + (size_t)row * RS + kk * 16 + q * 4);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int k = 0; k < NT; ++k)
-                                acc[i][k] =
-                                    __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
-                }
+                        for (int k = 0; k < NT; ++k)
+                            acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
             }
         }
     }
@@ -183,9 +229,9 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     const size_t tap_bytes = (size_t)TM * RS * sizeof(float);
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
-    if (patch_bytes + tap_bytes > 150 * 1024) return RGBD_ENOSPC;
-    long room = ((long)LDS_BUDGET - (long)patch_bytes) / (long)tap_bytes;
-    if (room < 1) room = 1;
+    if ((long)PH * PW * (KC / 4) > 12 * 256) return RGBD_ENOSPC;  // patch registers (PR)
+    long room = (8 * 256) / ((long)TM * (KC / 4));               // weight registers (WR)
+    if (room < 1) return RGBD_ENOSPC;
     const int tps = (int)(room < max_taps ? room : max_taps);
     if (KC > 16 && tps < max_taps) return RGBD_ENOSPC;  // would break the canonical accumulation order
     const size_t lds = patch_bytes + (size_t)tps * tap_bytes;
@@ -245,7 +291,7 @@ Choice choose(const ConvArgs& a)
         const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
         const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase;
         const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
-        if ((size_t)PH * PW * 64 + (size_t)tm * 64 > (size_t)LDS_BUDGET) continue;
+        if ((long)PH * PW * 4 > 12 * 256 || (long)tm * 4 > 8 * 256) continue;  // register-staging limits (KC=16)
         const double mfma = (double)mt * nt * (K / 4.0) * 32.0 + 3000.0;             // cycles per workgroup (+ prologue)
         const double load = (K * tm * 4.0 + (double)PH * PW * a.cin_pad * 4.0) / 12.0;  // ~12 B/clk/CU from L2
         const long nb = (blocks + 255) / 256;
@@ -263,7 +309,11 @@ Choice choose(const ConvArgs& a)
         const size_t patch64 = (size_t)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 68 * 4;
         const size_t tap64 = (size_t)16 * best.mt * best.wm * 68 * 4;
         const long mfma_per_stage16 = (long)max_taps * 4 * best.mt * best.nt;
-        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400) best.kc = 64;
+        const long p4 = (long)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 16;
+        const long w4 = (long)max_taps * 16 * best.mt * best.wm * 16;
+        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400 && p4 <= 12 * 256 &&
+            w4 <= 8 * 256)
+            best.kc = 64;
     }
     return best;
 }

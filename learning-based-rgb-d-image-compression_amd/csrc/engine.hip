@@ -1329,6 +1329,79 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
     return rc;
 }
 
+// Kernel-only timing of one conv shape on NHWC buffers (tools/conv_sweep.py); not part of the codec path.
+int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k, int32_t stride, int32_t pad,
+                    int32_t transposed, int32_t with_residual, int32_t iters, float* ms_out)
+{
+    if (!ms_out || n <= 0 || iters <= 0) return RGBD_EINVAL;
+    HostTensor hw;
+    hw.shape = transposed ? std::vector<int64_t>{cin, cout, k, k} : std::vector<int64_t>{cout, cin, k, k};
+    hw.v.assign((size_t)cin * cout * k * k, 0.01f);
+    PackedConv pc;
+    int rc = pack_conv(hw, nullptr, transposed != 0, &pc);
+    if (rc) return rc;
+    int OH, OW;
+    if (!transposed) {
+        OH = (h + 2 * pad - k) / stride + 1;
+        OW = (w + 2 * pad - k) / stride + 1;
+    } else {
+        OH = (h - 1) * stride - 2 * pad + k + (stride - 1);
+        OW = (w - 1) * stride - 2 * pad + k + (stride - 1);
+    }
+    float *x = nullptr, *y = nullptr, *r = nullptr;
+    const size_t xb = (size_t)n * h * w * pc.cin_pad * sizeof(float), yb = (size_t)n * OH * OW * pc.cout_pad * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&x, xb));
+    HIP_TRY(hipMalloc((void**)&y, yb));
+    HIP_TRY(hipMemset(x, 0x3c, xb));  // small positive floats
+    if (with_residual) {
+        HIP_TRY(hipMalloc((void**)&r, yb));
+        HIP_TRY(hipMemset(r, 0x3c, yb));
+    }
+    ConvArgs a{};
+    a.x = x;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.xcs = pc.cin_pad;
+    a.cin_pad = pc.cin_pad;
+    a.w = pc.w;
+    a.ntaps_total = k * k;
+    a.bias = pc.bias;
+    a.y = y;
+    a.OH = OH;
+    a.OW = OW;
+    a.ycs = pc.cout_pad;
+    a.cout_pad = pc.cout_pad;
+    make_taps(pc, stride, pad, &a);
+    a.GH = transposed ? h : OH;
+    a.GW = transposed ? w : OW;
+    a.act = ACT_RELU;
+    if (r) {
+        a.res1 = r;
+        a.r1cs = pc.cout_pad;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    rc = launch_conv(a, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(a, nullptr);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(x);
+    (void)hipFree(y);
+    (void)hipFree(r);
+    (void)hipFree(pc.w);
+    (void)hipFree(pc.bias);
+    return rc;
+}
+
 // ---- codec ------------------------------------------------------------------------------------
 int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out)
 {

@@ -80,6 +80,28 @@ class CodecPool:
         xd = torch.cat([r[1]["x_hat"]["d"] for r in res])
         return [r[0] for r in res], xr, xd
 
+    def roundtrip_many(self, batches):
+        """Software pipeline over whole batches: worker w codes batches[w::W]; a batch's serial coder phases overlap the
+        other workers' convolutions.  batches: list of (rgb, depth).  Returns [(compress_out, x_hat_r, x_hat_d)]."""
+        n = len(batches)
+        torch.cuda.current_stream().synchronize()
+        W = min(self.workers, n)
+
+        def fn(i):
+            outs = []
+            for k in range(i, n, W):
+                rgb, depth = batches[k]
+                out = self.nets[i].compress(rgb, depth)
+                rec = self.nets[i].decompress(out["r_strings"], out["d_strings"], out["shape"])
+                outs.append((k, out, rec["x_hat"]["r"], rec["x_hat"]["d"]))
+            return outs
+
+        res = [None] * n
+        for lst in self._run(fn, W):
+            for k, out, xr, xd in lst:
+                res[k] = (out, xr, xd)
+        return res
+
     def set_profile(self, on: bool):
         for n in self.nets:
             n.set_profile(on)
