@@ -829,7 +829,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     int32_t* zsym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
     int32_t* zidx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
     const int64_t ycount = per_image ? T : T * B;
-    const int64_t ycap = 5 * ycount + 32, zcap = 5 * Tz + 32;
+    const int64_t ycap = ((5 * ycount + 32 + 704) + 63) & ~(int64_t)63, zcap = ((5 * Tz + 32 + 704) + 63) & ~(int64_t)63;
     uint32_t* ywords = (uint32_t*)arena.take(sizeof(uint32_t) * (size_t)(2 * ny * ycap));
     uint32_t* zwords = (uint32_t*)arena.take(sizeof(uint32_t) * (size_t)(2 * B * zcap));
     int* err = (int*)arena.take(256);
@@ -1137,7 +1137,9 @@ void rgbd_tables_destroy(rgbd_tables* t)
     delete t;
 }
 
-int64_t rgbd_rans_max_bytes(int64_t n) { return 4 * (5 * n + 32); }
+static int64_t enc_cap_words(int64_t n) { return ((5 * n + 32 + 704) + 63) & ~(int64_t)63; }
+
+int64_t rgbd_rans_max_bytes(int64_t n) { return 4 * enc_cap_words(n); }
 
 int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t* indexes, int64_t n, uint8_t* out,
                      int64_t cap, int64_t* out_len)
@@ -1145,7 +1147,7 @@ int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t
     if (!t || !t->ts.ready || n < 0 || !out || !out_len || (n && (!symbols || !indexes))) return RGBD_EINVAL;
     for (int64_t i = 0; i < n; ++i)
         if (indexes[i] < 0 || indexes[i] >= t->ts.d.nrows) return RGBD_EINVAL;
-    const int64_t capw = 5 * n + 32;
+    const int64_t capw = enc_cap_words(n);
     int32_t *dsym = nullptr, *didx = nullptr;
     uint32_t* dout = nullptr;
     int64_t* dmeta = nullptr;

@@ -12,8 +12,7 @@
 #define ESC_BITS 4
 #define ESC_MAX 15u
 #define RANS_LOW (1ull << 31)
-#define CHUNK 512    // decoder symbols per staging round
-#define ECHUNK 1024  // encoder symbols per staging round
+
 
 // ---------------------------------------------------------------------------------------------
 // checkerboard helpers: column of packed index k on a given row (utils/ckbd.py:51-64)
@@ -178,138 +177,148 @@ int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Serial parts below run in wave 0 with ALL lanes executing the same (uniform) computation: every value loaded from
-// LDS goes through readfirstlane, so the state recurrence lives in SGPRs, its branches are scalar branches (no exec
-// masking), and only the fp64 quotient estimate / LDS traffic use the vector pipe.
+// rANS coder kernels.  The state recurrence of one stream is strictly serial, and one wavefront issues at most one
+// instruction every ~4 clocks, so the design goal is the fewest instructions and the fewest LDS/memory round trips per
+// symbol on the critical path:
+//   * the recurrence runs in SGPRs (every lane of wave 0 executes the same uniform code; branches are scalar);
+//   * everything that does not depend on the state is produced 64 symbols at a time by the 64 lanes in parallel
+//     (coalesced loads, table gathers, fp64 reciprocals) and handed to the scalar chain with v_readlane;
+//   * results go back with v_writelane and leave as one coalesced 256-byte store per 64 items;
+//   * the decoder's only dependent memory access per symbol is one 8-byte LDS read of the bucket table.
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t rfl64(uint64_t v)
 {
     return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32);
 }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+// lane `sel` of the result takes the (uniform) value, the others keep theirs: v_cmp + v_cndmask
+__device__ __forceinline__ uint32_t wrl(uint32_t val, int sel, uint32_t old)
+{
+    return ((int)(threadIdx.x & 63) == sel) ? val : old;
+}
 
 // ---------------------------------------------------------------------------------------------
-// rANS encoder.  All threads expand a chunk of symbols to coded items in parallel (table lookups, escape split and the
-// fp64 reciprocal of the frequency); wave 0 then runs the state recurrence over the chunk in reverse
-// (rans_interface.cpp:167-185 pops from the back).
-struct EncItem {
-    uint32_t sf;    // start | freq << 16
-    uint32_t raw;   // escape payload
-    uint64_t rcpb;  // bits of (double)1/freq, bit 63 set when the symbol hit the escape slot
+// Encoder: one wavefront per stream, symbols consumed from the back (rans_interface.cpp:167-185 pops from the back).
+struct EncBatch {
+    uint32_t sf;   // start | freq << 16
+    uint32_t raw;  // escape payload
+    uint32_t rlo;  // low word of (double)1/freq
+    uint32_t rhi;  // high word, bit 31 set when the symbol hit the escape slot
 };
 
-__device__ __forceinline__ void enc_emit(uint64_t& x, uint32_t* out, int64_t& w, int lane)
+__device__ __forceinline__ EncBatch enc_prepare(const DevTables& t, const int32_t* __restrict__ sym,
+                                                const int32_t* __restrict__ idx, int64_t pos, bool valid)
 {
-    --w;
-    if (lane == 0) out[w] = (uint32_t)x;
-    x >>= 32;
-}
-
-__device__ __forceinline__ void enc_put(uint64_t& x, uint32_t start, uint32_t freq, double rcp, uint32_t* out,
-                                        int64_t& w, int lane)
-{
-    if (x >= ((uint64_t)freq << 47)) enc_emit(x, out, w, lane);  // ((RANS_LOW >> 16) << 32) * freq, rans64.h:82-83
-    // exact x / freq: fp64 estimate (|error| <= 1 since x < 2^63, q < 2^47) and an integer fix-up
-    uint64_t qn = rfl64((uint64_t)((double)x * rcp));
-    int64_t r = (int64_t)(x - qn * (uint64_t)freq);
-    while (r < 0) {
-        --qn;
-        r += freq;
+    EncBatch b;
+    b.sf = 1u << 16;
+    b.raw = 0;
+    b.rlo = 0;
+    b.rhi = 0x3FF00000u;  // 1.0
+    if (valid) {
+        const int ti = idx[pos];
+        const int top = t.sizes[ti] - 2;
+        const int ro = t.row_off[ti];
+        int v = sym[pos] - t.offsets[ti];
+        uint32_t raw = 0;
+        if (v < 0) {
+            raw = (uint32_t)(-2 * v - 1);
+            v = top;
+        } else if (v >= top) {
+            raw = (uint32_t)(2 * (v - top));
+            v = top;
+        }
+        const uint32_t start = t.cdf[ro + v];
+        const uint32_t next = (v == top) ? 65536u : (uint32_t)t.cdf[ro + v + 1];
+        const uint32_t freq = next - start;
+        const uint64_t rb = (uint64_t)__double_as_longlong(1.0 / (double)freq);
+        b.sf = start | (freq << 16);
+        b.raw = raw;
+        b.rlo = (uint32_t)rb;
+        b.rhi = (uint32_t)(rb >> 32) | ((v == top) ? 0x80000000u : 0u);
     }
-    while (r >= (int64_t)freq) {
-        ++qn;
-        r -= freq;
-    }
-    x = (qn << PROB_BITS) + (uint64_t)r + start;
+    return b;
 }
 
-__device__ __forceinline__ void enc_put_bits(uint64_t& x, uint32_t val, uint32_t* out, int64_t& w, int lane)
+__global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
+                                                         const int64_t* __restrict__ sym_base,
+                                                         const int64_t* __restrict__ counts, int split, DevTables t0,
+                                                         DevTables t1, uint32_t* __restrict__ out, int64_t cap_words,
+                                                         int64_t* __restrict__ out_words, int* __restrict__ err)
 {
-    // ((RANS_LOW >> 16) << 32) * (1 << (16 - 4)) = 2^59, rans_interface.cpp:67-68
-    if (x >= (1ull << 59)) enc_emit(x, out, w, lane);
-    x = (x << ESC_BITS) | val;
-}
-
-__global__ __launch_bounds__(256) void rans_encode_kernel(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
-                                                          const int64_t* __restrict__ sym_base,
-                                                          const int64_t* __restrict__ counts, int split, DevTables t0,
-                                                          DevTables t1, uint32_t* __restrict__ out, int64_t cap_words,
-                                                          int64_t* __restrict__ out_words, int* __restrict__ err)
-{
-    __shared__ __attribute__((aligned(16))) EncItem items[ECHUNK];
-    __shared__ int s_bad;
     const int s = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const DevTables& t = s < split ? t0 : t1;
     const int64_t n = counts[s];
     const int64_t base = sym_base[s];
-    uint32_t* o = out + (size_t)s * cap_words;
+    uint32_t* o = out + (size_t)s * cap_words;  // cap_words is a multiple of 64
     uint64_t x = RANS_LOW;
-    int64_t w = cap_words;
-    if (tid == 0) s_bad = 0;
-    for (int64_t hi = n; hi > 0; hi -= ECHUNK) {
-        const int64_t lo = hi > ECHUNK ? hi - ECHUNK : 0;
-        const int cnt = (int)(hi - lo);
-        __syncthreads();
-        for (int i = tid; i < cnt; i += 256) {
-            const int ti = idx[base + lo + i];
-            const int top = t.sizes[ti] - 2;
-            const int ro = t.row_off[ti];
-            int v = sym[base + lo + i] - t.offsets[ti];
-            uint32_t raw = 0;
-            if (v < 0) {
-                raw = (uint32_t)(-2 * v - 1);
-                v = top;
-            } else if (v >= top) {
-                raw = (uint32_t)(2 * (v - top));
-                v = top;
-            }
-            const uint32_t start = t.cdf[ro + v];
-            const uint32_t next = (v == top) ? 65536u : (uint32_t)t.cdf[ro + v + 1];
-            const uint32_t freq = next - start;
-            EncItem it;
-            it.sf = start | (freq << 16);
-            it.raw = raw;
-            it.rcpb = (uint64_t)__double_as_longlong(1.0 / (double)freq) | ((uint64_t)(v == top) << 63);
-            items[i] = it;
+    int64_t w = cap_words;  // next free slot is w-1; slot k lives in lane (k & 63) of `ov` until its 64-block is full
+    uint32_t ov = 0;
+    int bad = 0;
+
+    auto emit = [&]() {
+        --w;
+        ov = wrl((uint32_t)x, (int)(w & 63), ov);
+        x >>= 32;
+        if ((w & 63) == 0) o[w + lane] = ov;  // block [w, w+64) complete: one coalesced 256-byte store
+    };
+
+    const int64_t nb = (n + 63) >> 6;
+    EncBatch cur = enc_prepare(t, sym, idx, base + (nb - 1) * 64 + lane, nb > 0 && (nb - 1) * 64 + lane < n);
+    for (int64_t b = nb - 1; b >= 0; --b) {
+        // batch b-1 is prepared while batch b is coded: its loads are only consumed after the serial loop
+        const EncBatch nxt = enc_prepare(t, sym, idx, base + (b - 1) * 64 + lane, b > 0);
+        const int cnt = (int)((n - b * 64) < 64 ? (n - b * 64) : 64);
+        if (w < 64 + 10 * 64) {  // worst case for one batch: 64 * (1 + 1 + 8) items
+            bad = 1;
+            break;
         }
-        __syncthreads();
-        if (tid < 64) {
-            x = rfl64(x);  // re-assert uniformity (merged with the idle waves' copy at every chunk)
-            w = (int64_t)rfl64((uint64_t)w);
-            int bad = 0;
-            for (int i = cnt - 1; i >= 0; --i) {
-                const uint4 itv = *reinterpret_cast<const uint4*>(&items[i]);
-                const uint32_t sf = rfl(itv.x), raw = rfl(itv.y), rlo = rfl(itv.z), rhi = rfl(itv.w);
-                if (w < 24) {  // worst case for one symbol: 1 + 1 + 8 items + flush
-                    bad = 1;
-                    break;
+        for (int j = cnt - 1; j >= 0; --j) {
+            const uint32_t sf = rdl(cur.sf, j), rhi = rdl(cur.rhi, j), rlo = rdl(cur.rlo, j);
+            if (rhi >> 31) {  // escape payload first (reverse of rans_interface.cpp:147-162)
+                const uint32_t raw = rdl(cur.raw, j);
+                int nn = 0;
+                while (nn < 8 && (raw >> (nn * ESC_BITS)) != 0) ++nn;
+                for (int k = nn - 1; k >= -1; --k) {
+                    const uint32_t val = k >= 0 ? ((raw >> (k * ESC_BITS)) & ESC_MAX) : (uint32_t)nn;
+                    if (x >= (1ull << 59)) emit();  // ((RANS_LOW >> 16) << 32) << 12, rans_interface.cpp:67-68
+                    x = (x << ESC_BITS) | val;
                 }
-                if (rhi >> 31) {
-                    int nn = 0;
-                    while (nn < 8 && (raw >> (nn * ESC_BITS)) != 0) ++nn;
-                    for (int j = nn - 1; j >= 0; --j) enc_put_bits(x, (raw >> (j * ESC_BITS)) & ESC_MAX, o, w, tid);
-                    // count items were pushed as [15]*k + [rem]; reverse order = rem first (nn <= 8 -> k == 0)
-                    enc_put_bits(x, (uint32_t)nn, o, w, tid);
-                }
-                const double rcp = __longlong_as_double((long long)(((uint64_t)(rhi & 0x7FFFFFFFu) << 32) | rlo));
-                enc_put(x, sf & 0xFFFFu, sf >> 16, rcp, o, w, tid);
             }
-            if (bad && tid == 0) s_bad = 1;
+            const uint32_t start = sf & 0xFFFFu, freq = sf >> 16;
+            if (x >= ((uint64_t)freq << 47)) emit();  // ((RANS_LOW >> 16) << 32) * freq, rans64.h:82-83
+            // exact x / freq: fp64 estimate (|error| <= 1 since x < 2^63, q < 2^47) and an integer fix-up
+            const double rcp = __longlong_as_double((long long)(((uint64_t)(rhi & 0x7FFFFFFFu) << 32) | rlo));
+            uint64_t qn = rfl64((uint64_t)((double)x * rcp));
+            int64_t r = (int64_t)(x - qn * (uint64_t)freq);
+            while (r < 0) {
+                --qn;
+                r += freq;
+            }
+            while (r >= (int64_t)freq) {
+                ++qn;
+                r -= freq;
+            }
+            x = (qn << PROB_BITS) + (uint64_t)r + start;
         }
-        __syncthreads();
-        if (s_bad) break;
+        cur = nxt;
     }
-    if (tid == 0) {
-        if (s_bad) {
+    if (bad) {
+        if (lane == 0) {
             *err = 1;
             out_words[s] = 0;
-        } else {
-            w -= 2;  // rans64.h:96-103
-            o[w] = (uint32_t)x;
-            o[w + 1] = (uint32_t)(x >> 32);
-            out_words[s] = cap_words - w;
         }
+        return;
     }
+    // rans64.h:96-103: the two state words go in front
+    --w;
+    ov = wrl((uint32_t)(x >> 32), (int)(w & 63), ov);
+    if ((w & 63) == 0) o[w + lane] = ov;
+    --w;
+    ov = wrl((uint32_t)x, (int)(w & 63), ov);
+    if ((w & 63) == 0) o[w + lane] = ov;
+    else if (lane >= (int)(w & 63)) o[(w & ~(int64_t)63) + lane] = ov;  // partial leading block
+    if (lane == 0) out_words[s] = cap_words - w;
 }
 
 int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sym_base, const int64_t* counts,
@@ -317,20 +326,18 @@ int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sy
                        int64_t* out_words, int* err, hipStream_t s)
 {
     if (nstreams <= 0) return RGBD_OK;
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(256), 0, s, sym, idx, sym_base, counts, split, t0, t1, out,
+    if (cap_words % 64) return RGBD_EINVAL;
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), 0, s, sym, idx, sym_base, counts, split, t0, t1, out,
                        cap_words, out_words, err);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// rANS decoder.  LDS holds the packed u16 CDF rows, a per-row bucket table (cum >> (16 - lut_bits) -> first candidate
-// symbol, its start and its frequency: one 8-byte read resolves a symbol unless a boundary falls inside the bucket)
-// and a window of the stream's words.  Wave 0 runs the state recurrence (scalar, see above); the other waves stage
-// indexes / stream words in and symbols out.  The (x, pos) state persists in HBM between the 20 per-part launches of
+// Decoder.  LDS holds the packed u16 CDF rows and a per-row bucket table (cum >> (16 - lut_bits) -> first candidate
+// symbol, its start and its frequency: one 8-byte read resolves a symbol unless a boundary falls inside the bucket).
+// 256 threads fill LDS, then wave 0 decodes.  The (x, pos) state persists in HBM between the 20 per-part launches of
 // one stream (RansDecoder::decode_stream semantics).
-#define WWIN 1024  // stream words staged per chunk
-
 __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __restrict__ streams,
                                                           const int64_t* __restrict__ stream_off,
                                                           const int64_t* __restrict__ stream_len,
@@ -341,12 +348,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int lut_n = (1 << t.lut_bits) + 1;
-    int64_t* hdr = reinterpret_cast<int64_t*>(dsm);                                    // 16-byte header: [pos]
-    uint2* sl = reinterpret_cast<uint2*>(dsm + 16);                                    // [nrows][lut_n]
-    uint32_t* win = reinterpret_cast<uint32_t*>(sl + ((t.nrows * lut_n + 1) & ~1));    // [WWIN]
-    uint2* meta = reinterpret_cast<uint2*>(win + WWIN);                                // [CHUNK] packed row info
-    int32_t* osym = reinterpret_cast<int32_t*>(meta + CHUNK);                          // [CHUNK]
-    uint16_t* cdf = reinterpret_cast<uint16_t*>(osym + CHUNK);                         // [t.total]
+    uint2* sl = reinterpret_cast<uint2*>(dsm);                                          // [nrows][lut_n]
+    uint2* rowinfo = sl + ((t.nrows * lut_n + 1) & ~1);                                  // [nrows] packed row info
+    uint16_t* cdf = reinterpret_cast<uint16_t*>(rowinfo + ((t.nrows + 1) & ~1));        // [t.total]
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -355,6 +359,13 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         const uint2* gl = reinterpret_cast<const uint2*>(t.lut);
         for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = gl[i];
     }
+    for (int i = tid; i < t.nrows; i += 256)  // {row start : 16 | cdf_length : 16}, {offset (signed) : 16 | table base : 16}
+        rowinfo[i] = make_uint2((uint32_t)t.row_off[i] | ((uint32_t)t.sizes[i] << 16),
+                                ((uint32_t)t.offsets[i] & 0xFFFFu) | ((uint32_t)(i * lut_n) << 16));
+    __syncthreads();
+    if (tid >= 64) return;
+    const int lane = tid;
+
     const uint32_t* st = streams + stream_off[s];
     const int64_t nwords = stream_len[s];
     uint64_t x;
@@ -368,88 +379,75 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     }
     x = rfl64(x);
     pos = (int64_t)rfl64((uint64_t)pos);
-    if (tid == 0) hdr[0] = pos;
     const int64_t base = sym_base[s] + part_off;
     const int shift = 16 - t.lut_bits;
-    for (int64_t lo = 0; lo < count; lo += CHUNK) {
-        const int cnt = (int)((count - lo) < CHUNK ? (count - lo) : CHUNK);
-        __syncthreads();
-        const int64_t win0 = (int64_t)rfl64((uint64_t)hdr[0]);
-        for (int i = tid; i < WWIN; i += 256) win[i] = (win0 + i < nwords) ? st[win0 + i] : 0u;
-        for (int i = tid; i < cnt; i += 256) {
-            const int ti = idx[base + lo + i];
-            // {row start : 16 | cdf_length : 16} , {offset (signed) : 16 | row : 16}
-            meta[i] = make_uint2((uint32_t)t.row_off[ti] | ((uint32_t)t.sizes[ti] << 16),
-                                 ((uint32_t)t.offsets[ti] & 0xFFFFu) | ((uint32_t)ti << 16));
+
+    // stream words: lane k of wcur holds word wpos0 + k; wnext is the following 64 words (already in flight)
+    int64_t wpos0 = pos;
+    uint32_t wcur = (wpos0 + lane < nwords) ? st[wpos0 + lane] : 0u;
+    uint32_t wnext = (wpos0 + 64 + lane < nwords) ? st[wpos0 + 64 + lane] : 0u;
+    auto next_word = [&]() -> uint32_t {
+        const uint32_t wv = rdl(wcur, (int)(pos - wpos0));
+        ++pos;
+        if (pos - wpos0 == 64) {
+            wpos0 += 64;
+            wcur = wnext;
+            wnext = (wpos0 + 64 + lane < nwords) ? st[wpos0 + 64 + lane] : 0u;
         }
-        __syncthreads();
-        if (tid < 64) {
-            x = rfl64(x);  // re-assert uniformity: the state is merged with the idle waves' copy at every chunk
-            pos = (int64_t)rfl64((uint64_t)pos);
-            uint2 mraw = meta[0];
-            for (int i = 0; i < cnt; ++i) {
-                const uint32_t m0 = rfl(mraw.x), m1 = rfl(mraw.y);
-                if (i + 1 < cnt) mraw = meta[i + 1];  // independent of the state: overlaps the chain below
-                const int ro = (int)(m0 & 0xFFFFu), last = (int)(m0 >> 16) - 2;  // last = escape slot
-                const int off = (int)(int16_t)(m1 & 0xFFFFu);
-                const uint32_t cum = (uint32_t)x & 0xFFFFu;
-                const uint2 ev = sl[(m1 >> 16) * lut_n + (cum >> shift)];
-                const uint32_t e0 = rfl(ev.x), e1 = rfl(ev.y);
-                int a = (int)(e0 & 0xFFFFu);
-                uint32_t start = e0 >> 16, freq = e1;
-                while (cum - start >= freq) {  // a symbol boundary inside the bucket: walk forward (rare, short)
-                    ++a;
-                    start += freq;
-                    const uint32_t next = (a == last) ? 65536u : rfl((uint32_t)cdf[ro + a + 1]);
-                    freq = next - start;
-                }
-                x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);  // rans64.h:131-133
-                if (x < RANS_LOW) {
-                    const int64_t rel = pos - win0;
-                    uint32_t wv = 0u;
-                    if (rel < WWIN) wv = rfl(win[rel]);
-                    else if (pos < nwords) wv = rfl(st[pos]);
-                    ++pos;
-                    x = (x << 32) | wv;
-                }
-                int v = a;
-                if (a == last) {  // escape: rans_interface.cpp:323-345 (4-bit nibbles, 80-96)
-                    auto bits = [&]() -> int {
-                        const int val = (int)((uint32_t)x & ESC_MAX);
-                        x >>= ESC_BITS;
-                        if (x < RANS_LOW) {
-                            const int64_t rel = pos - win0;
-                            uint32_t wv = 0u;
-                            if (rel < WWIN) wv = rfl(win[rel]);
-                            else if (pos < nwords) wv = rfl(st[pos]);
-                            ++pos;
-                            x = (x << 32) | wv;
-                        }
-                        return val;
-                    };
-                    int nib = bits();
-                    int nn = nib;
-                    while (nib == (int)ESC_MAX) {
-                        nib = bits();
-                        nn += nib;
-                    }
-                    int raw = 0;
-                    for (int j = 0; j < nn; ++j) {
-                        nib = bits();
-                        if (j < 8) raw |= nib << (j * ESC_BITS);
-                    }
-                    v = raw >> 1;
-                    if (raw & 1) v = -v - 1;
-                    else v += last;
-                }
-                osym[i] = v + off;  // uniform value, same address from every lane
+        return wv;
+    };
+
+    const int64_t nb = (count + 63) >> 6;
+    int ti_next = (lane < count) ? idx[base + lane] : 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int cnt = (int)((count - b * 64) < 64 ? (count - b * 64) : 64);
+        const uint2 ri = rowinfo[ti_next];  // per-lane gather of the 64 symbols' row info
+        if (b + 1 < nb) ti_next = ((b + 1) * 64 + lane < count) ? idx[base + (b + 1) * 64 + lane] : 0;  // prefetch
+        uint32_t outv = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t m0 = rdl(ri.x, j), m1 = rdl(ri.y, j);
+            const int ro = (int)(m0 & 0xFFFFu), last = (int)(m0 >> 16) - 2;  // last = escape slot
+            const uint32_t cum = (uint32_t)x & 0xFFFFu;
+            const uint2 ev = sl[(m1 >> 16) + (cum >> shift)];
+            const uint32_t e0 = rfl(ev.x), e1 = rfl(ev.y);
+            int a = (int)(e0 & 0xFFFFu);
+            uint32_t start = e0 >> 16, freq = e1;
+            while (cum - start >= freq) {  // a symbol boundary inside the bucket: walk forward (rare, short)
+                ++a;
+                start += freq;
+                const uint32_t next = (a == last) ? 65536u : rfl((uint32_t)cdf[ro + a + 1]);
+                freq = next - start;
             }
-            if (tid == 0) hdr[0] = pos;
+            x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);  // rans64.h:131-133
+            if ((x >> 31) == 0) x = (x << 32) | next_word();
+            int v = a;
+            if (a == last) {  // escape: rans_interface.cpp:323-345 (4-bit nibbles, 80-96)
+                auto bits = [&]() -> int {
+                    const int val = (int)((uint32_t)x & ESC_MAX);
+                    x >>= ESC_BITS;
+                    if ((x >> 31) == 0) x = (x << 32) | next_word();
+                    return val;
+                };
+                int nib = bits();
+                int nn = nib;
+                while (nib == (int)ESC_MAX) {
+                    nib = bits();
+                    nn += nib;
+                }
+                int raw = 0;
+                for (int k = 0; k < nn; ++k) {
+                    nib = bits();
+                    if (k < 8) raw |= nib << (k * ESC_BITS);
+                }
+                v = raw >> 1;
+                if (raw & 1) v = -v - 1;
+                else v += last;
+            }
+            outv = wrl((uint32_t)(v + (int)(int16_t)(m1 & 0xFFFFu)), j, outv);
         }
-        __syncthreads();
-        for (int i = tid; i < cnt; i += 256) sym[base + lo + i] = osym[i];
+        if (lane < cnt) sym[base + b * 64 + lane] = (int32_t)outv;  // one coalesced store per 64 symbols
     }
-    if (tid == 0) {
+    if (lane == 0) {
         state[2 * s] = x;
         state[2 * s + 1] = (uint64_t)pos;
     }
@@ -458,7 +456,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 size_t rans_decode_lds_bytes(const DevTables& t)
 {
     const size_t lut_n = ((size_t)1 << t.lut_bits) + 1;
-    return 16 + (((size_t)t.nrows * lut_n + 1) & ~(size_t)1) * 8 + WWIN * 4 + CHUNK * 8 + CHUNK * sizeof(int32_t) +
+    return (((size_t)t.nrows * lut_n + 1) & ~(size_t)1) * 8 + (((size_t)t.nrows + 1) & ~(size_t)1) * 8 +
            (((size_t)t.total * 2 + 15) & ~(size_t)15);
 }
 
@@ -468,7 +466,7 @@ int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words,
 {
     if (nstreams <= 0 || count <= 0) return RGBD_OK;
     const size_t lds = rans_decode_lds_bytes(t);
-    if (lds > 158 * 1024) return RGBD_ENOSPC;
+    if (lds > 158 * 1024 || t.nrows * (((size_t)1 << t.lut_bits) + 1) > 65535) return RGBD_ENOSPC;
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel),
