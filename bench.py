@@ -17,6 +17,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per engine instance (the HIP default of 4 makes streams share queues, and a long serial coder
+# kernel then blocks another instance's convolutions); must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WORKLOADS = {
     # name: (batch per GPU, H, W, synthetic config id)

@@ -118,6 +118,10 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
 /* Symbols / indexes of the last compress() in stream order (modality 0/1), total count in *n. */
 int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n);
 
+/* When several codec instances share one GPU (one per HIP stream), their chip-filling transform phases (g_a, g_s) can be
+ * made mutually exclusive so that they overlap the other instances' serial entropy-coding phases instead of each other. */
+int rgbd_elic_set_exclusive_transforms(rgbd_elic* m, int32_t on);
+
 /* Measurement hook (bench.py): when on, every convolution launch is bracketed by HIP events on the launch stream.
  * profile_read returns the summed kernel time (ms), the launch count and the algorithmic FLOPs (2*MACs, unpadded)
  * accumulated since set_profile(). */

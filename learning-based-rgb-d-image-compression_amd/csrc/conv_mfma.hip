@@ -12,13 +12,18 @@
 // Numerics: every output element is one k-ordered fp32 fma chain (MFMA f32 semantics) whose order depends only on
 // the layer (chunk -> tap -> channel), never on tiling or batch size: results are run-to-run, batch- and
 // tile-invariant, which the entropy decoder relies on to reproduce the encoder's means/scales bit for bit.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // KC = channels per LDS stage (16 or 64).  LDS rows are padded by one 16-byte slot when KC > 16 so that the 16 rows a
 // ds_read_b128 lane group touches fall on different banks (row stride 272 B instead of 256 B).
-template <int WM, int WN, int MT, int NT, int KC>
+// PF: software-pipelined staging -- the global loads of stage s+1 are issued before the MFMAs of stage s and stay in
+// flight under them (costs ~80 VGPRs; used when a launch has too few workgroups to overlap load and compute phases of
+// different workgroups on one CU).
+template <int WM, int WN, int MT, int NT, int KC, bool PF>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
                                                          int taps_per_stage)
 {
@@ -27,7 +32,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     constexpr int RS = KC > 16 ? KC + 4 : KC;  // LDS row stride in floats
     constexpr int C4 = KC / 4;                  // 16-byte slots per row
     constexpr int WR = 8;                       // weight float4 per thread per stage (<= 32 KiB of weights per stage)
-    constexpr int PR = 12;                      // patch float4 per thread per chunk (<= 48 KiB patch)
+    constexpr int PR = TP >= 128 ? 12 : (TP >= 64 ? 6 : 4);  // patch float4 per thread per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -74,81 +79,102 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     }
 
     const int npatch4 = PH * PW * C4;
-    const size_t img_base = (size_t)n * a.H * a.W;
+    int brow0[NT];  // LDS float offset of this lane's pixel (tap (min_dy, min_dx)) for each column group
+#pragma unroll
+    for (int j = 0; j < NT; ++j) brow0[j] = ((ppy[j] * a.IS) * PW + ppx[j] * a.IS) * RS + q * 4;
     const int nchunks = (a.cin_pad + KC - 1) / KC;
     const int ngroups = (ntaps + taps_per_stage - 1) / taps_per_stage;
     const int nstages = nchunks * ngroups;
 
     // Register staging.  A stage = one tap group of one channel chunk; the input patch is reloaded per chunk.
+    // Everything that does not change from stage to stage is computed once here: per staging slot u the thread's
+    // global element offsets (weights: without the tap/chunk term; patch: pixel offset or -1 outside the image) --
+    // the per-stage work is then one add and one 16-byte load per slot.  LDS destinations are affine in u.
     f32x4 pw[WR], pp[PR];
-    auto issue_w = [&](int stage) {
-        const int ci0 = (stage / ngroups) * KC;
-        const int t0 = (stage % ngroups) * taps_per_stage;
-        const int nw4 = min(taps_per_stage, ntaps - t0) * TM * C4;
+    int gw_base[WR];   // (co0+m) * ntaps_total * cin_pad + c4*4, or -1 when the row is outside cout_pad
+    int gw_j[WR];      // tap slot inside the stage
+    int gp_off[PR];    // ((n*H + iy)*W + ix) * xcs + c4*4, or -1 when outside the image / patch
+    {
 #pragma unroll
         for (int u = 0; u < WR; ++u) {
             const int f = tid + u * 256;
             const int c4 = f % C4;
             const int m = (f / C4) % TM;
-            const int j = (f / C4) / TM;
+            gw_j[u] = (f / C4) / TM;
             const int co = co0 + m;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (f < nw4 && co < a.cout_pad && ci0 + c4 * 4 < a.cin_pad)
-                v = *reinterpret_cast<const f32x4*>(
-                    a.w + ((size_t)co * a.ntaps_total + a.taps.wt[phase][t0 + j]) * a.cin_pad + ci0 + c4 * 4);
-            pw[u] = v;
+            gw_base[u] = co < a.cout_pad ? (co * a.ntaps_total) * a.cin_pad + c4 * 4 : -1;
         }
-    };
-    auto commit_w = [&](int stage) {
-        const int t0 = (stage % ngroups) * taps_per_stage;
-        const int nw4 = min(taps_per_stage, ntaps - t0) * TM * C4;
-#pragma unroll
-        for (int u = 0; u < WR; ++u) {
-            const int f = tid + u * 256;
-            if (f < nw4) {
-                const int c4 = f % C4;
-                const int r = f / C4;  // j * TM + m
-                *reinterpret_cast<f32x4*>(wl + (size_t)r * RS + c4 * 4) = pw[u];
-            }
-        }
-    };
-    auto issue_p = [&](int chunk) {
-        const int ci0 = chunk * KC;
 #pragma unroll
         for (int u = 0; u < PR; ++u) {
             const int f = tid + u * 256;
             const int row = f / C4, c4 = f - row * C4;
             const int pr = row / PW, pc = row - pr * PW;
             const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = f < npatch4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            gp_off[u] = ok ? (int)(((size_t)n * a.H * a.W + (size_t)iy * a.W + ix) * a.xcs) + c4 * 4 : -1;
+        }
+    }
+    const int w_lds0 = (tid / C4) * RS + (tid % C4) * 4;  // slot u adds u * (256 / C4) * RS floats
+    auto issue_w = [&](int stage) {
+        const int ci0 = (stage / ngroups) * KC;
+        const int t0 = (stage % ngroups) * taps_per_stage;
+        const int tg = min(taps_per_stage, ntaps - t0);
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (f < npatch4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci0 + c4 * 4 < a.cin_pad)
-                v = *reinterpret_cast<const f32x4*>(a.x + (img_base + (size_t)iy * a.W + ix) * a.xcs + ci0 + c4 * 4);
+            const int c4x4 = ((tid + u * 256) % C4) * 4;
+            if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < a.cin_pad))
+                v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + (int)a.taps.wt[phase][t0 + gw_j[u]] * a.cin_pad + ci0);
+            pw[u] = v;
+        }
+    };
+    auto commit_w = [&](int stage) {
+        const int t0 = (stage % ngroups) * taps_per_stage;
+        const int nrows = min(taps_per_stage, ntaps - t0) * TM;
+#pragma unroll
+        for (int u = 0; u < WR; ++u)
+            if (tid / C4 + u * (256 / C4) < nrows)
+                *reinterpret_cast<f32x4*>(wl + w_lds0 + u * (256 / C4) * RS) = pw[u];
+    };
+    auto issue_p = [&](int chunk) {
+        const int ci0 = chunk * KC;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int c4x4 = ((tid + u * 256) % C4) * 4;
+            if (gp_off[u] >= 0 && (KC == 16 || ci0 + c4x4 < a.cin_pad))
+                v = *reinterpret_cast<const f32x4*>(a.x + gp_off[u] + ci0);
             pp[u] = v;
         }
     };
     auto commit_p = [&]() {
 #pragma unroll
-        for (int u = 0; u < PR; ++u) {
-            const int f = tid + u * 256;
-            if (f < npatch4) {
-                const int row = f / C4, c4 = f - row * C4;
-                *reinterpret_cast<f32x4*>(patch + (size_t)row * RS + c4 * 4) = pp[u];
-            }
-        }
+        for (int u = 0; u < PR; ++u)
+            if (tid + u * 256 < npatch4) *reinterpret_cast<f32x4*>(patch + w_lds0 + u * (256 / C4) * RS) = pp[u];
     };
 
+    if (PF) {
+        issue_p(0);
+        issue_w(0);
+    }
     for (int stage = 0; stage < nstages; ++stage) {
         const int t0 = (stage % ngroups) * taps_per_stage;
         const int tg = min(taps_per_stage, ntaps - t0);
-        // all global loads of the stage are issued back to back (one memory round trip per stage), then committed to
-        // LDS; the staging registers are dead during the MFMA phase so two workgroups fit per CU and hide each other's
-        // load phase
-        issue_w(stage);
-        if (t0 == 0) issue_p(stage / ngroups);
+        if (!PF) {
+            // all global loads of the stage are issued back to back (one memory round trip per stage), then committed
+            // to LDS; the staging registers are dead during the MFMA phase so two workgroups fit per CU and hide each
+            // other's load phase
+            issue_w(stage);
+            if (t0 == 0) issue_p(stage / ngroups);
+        }
         __syncthreads();  // every wave has finished reading the previous stage from LDS
         if (t0 == 0) commit_p();
         commit_w(stage);
         __syncthreads();
+        if (PF && stage + 1 < nstages) {
+            issue_w(stage + 1);
+            if ((stage + 1) % ngroups == 0) issue_p((stage + 1) / ngroups);
+        }
         // canonical accumulation order: 16-channel chunk -> tap -> channel.  A 64-channel stage therefore walks its
         // four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so the
         // fma chain of each output is the same for every KC / tile choice.
@@ -157,16 +183,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             for (int j = 0; j < tg; ++j) {
                 const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
                 const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
+                const int toff = (dy * PW + dx) * RS + kk * 16;  // wave-uniform
                 f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-                    af[i] = *reinterpret_cast<const f32x4*>(
-                        wl + ((size_t)j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
+                    af[i] = *reinterpret_cast<const f32x4*>(wl + (j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
 #pragma unroll
-                for (int k = 0; k < NT; ++k) {
-                    const int row = (ppy[k] * a.IS + dy) * PW + ppx[k] * a.IS + dx;
-                    bf[k] = *reinterpret_cast<const f32x4*>(patch + (size_t)row * RS + kk * 16 + q * 4);
-                }
+                for (int k = 0; k < NT; ++k) bf[k] = *reinterpret_cast<const f32x4*>(patch + brow0[k] + toff);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -216,7 +239,7 @@ namespace {
 
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
-template <int WM, int WN, int MT, int NT, int KC>
+template <int WM, int WN, int MT, int NT, int KC, bool PF>
 int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
 {
     constexpr int TM = 16 * MT * WM;
@@ -229,13 +252,14 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     const size_t tap_bytes = (size_t)TM * RS * sizeof(float);
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
-    if ((long)PH * PW * (KC / 4) > 12 * 256) return RGBD_ENOSPC;  // patch registers (PR)
+    constexpr int PR = TP >= 128 ? 12 : (TP >= 64 ? 6 : 4);
+    if ((long)PH * PW * (KC / 4) > PR * 256) return RGBD_ENOSPC;  // patch registers
     long room = (8 * 256) / ((long)TM * (KC / 4));               // weight registers (WR)
     if (room < 1) return RGBD_ENOSPC;
     const int tps = (int)(room < max_taps ? room : max_taps);
     if (KC > 16 && tps < max_taps) return RGBD_ENOSPC;  // would break the canonical accumulation order
     const size_t lds = patch_bytes + (size_t)tps * tap_bytes;
-    auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC>;
+    auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, PF>;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -267,6 +291,7 @@ int pick_tw_log2(int GW, int GH, int TP)
 
 struct Choice {
     int wm, mt, nt, kc, tw_log2;
+    bool pf;
 };
 
 Choice choose(const ConvArgs& a)
@@ -281,8 +306,9 @@ Choice choose(const ConvArgs& a)
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
     const double K = (double)max_taps * a.cin_pad;
-    Choice best{2, 4, 4, 16, 4};
+    Choice best{2, 4, 4, 16, 4, false};
     double best_cost = -1.0;
+    long best_blocks = 0;
     for (const auto& c : cand) {
         const int wm = c[0], mt = c[1], nt = c[2];
         const int tm = 16 * mt * wm, tp = 16 * nt * (wm == 2 ? 2 : 4);
@@ -291,14 +317,18 @@ Choice choose(const ConvArgs& a)
         const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
         const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase;
         const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
-        if ((long)PH * PW * 4 > 12 * 256 || (long)tm * 4 > 8 * 256) continue;  // register-staging limits (KC=16)
-        const double mfma = (double)mt * nt * (K / 4.0) * 32.0 + 3000.0;             // cycles per workgroup (+ prologue)
+        const int pr = tp >= 128 ? 12 : (tp >= 64 ? 6 : 4);
+        if ((long)PH * PW * 4 > pr * 256 || (long)tm * 4 > 8 * 256) continue;  // register-staging limits (KC=16)
+        // a wave with one or two accumulator tiles cannot cover the MFMA latency / its LDS reads
+        const double ilp = mt * nt >= 4 ? 1.0 : (mt * nt >= 2 ? 0.7 : 0.45);
+        const double mfma = (double)mt * nt * (K / 4.0) * 32.0 / ilp + 3000.0;      // cycles per workgroup (+ prologue)
         const double load = (K * tm * 4.0 + (double)PH * PW * a.cin_pad * 4.0) / 12.0;  // ~12 B/clk/CU from L2
         const long nb = (blocks + 255) / 256;
         const double cost = nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load);
         if (best_cost < 0 || cost < best_cost * 0.999) {
             best_cost = cost;
-            best = Choice{wm, mt, nt, 16, twl};
+            best = Choice{wm, mt, nt, 16, twl, false};
+            best_blocks = blocks;
         }
     }
     // channels per stage: 64 when one stage can hold every tap (keeps the canonical order) and a 16-channel stage
@@ -311,17 +341,21 @@ Choice choose(const ConvArgs& a)
         const long mfma_per_stage16 = (long)max_taps * 4 * best.mt * best.nt;
         const long p4 = (long)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 16;
         const long w4 = (long)max_taps * 16 * best.mt * best.wm * 16;
-        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400 && p4 <= 12 * 256 &&
+        const int pr = tp >= 128 ? 12 : (tp >= 64 ? 6 : 4);
+        if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400 && p4 <= pr * 256 &&
             w4 <= 8 * 256)
             best.kc = 64;
     }
+    best.pf = best_blocks <= 512;  // at most ~2 workgroups per CU: overlap load and compute inside the workgroup
     return best;
 }
 
 #define RGBD_CASE(WM_, WN_, MT_, NT_)                                              \
     if (c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                                 \
-        return c.kc == 64 ? launch_cfg<WM_, WN_, MT_, NT_, 64>(a, c.tw_log2, s)    \
-                          : launch_cfg<WM_, WN_, MT_, NT_, 16>(a, c.tw_log2, s);
+        return c.kc == 64 ? (c.pf ? launch_cfg<WM_, WN_, MT_, NT_, 64, true>(a, c.tw_log2, s)    \
+                                  : launch_cfg<WM_, WN_, MT_, NT_, 64, false>(a, c.tw_log2, s)) \
+                          : (c.pf ? launch_cfg<WM_, WN_, MT_, NT_, 16, true>(a, c.tw_log2, s)    \
+                                  : launch_cfg<WM_, WN_, MT_, NT_, 16, false>(a, c.tw_log2, s));
 
 }  // namespace
 
@@ -331,6 +365,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s)
     if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;
     if (a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
     const Choice c = choose(a);
+    static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "[conv] N=%d GH=%d GW=%d cin=%d cout=%d taps=%d IS=%d nph=%d -> WM=%d MT=%d NT=%d KC=%d tw=%d pf=%d\n", a.N,
+                a.GH, a.GW, a.cin_pad, a.cout_pad, a.taps.n[0], a.IS, a.nphase, c.wm, c.mt, c.nt, c.kc, 1 << c.tw_log2, (int)c.pf);
     RGBD_CASE(2, 2, 5, 4) RGBD_CASE(2, 2, 4, 4) RGBD_CASE(2, 2, 3, 4) RGBD_CASE(2, 2, 2, 4) RGBD_CASE(2, 2, 1, 4)
     RGBD_CASE(2, 2, 5, 2) RGBD_CASE(2, 2, 4, 2) RGBD_CASE(2, 2, 3, 2) RGBD_CASE(2, 2, 2, 2) RGBD_CASE(2, 2, 1, 2)
     RGBD_CASE(2, 2, 5, 1) RGBD_CASE(2, 2, 4, 1) RGBD_CASE(2, 2, 3, 1) RGBD_CASE(2, 2, 2, 1) RGBD_CASE(2, 2, 1, 1)

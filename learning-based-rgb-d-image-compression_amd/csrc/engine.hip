@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -182,6 +183,11 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
     a->span_y = a->span_x = mx - mn + 1;
 }
 
+// Several engine instances may share one GPU (CodecPool): their chip-filling transform phases (g_a, g_s) take this
+// lock in turn, so one instance's transforms overlap the OTHER instances' serial entropy-coding phases instead of
+// each other.
+std::mutex g_transform_phase;
+
 // ------------------------------------------------------------------------------------------------
 // the model
 // ------------------------------------------------------------------------------------------------
@@ -234,10 +240,15 @@ struct rgbd_elic {
     int32_t* dbg_idx = nullptr;
     int64_t dbg_per_mod = 0;
 
+    bool exclusive_transforms = false;  // serialise g_a / g_s against other instances (see g_transform_phase)
+
     // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    std::vector<std::pair<std::string, double>> ev_names;  // per recorded launch: layer name, flops
+    std::map<std::string, std::pair<double, double>> prof_layers;  // name -> (ms, flops)
+    std::map<std::string, int> prof_counts;
     double prof_flops = 0.0;   // algorithmic (unpadded) FLOPs of the recorded launches
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
@@ -359,9 +370,11 @@ struct rgbd_elic {
         const int r = launch_conv(a, s);
         if (profile) {
             (void)hipEventRecord(e1, s);
-            prof_flops += 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
-                          (pc->transposed ? (double)(stride * stride) : 1.0);
+            const double fl = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
+                              (pc->transposed ? (double)(stride * stride) : 1.0);
+            prof_flops += fl;
             ++prof_launches;
+            ev_names.emplace_back(name, fl);
         }
         if (r) {
             fprintf(stderr, "[rgbd_amd] conv launch failed at %s (%d)\n", name.c_str(), r);
@@ -375,9 +388,18 @@ struct rgbd_elic {
     {
         for (size_t i = 0; i + 1 < ev_used; i += 2) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) prof_ms += ms;
+            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) {
+                prof_ms += ms;
+                if (i / 2 < ev_names.size()) {
+                    auto& acc = prof_layers[ev_names[i / 2].first];
+                    acc.first += ms;
+                    acc.second += ev_names[i / 2].second;
+                    ++prof_counts[ev_names[i / 2].first];
+                }
+            }
         }
         ev_used = 0;
+        ev_names.clear();
     }
 
     void copy_ch(const Act& src, const Act& dst)
@@ -865,12 +887,15 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
     Act z_r, z_d;
     {
+        std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
+        if (exclusive_transforms && !dry()) phase.lock();
         const size_t mark = arena.top;
         Act yr_t, yd_t;
         g_a(rgb, depth, &yr_t, &yd_t);
         copy_ch(yr_t, y_r);
         copy_ch(yd_t, y_d);
         arena.top = mark;
+        if (phase.owns_lock()) HIP_TRY(hipStreamSynchronize(s));  // the phase ends when the GPU has finished it
     }
     h_a(y_r, y_d, &z_r, &z_d);
     named["y_r"] = y_r;
@@ -1068,11 +1093,17 @@ int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2
     bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
 
     Act xr, xd;
+    std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
+    if (exclusive_transforms && !dry()) {
+        HIP_TRY(hipStreamSynchronize(s));  // wait for our own serial phase outside the lock
+        phase.lock();
+    }
     g_s(yhat_r, yhat_d, &xr, &xd);
     if (rc) return rc;
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 1, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 1, s);
+    if (phase.owns_lock()) HIP_TRY(hipStreamSynchronize(s));
     return r;
 }
 
@@ -1601,6 +1632,13 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
     return r;
 }
 
+int rgbd_elic_set_exclusive_transforms(rgbd_elic* m, int32_t on)
+{
+    if (!m) return RGBD_EINVAL;
+    m->exclusive_transforms = on != 0;
+    return RGBD_OK;
+}
+
 int rgbd_elic_set_profile(rgbd_elic* m, int32_t on)
 {
     if (!m) return RGBD_EINVAL;
@@ -1609,6 +1647,22 @@ int rgbd_elic_set_profile(rgbd_elic* m, int32_t on)
     m->prof_flops = 0.0;
     m->prof_ms = 0.0;
     m->prof_launches = 0;
+    m->prof_layers.clear();
+    m->prof_counts.clear();
+    m->ev_names.clear();
+    return RGBD_OK;
+}
+
+int rgbd_elic_profile_dump(rgbd_elic* m, const char* path)
+{
+    if (!m || !path) return RGBD_EINVAL;
+    FILE* f = fopen(path, "w");
+    if (!f) return RGBD_EINVAL;
+    fprintf(f, "layer,launches,ms,gflop,tflops\n");
+    for (const auto& kv : m->prof_layers)
+        fprintf(f, "%s,%d,%.4f,%.3f,%.2f\n", kv.first.c_str(), m->prof_counts[kv.first], kv.second.first,
+                kv.second.second / 1e9, kv.second.first > 0 ? kv.second.second / kv.second.first / 1e9 : 0.0);
+    fclose(f);
     return RGBD_OK;
 }
 

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-layer conv timing inside a real compress()+decompress() (HIP events around every launch, single instance)."""
+import ctypes
+import os
+import re
+import sys
+import collections
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import rgbd_amd  # noqa: E402
+from rgbd_amd import ELIC_united, synth  # noqa: E402
+from rgbd_amd._lib import _SO  # noqa: E402
+
+B, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (8, 256, 256)
+sd = synth.synthetic_state_dict(0)
+net = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+net.load_state_dict(sd)
+net.update(force=True)
+net = net.to("cuda")
+net.per_image_streams = True
+r, d = synth.synthetic_batch(B, H, W, config_id=2)
+rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+for _ in range(2):
+    out = net.compress(rgb, depth)
+    net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+net.set_profile(True)
+N = 3
+for _ in range(N):
+    out = net.compress(rgb, depth)
+    net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+L = ctypes.CDLL(_SO)
+L.rgbd_elic_profile_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+path = "/tmp/layers.csv"
+L.rgbd_elic_profile_dump(net._h, path.encode())
+rows = [l.strip().split(",") for l in open(path)][1:]
+groups = collections.defaultdict(lambda: [0, 0.0, 0.0])
+
+
+def group(name):
+    name = re.sub(r"\.\d+\.", ".N.", name)
+    name = re.sub(r"(rgb|depth)_", "M_", name)
+    name = re.sub(r"\.(r|d)_", ".M_", name)
+    return re.sub(r"\.\d+$", ".N", name)
+
+
+for name, cnt, ms, gf, tf in rows:
+    g = groups[group(name)]
+    g[0] += int(cnt)
+    g[1] += float(ms)
+    g[2] += float(gf)
+tot = sum(g[1] for g in groups.values())
+print(f"total conv ms/step {tot/N:.2f}")
+for k, g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{k:62s} n={g[0]//N:4d} {g[1]/N:7.3f} ms/step {g[2]/max(g[1],1e-9):7.1f} TF/s {100*g[1]/tot:5.1f}%")
