@@ -1,0 +1,77 @@
+"""Quality metrics of the reference harness (utils/metrics.py:8-30).
+
+PSNR follows the reference exactly (MSE of the clamped tensors).  MS-SSIM restates the published definition that
+pytorch_msssim implements (11-tap Gaussian, sigma 1.5, five scales, default weights); pytorch_msssim is not installed in
+the build image, so that number is NOT pinned against the reference.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_MS_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def psnr(a: torch.Tensor, b: torch.Tensor, max_val: float = 1.0) -> float:
+    mse = torch.mean((a.clamp(0, 1) - b.clamp(0, 1)) ** 2).item()
+    return float(20 * np.log10(max_val) - 10 * np.log10(mse))
+
+
+def _gauss(size=11, sigma=1.5, device=None):
+    c = torch.arange(size, dtype=torch.float32, device=device) - size // 2
+    g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def _filter(x, g):
+    C = x.shape[1]
+    x = F.conv2d(x, g.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+    return F.conv2d(x, g.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
+
+
+def _ssim_cs(x, y, g, data_range):
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    mu1, mu2 = _filter(x, g), _filter(y, g)
+    s1 = _filter(x * x, g) - mu1 * mu1
+    s2 = _filter(y * y, g) - mu2 * mu2
+    s12 = _filter(x * y, g) - mu1 * mu2
+    cs = (2 * s12 + c2) / (s1 + s2 + c2)
+    ssim = ((2 * mu1 * mu2 + c1) / (mu1 * mu1 + mu2 * mu2 + c1)) * cs
+    return ssim.flatten(2).mean(-1), cs.flatten(2).mean(-1)
+
+
+def ms_ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> float:
+    if min(x.shape[-2:]) <= (11 - 1) * 2 ** 4:
+        raise ValueError("image too small for 5-scale MS-SSIM (needs a side > 160)")
+    g = _gauss(device=x.device)
+    w = torch.tensor(_MS_WEIGHTS, device=x.device)
+    mcs = []
+    for i in range(5):
+        s, cs = _ssim_cs(x, y, g, data_range)
+        if i < 4:
+            mcs.append(torch.relu(cs))
+            pad = [d % 2 for d in x.shape[2:]]
+            x = F.avg_pool2d(x, 2, padding=pad)
+            y = F.avg_pool2d(y, 2, padding=pad)
+    vals = torch.stack(mcs + [torch.relu(s)], dim=0)
+    return float(torch.prod(vals ** w.view(-1, 1, 1), dim=0).mean().item())
+
+
+def compute_metrics(a, b, max_val: float = 1.0):
+    a, b = a.clamp(0, 1), b.clamp(0, 1)
+    p = psnr(a, b, max_val)
+    try:
+        m = ms_ssim(a.float(), b.float(), data_range=max_val)
+    except ValueError:
+        m = float("nan")
+    return p, m
+
+
+class AverageMeter:
+    def __init__(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count

@@ -18,6 +18,8 @@ from .elic_united import ELIC_united
 class CodecPool:
     def __init__(self, state_dict, config=None, workers: int = 2, device="cuda", per_image_streams: bool = True):
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.nets: List[ELIC_united] = []
         self.streams = []
         for _ in range(workers):

@@ -1,0 +1,165 @@
+"""`TesterUnited` on the MI355X engine: the reference's test harness for channel==4 models
+(testing/tester.py:17-108, testing/tester_single.py:34-42, testing/tester_united.py:15-195) with the same directory
+layout, container files, bpp / PSNR arithmetic, timing windows and log lines, so `playground/test.py -m ELIC_united
+--channel 4 -q 2_2 -d <dataset>` has a drop-in target.  Image I/O uses PIL (cv2 / torchvision are not required).
+"""
+import logging
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .arch import model_config
+from .datautils import crop0, crop1, pad
+from .elic_united import modelZoo
+from .ioutils import filesize, read_body, read_uints, write_body, write_uints
+from .metrics import AverageMeter, compute_metrics
+
+
+def load_image(path, mode):
+    """dataset/testDataset.py:36-61: RGB/255; depth scaled by 10000 / 100000 / 255 depending on its range."""
+    from PIL import Image
+
+    img = np.array(Image.open(path))
+    if mode == "RGB":
+        if img.ndim == 2:
+            img = np.stack([img] * 3, -1)
+        t = torch.from_numpy(np.ascontiguousarray(img[..., :3].transpose(2, 0, 1))).float() / 255.0
+    else:
+        t = torch.from_numpy(img.astype("float32"))[None]
+        mx = float(t.max())
+        t = t / (10000.0 if 255 < mx < 10000 else (100000.0 if mx > 10000 else 255.0))
+    return t
+
+
+class ImageFolderUnited:
+    """Pairs <root>/rgb/* with <root>/depth/* by sorted file name (dataset/testDataset.py:14-79)."""
+
+    def __init__(self, root, debug=False):
+        self.rgb = sorted(f for f in (Path(root) / "rgb").iterdir() if f.is_file())
+        self.depth = sorted(f for f in (Path(root) / "depth").iterdir() if f.is_file())
+        if not self.rgb or len(self.rgb) != len(self.depth):
+            raise RuntimeError(f'Invalid directory "{root}"')
+        if debug:
+            self.rgb, self.depth = self.rgb[:20], self.depth[:20]
+
+    def __len__(self):
+        return len(self.rgb)
+
+    def __getitem__(self, i):
+        return (load_image(self.rgb[i], "RGB")[None], load_image(self.depth[i], "L")[None],
+                [os.path.splitext(self.rgb[i].name)[0]], [os.path.splitext(self.depth[i].name)[0]])
+
+
+class TesterUnited:
+    def __init__(self, args, config=None, net=None):
+        self.device = "cuda"
+        self.channel = args.channel
+        self.debug = getattr(args, "debug", False)
+        self.exp_name = args.experiment or self.get_exp_name(args.dataset, args.channel, args.model, args.quality)
+        self.exp_dir_path = os.path.join("../experiments_test" if self.debug else "../experiments", self.exp_name)
+        self.ckpt_dir_path = os.path.join(self.exp_dir_path, "checkpoints")
+        self.model_config = config or model_config()
+        self.net = net
+        self.epoch = 0
+        if net is None:
+            self.epoch = self.get_net(self.model_config, args.model, args.checkpoint)
+        self.logger_test = logging.getLogger("test")
+        self.test_dataloader = ImageFolderUnited(args.dataset, debug=self.debug) if args.dataset else None
+        self.save_dir = os.path.join(self.exp_dir_path, "codestream")
+
+    # tester.py:55-108
+    def get_net(self, model_config_, model_name, ckpt_path):
+        for name, model in modelZoo.items():
+            if model_name.find(name) != -1:
+                self.net = model(config=model_config_, channel=self.channel).eval()
+                break
+        else:
+            raise ValueError(f"model {model_name} is not provided by rgbd_amd (ELIC_united only)")
+        best = os.path.join(self.ckpt_dir_path, "checkpoint_best_loss.pth.tar")
+        if ckpt_path is None and os.path.exists(best):
+            ckpt_path = best
+        checkpoint = torch.load(ckpt_path, map_location="cpu")
+        self.net.load_state_dict(checkpoint["state_dict"])
+        self.net.update(force=True)
+        self.net = self.net.to(self.device)
+        return checkpoint["epoch"]
+
+    @staticmethod
+    def get_exp_name(dataset, channel, model_name, quality):
+        modal = {1: "depth_", 3: "rgb_", 4: ""}[channel]
+        return f"{'nyuv2' if dataset.find('nyu') != -1 else 'sunrgbd'}_{modal}{model_name}_{quality}"
+
+    def get_rec_dir(self, padding=True, padding_mode="reflect0"):
+        rec_dir = os.path.join(self.save_dir, f"{self.epoch}-padding-{padding_mode}" if padding else f"{self.epoch}-CenterCrop")
+        for d in (rec_dir, os.path.join(rec_dir, "depth_rec"), os.path.join(rec_dir, "rgb_rec")):
+            os.makedirs(d, exist_ok=True)
+        return rec_dir
+
+    # tester_united.py:141-167
+    def compress_one_image_united(self, x, stream_path, H, W, img_name):
+        torch.cuda.synchronize()
+        start = time.time()
+        out = self.net.compress(x[0], x[1])
+        torch.cuda.synchronize()
+        enc_time = time.time() - start
+        bpps = []
+        for path, key in ((stream_path[0], "r_strings"), (stream_path[1], "d_strings")):
+            os.makedirs(path, exist_ok=True)
+            fn = os.path.join(path, img_name)
+            with Path(fn).open("wb") as f:
+                write_uints(f, (H, W))
+                write_body(f, out["shape"], out[key])
+            bpps.append(float(filesize(fn)) * 8 / (H * W))
+        return bpps[0], bpps[1], enc_time
+
+    # tester_united.py:169-195
+    def decompress_one_image_united(self, stream_path, img_name, mode="reflect0"):
+        strings = []
+        for path in stream_path:
+            with Path(os.path.join(path, img_name)).open("rb") as f:
+                original_size = read_uints(f, 2)
+                s, shape = read_body(f)
+                strings.append(s)
+        torch.cuda.synchronize()
+        start = time.time()
+        out = self.net.decompress(strings[0], strings[1], shape)
+        torch.cuda.synchronize()
+        dec_time = time.time() - start
+        cropper = crop0 if mode.find("0") != -1 else crop1
+        return cropper(out["x_hat"]["r"], original_size), cropper(out["x_hat"]["d"], original_size), dec_time
+
+    # tester_united.py:48-88 (the rgb stream really lands in "depth_bin" and vice versa, :62-63)
+    @torch.no_grad()
+    def test_model(self, padding_mode="reflect0", padding=True):
+        self.net.eval()
+        names = ("avg_rgb_psnr", "avg_rgb_ms_ssim", "avg_rgb_bpp", "avg_depth_psnr", "avg_depth_ms_ssim",
+                 "avg_depth_bpp", "avg_deocde_time", "avg_encode_time")
+        meters = {k: AverageMeter() for k in names}
+        rec_dir = self.get_rec_dir(padding=padding, padding_mode=padding_mode)
+        rows = []
+        for i in range(len(self.test_dataloader)):
+            rgb, depth, rgb_name, _ = self.test_dataloader[i]
+            _, _, H, W = rgb.shape
+            rgb, depth = rgb.to(self.device), depth.to(self.device)
+            paths = (os.path.join(rec_dir, "depth_bin"), os.path.join(rec_dir, "rgb_bin"))
+            rb, db, et = self.compress_one_image_united((pad(rgb, padding_mode), pad(depth, padding_mode)), paths, H, W,
+                                                        rgb_name[0])
+            xr, xd, dt = self.decompress_one_image_united(paths, rgb_name[0], mode=padding_mode)
+            rp, rm = compute_metrics(xr, rgb)
+            dp, dm = compute_metrics(xd, depth)
+            for k, v in zip(names, (rp, rm, rb, dp, dm, db, dt, et)):
+                meters[k].update(v)
+            self.logger_test.info(
+                f"Image[{i}:{rgb_name[0]}] | rBpp loss: {rb:.4f} | dBpp loss: {db:.4f} | rPSNR: {rp:.4f} | dPSNR: {dp:.4f} | "
+                f"rMS-SSIM: {rm:.4f} | dMS-SSIM: {dm:.4f} | Encoding Latency: {et:.4f} | Decoding latency: {dt:.4f}")
+            rows.append({"name": rgb_name[0], "rgb_bpp": rb, "depth_bpp": db, "rgb_psnr": rp, "depth_psnr": dp,
+                         "enc_time": et, "dec_time": dt})
+        self.logger_test.info(
+            f"Epoch:[{self.epoch}] | Avg rBpp: {meters['avg_rgb_bpp'].avg:.7f} | Avg dBpp: {meters['avg_depth_bpp'].avg:.7f} | "
+            f"Avg rPSNR: {meters['avg_rgb_psnr'].avg:.7f} | Avg dPSNR: {meters['avg_depth_psnr'].avg:.7f} | "
+            f"Avg rMS-SSIM: {meters['avg_rgb_ms_ssim'].avg:.7f} | Avg dMS-SSIM: {meters['avg_depth_ms_ssim'].avg:.7f} | "
+            f"Avg Encoding Latency: {meters['avg_encode_time'].avg:.6f} | Avg Decoding latency: {meters['avg_deocde_time'].avg:.6f}")
+        return rows, meters

@@ -1,0 +1,86 @@
+"""TesterUnited counterpart end to end on the GPU (files on disk, container format, bpp / PSNR arithmetic), and the
+pooled multi-stream path against the single-instance path."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_utils import require_gpu
+from oracle import elic_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net(synth_sd):
+    require_gpu()
+    import rgbd_amd
+
+    m = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    m.load_state_dict(synth_sd)
+    m.update(force=True)
+    return m.to("cuda")
+
+
+def test_tester_united_on_files(net, tmp_path, monkeypatch):
+    from PIL import Image
+
+    import rgbd_amd
+    from rgbd_amd import synth
+
+    root = tmp_path / "nyu_test"
+    (root / "rgb").mkdir(parents=True)
+    (root / "depth").mkdir()
+    for i in range(2):
+        r, d = synth.synthetic_pair(i, 100, 150, config_id=5, smooth=True)
+        Image.fromarray((r.transpose(1, 2, 0) * 255).astype(np.uint8)).save(root / "rgb" / f"{i:04d}.png")
+        Image.fromarray((d[0] * 9000).astype(np.uint16)).save(root / "depth" / f"{i:04d}.png")
+    monkeypatch.chdir(tmp_path)
+    args = types.SimpleNamespace(channel=4, debug=False, experiment="exp", dataset=str(root), model="ELIC_united",
+                                 quality="2_2", checkpoint=None)
+    t = rgbd_amd.TesterUnited(args, rgbd_amd.model_config(), net=net)
+    rows, meters = t.test_model(padding_mode="replicate0", padding=True)
+    assert len(rows) == 2
+    rec_dir = t.get_rec_dir(padding=True, padding_mode="replicate0")
+    for row in rows:
+        # rgb stream lands in depth_bin and vice versa (tester_united.py:62-63)
+        fr = os.path.join(rec_dir, "depth_bin", row["name"])
+        fd = os.path.join(rec_dir, "rgb_bin", row["name"])
+        assert row["rgb_bpp"] == os.path.getsize(fr) * 8.0 / (100 * 150)
+        assert row["depth_bpp"] == os.path.getsize(fd) * 8.0 / (100 * 150)
+        assert np.isfinite(row["rgb_psnr"]) and np.isfinite(row["depth_psnr"]) and row["enc_time"] > 0
+    # the file round trip reproduces the direct call bit for bit
+    rgb, depth, name, _ = t.test_dataloader[0]
+    rp, dp = rgbd_amd.datautils.pad(rgb.cuda(), "replicate0"), rgbd_amd.datautils.pad(depth.cuda(), "replicate0")
+    out = net.compress(rp, dp)
+    rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    xr, xd, _ = t.decompress_one_image_united((os.path.join(rec_dir, "depth_bin"), os.path.join(rec_dir, "rgb_bin")),
+                                              name[0], mode="replicate0")
+    assert torch.equal(xr, rec["x_hat"]["r"][:, :, :100, :150]) and torch.equal(xd, rec["x_hat"]["d"][:, :, :100, :150])
+    assert abs(eo.psnr(xr.cpu(), rgb) - rows[0]["rgb_psnr"]) < 1e-9
+    assert abs(meters["avg_rgb_bpp"].avg - np.mean([r["rgb_bpp"] for r in rows])) < 1e-12
+
+
+def test_pool_matches_single_instance(net, synth_sd):
+    import rgbd_amd
+    from rgbd_amd import synth
+
+    pool = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=2, device="cuda", per_image_streams=True)
+    r, d = synth.synthetic_batch(4, 128, 128, config_id=11)
+    rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+    net.per_image_streams = True
+    try:
+        ref = net.compress(rgb, depth)
+        ref_rec = net.decompress(ref["r_strings"], ref["d_strings"], ref["shape"])
+    finally:
+        net.per_image_streams = False
+    outs, xr, xd = pool.roundtrip(rgb, depth)  # two groups of two images on two streams
+    ys = [s for o in outs for s in o["r_strings"][0]]
+    assert ys == ref["r_strings"][0]
+    assert torch.equal(xr, ref_rec["x_hat"]["r"]) and torch.equal(xd, ref_rec["x_hat"]["d"])
+    many = pool.roundtrip_many([(rgb, depth)] * 3)
+    for out, mxr, mxd in many:
+        assert out["r_strings"] == ref["r_strings"] and out["d_strings"] == ref["d_strings"]
+        assert torch.equal(mxr, ref_rec["x_hat"]["r"])

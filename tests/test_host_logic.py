@@ -1,0 +1,153 @@
+"""Host-side logic that needs no GPU: C-ABI surface, table construction, checkpoint interface, container / pad / PSNR
+arithmetic of the harness (pinned by goldens captured from the reference)."""
+import ctypes
+import hashlib
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import elic_oracle as eo
+
+
+def test_library_exports_every_declared_symbol():
+    from rgbd_amd import _lib
+
+    L = _lib.lib()  # raises if a declared symbol is missing
+    assert L.rgbd_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "rgbd_amd.h")).read()
+    declared = set(re.findall(r"\b(rgbd_[a-z0-9_]+)\s*\(", header))
+    raw = ctypes.CDLL(_lib._SO)
+    for name in sorted(declared):
+        getattr(raw, name)
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_abi_argument_errors_without_gpu():
+    from rgbd_amd._lib import lib
+
+    L = lib()
+    out = (ctypes.c_uint32 * 4)()
+    assert L.rgbd_pmf_to_quantized_cdf(None, 3, 16, out) == -22
+    h = ctypes.c_void_p()
+    bad = (ctypes.c_int32 * 2)(16, 17)
+    assert L.rgbd_elic_create(192, 320, bad, 2, ctypes.byref(h)) == -22  # slices must sum to M, multiples of 16
+    assert L.rgbd_elic_compress(None, None, None, 1, 64, 64, 1, None) != 0
+    assert L.rgbd_rans_max_bytes(100) >= 4 * (100 + 2)
+
+
+def test_host_cdf_quantiser_matches_reference(kat):
+    from rgbd_amd import ans
+
+    for k in range(4):
+        assert ans.pmf_to_quantized_cdf(kat[f"pmf{k}"].tolist(), 16) == kat[f"pmf{k}_cdf"].tolist()
+
+
+def test_update_builds_reference_tables(kat, synth_sd):
+    import rgbd_amd
+
+    net = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    net.load_state_dict(synth_sd)
+    assert net.update(force=True) is True
+    gc = net.rgb_gaussian_conditional
+    assert np.array_equal(gc.quantized_cdf.numpy(), kat["gc_cdf"])
+    assert np.array_equal(gc.cdf_length.numpy(), kat["gc_sizes"]) and np.array_equal(gc.offset.numpy(), kat["gc_offsets"])
+    for m in ("rgb", "depth"):
+        eb = getattr(net, f"{m}_entropy_bottleneck")
+        assert np.array_equal(eb.quantized_cdf.numpy(), kat[f"{m}_eb_cdf"])
+        assert np.array_equal(eb.cdf_length.numpy(), kat[f"{m}_eb_sizes"])
+    assert net.update(force=False) is True  # bottlenecks always rebuild (entropy_models.py:320-325), as in the reference
+    # state_dict round trip keeps every reference key, including the table buffers
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(synth_sd.keys())
+    assert sd["rgb_gaussian_conditional._quantized_cdf"].shape == (64, 3133)
+    net2 = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4)
+    net2.load_state_dict(sd, strict=True)
+    assert np.array_equal(net2.rgb_gaussian_conditional.quantized_cdf.numpy(), kat["gc_cdf"])
+    assert sum(p.numel() for p in net2.parameters()) == 149532369
+
+
+def test_checkpoint_interface_errors(synth_sd):
+    import rgbd_amd
+    from rgbd_amd._lib import RgbdError
+
+    net = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4)
+    bad = dict(synth_sd)
+    bad.pop("g_a.rgb_analysis_transform.0.weight")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad, strict=True)
+    wrong = dict(synth_sd)
+    wrong["g_a.rgb_analysis_transform.0.weight"] = torch.zeros(192, 3, 3, 3)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(wrong)
+    with pytest.raises(RgbdError):
+        net.to("cpu")
+    fresh = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4)
+    with pytest.raises(ValueError, match="Run update"):
+        fresh.rgb_gaussian_conditional.check()
+    with pytest.raises(RgbdError):
+        fresh.compress(torch.zeros(1, 3, 64, 64), torch.zeros(1, 1, 64, 64))
+
+
+@pytest.mark.parametrize("name", ["a_128x192", "b_100x150", "d_256x256"])
+def test_container_bytes_and_bpp(name, tmp_path):
+    from rgbd_amd import ioutils
+
+    g = load_golden(name)
+    H, W = int(g["H"]), int(g["W"])
+    for k in ("r", "d"):
+        strings = [[g[f"{k}_y"].tobytes()], [g[f"{k}_z0"].tobytes()]]
+        fn = tmp_path / f"{name}_{k}.bin"
+        with open(fn, "wb") as f:
+            ioutils.write_uints(f, (H, W))
+            ioutils.write_body(f, tuple(g["shape"]), strings)
+        data = open(fn, "rb").read()
+        assert hashlib.sha256(data).hexdigest()[:16] == g[f"{k}_container_sha"].tobytes().decode()
+        assert data == eo.container_bytes(H, W, tuple(g["shape"]), strings)
+        assert ioutils.filesize(fn) * 8.0 / (H * W) == g["bpp"][0 if k == "r" else 1]
+        with open(fn, "rb") as f:
+            assert ioutils.read_uints(f, 2) == (H, W)
+            back, shape = ioutils.read_body(f)
+        assert back == strings and tuple(shape) == tuple(g["shape"])
+
+
+def test_pad_crop_like_reference():
+    from rgbd_amd import datautils
+
+    x = torch.arange(2 * 3 * 100 * 150, dtype=torch.float32).reshape(2, 3, 100, 150)
+    p = datautils.pad(x, "replicate0")
+    assert tuple(p.shape[-2:]) == tuple(load_golden("b_100x150")["padded"]) == (128, 192)
+    assert torch.equal(p, eo.pad_replicate0(x))
+    assert torch.equal(p[:, :, 100:, :150], x[:, :, 99:100, :].expand(-1, -1, 28, -1))
+    assert torch.equal(datautils.crop(p, "replicate0", (100, 150)), x)
+    assert datautils.pad(torch.zeros(1, 1, 128, 192), "replicate0").shape[-2:] == (128, 192)
+    c = datautils.pad(x, "reflect1")
+    assert torch.equal(datautils.crop(c, "reflect1", (100, 150)), x)
+
+
+def test_psnr_matches_reference_arithmetic():
+    from rgbd_amd import metrics
+
+    g = load_golden("a_128x192")
+    from rgbd_amd import synth
+
+    r, d = synth.synthetic_batch(1, 128, 192, config_id=9)
+    assert abs(metrics.psnr(torch.from_numpy(g["xhat_r"]), torch.from_numpy(r)) - g["psnr"][0]) < 1e-9
+    assert abs(metrics.psnr(torch.from_numpy(g["xhat_d"]), torch.from_numpy(d)) - g["psnr"][1]) < 1e-9
+    x = torch.rand(1, 3, 192, 192)
+    assert abs(metrics.ms_ssim(x, x) - 1.0) < 1e-6
+
+
+def test_synthetic_weights_are_reproducible():
+    from rgbd_amd import synth
+
+    a = synth.uniform_like("rgb", 9000, (4,), 0.0, 1.0)
+    assert a.dtype == np.float32 and np.allclose(a, synth.uniform_like("rgb", 9000, (4,), 0.0, 1.0))
+    w = synth.make_tensor("g_a.rgb_analysis_transform.0.weight", synth.elic_united_entries()["g_a.rgb_analysis_transform.0.weight"], 0)
+    assert hashlib.sha256(w.tobytes()).hexdigest()[:16] == hashlib.sha256(
+        synth.synthetic_state_dict.__globals__["make_tensor"]("g_a.rgb_analysis_transform.0.weight",
+                                                              synth.elic_united_entries()["g_a.rgb_analysis_transform.0.weight"], 0).tobytes()).hexdigest()[:16]
