@@ -124,6 +124,12 @@ def main():
     prof1 = solo.profile_read()
     solo.set_profile(False)
 
+    traffic = None
+    try:  # HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), see profiles/
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"]) if args.workload == "c2_8x256x256" else None
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0:
         px = world * B * H * W * args.steps
         bytes_y = sum(len(s) for o in out for s in o["r_strings"][0] + o["d_strings"][0])
@@ -147,7 +153,9 @@ def main():
                        "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (all conv/deconv layers)",
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per conv launch, rocprofv3 PMC passes committed under profiles/ "
+                                         "(not collectable from inside this process)",
                          "launches_per_step": prof["launches"] // max(args.steps, 1),
                          "avg_launch_us": round(prof["conv_ms"] * 1e3 / max(prof["launches"], 1), 2),
                          "conv_ms_per_step": round(prof["conv_ms"] / max(args.steps, 1), 3),
