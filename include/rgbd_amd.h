@@ -122,6 +122,13 @@ int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, in
  * made mutually exclusive so that they overlap the other instances' serial entropy-coding phases instead of each other. */
 int rgbd_elic_set_exclusive_transforms(rgbd_elic* m, int32_t on);
 
+/* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
+ * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
+int rgbd_debug_force_splitk(int32_t s);
+int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k, int32_t stride, int32_t pad,
+                    int32_t transposed, int32_t with_residual, int32_t iters, float* ms_out);
+int rgbd_elic_profile_dump(rgbd_elic* m, const char* path);
+
 /* Measurement hook (bench.py): when on, every convolution launch is bracketed by HIP events on the launch stream.
  * profile_read returns the summed kernel time (ms), the launch count and the algorithmic FLOPs (2*MACs, unpadded)
  * accumulated since set_profile(). */

@@ -61,8 +61,22 @@ struct ConvArgs {
     int mcs;
     const float* res2;  // added last
     int r2cs;
+    int splitk;      // >1: reduce the input channels in `splitk` fixed ranges (partials + ordered sum); 0/1 = off
+    float* partial;  // [splitk][N*OH*OW][cout_pad] scratch when splitk > 1
     TapTable taps;
 };
+
+// split factor of a layer: a function of the layer geometry only (never of batch or image size), so the summation
+// order of every output is fixed once and for all
+static inline int conv_splitk_for(int cin_pad, int taps_per_phase)
+{
+    const long K = (long)cin_pad * taps_per_phase;
+    int s = (int)((K + 800) / 1600);
+    if (s < 1) s = 1;
+    if (s > 8) s = 8;
+    if (s > cin_pad / 16) s = cin_pad / 16;
+    return s;
+}
 
 int launch_conv(const ConvArgs& a, hipStream_t s);
 

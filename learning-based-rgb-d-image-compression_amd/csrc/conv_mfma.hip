@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 
     const int TW = 1 << tw_log2;
     const int TH = TP >> tw_log2;
-    const int phase = blockIdx.z;
+    const int phase = blockIdx.z / a.splitk;
+    const int split = blockIdx.z - phase * a.splitk;
     const int co0 = blockIdx.y * TM;
     int bt = blockIdx.x;
     const int tile_x = bt % tiles_x;
@@ -82,9 +83,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     int brow0[NT];  // LDS float offset of this lane's pixel (tap (min_dy, min_dx)) for each column group
 #pragma unroll
     for (int j = 0; j < NT; ++j) brow0[j] = ((ppy[j] * a.IS) * PW + ppx[j] * a.IS) * RS + q * 4;
-    const int nchunks = (a.cin_pad + KC - 1) / KC;
+    // split-K: this workgroup reduces 16-channel chunks [c16_lo, c16_hi) only (the split is a fixed function of the
+    // layer, so every output keeps one well-defined summation order: chain per split, then splits in order)
+    const int n16 = a.cin_pad / 16;
+    const int per = (n16 + a.splitk - 1) / a.splitk;
+    const int c16_lo = split * per, c16_hi = min(n16, c16_lo + per);
+    const int ci_lo = c16_lo * 16, ci_hi = c16_hi * 16;
+    const int nchunks = (ci_hi - ci_lo + KC - 1) / KC;
     const int ngroups = (ntaps + taps_per_stage - 1) / taps_per_stage;
-    const int nstages = nchunks * ngroups;
+    const int nstages = nchunks > 0 ? nchunks * ngroups : 0;
 
     // Register staging.  A stage = one tap group of one channel chunk; the input patch is reloaded per chunk.
     // Everything that does not change from stage to stage is computed once here: per staging slot u the thread's
@@ -116,14 +123,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     }
     const int w_lds0 = (tid / C4) * RS + (tid % C4) * 4;  // slot u adds u * (256 / C4) * RS floats
     auto issue_w = [&](int stage) {
-        const int ci0 = (stage / ngroups) * KC;
+        const int ci0 = ci_lo + (stage / ngroups) * KC;
         const int t0 = (stage % ngroups) * taps_per_stage;
         const int tg = min(taps_per_stage, ntaps - t0);
 #pragma unroll
         for (int u = 0; u < WR; ++u) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c4x4 = ((tid + u * 256) % C4) * 4;
-            if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < a.cin_pad))
+            if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
                 v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + (int)a.taps.wt[phase][t0 + gw_j[u]] * a.cin_pad + ci0);
             pw[u] = v;
         }
@@ -137,12 +144,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 *reinterpret_cast<f32x4*>(wl + w_lds0 + u * (256 / C4) * RS) = pw[u];
     };
     auto issue_p = [&](int chunk) {
-        const int ci0 = chunk * KC;
+        const int ci0 = ci_lo + chunk * KC;
 #pragma unroll
         for (int u = 0; u < PR; ++u) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c4x4 = ((tid + u * 256) % C4) * 4;
-            if (gp_off[u] >= 0 && (KC == 16 || ci0 + c4x4 < a.cin_pad))
+            if (gp_off[u] >= 0 && (KC == 16 || ci0 + c4x4 < ci_hi))
                 v = *reinterpret_cast<const f32x4*>(a.x + gp_off[u] + ci0);
             pp[u] = v;
         }
@@ -201,22 +208,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         }
     }
 
-    // epilogue: lane holds couts cb..cb+3 of pixel (ppy,ppx) for each (i,k)
+    // Epilogue.  The MFMA result layout gives each lane 4 consecutive couts of one pixel (64-byte segments per pixel
+    // and store instruction); writing that straight to HBM wastes half of every 128-byte line transaction.  The tile is
+    // therefore staged through LDS as [pixel][cout] and written back by all 256 threads with consecutive lanes on
+    // consecutive couts of the same pixel (full lines for TM >= 32 couts), which is also how the fused
+    // residual / gate / skip operands are read.
+    constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;  // cout tiles per pass
+    constexpr int SW = 16 * WM * EMT + 4;                                                   // staging row stride (floats)
+    constexpr int S4 = 4 * WM * EMT;                                                        // float4 per staged pixel row
     const int oy_off = a.nphase > 1 ? (phase >> 1) : 0;
     const int ox_off = a.nphase > 1 ? (phase & 1) : 0;
+    for (int ip = 0; ip < MT; ip += EMT) {
+        __syncthreads();  // LDS is free: the last stage (or the previous pass) has been consumed
 #pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        const int gy = ty0 + ppy[k], gx = tx0 + ppx[k];
-        if (gy >= a.GH || gx >= a.GW) continue;
-        const int oy = gy * a.OS + oy_off, ox = gx * a.OS + ox_off;
-        const size_t pix = ((size_t)n * a.OH + oy) * a.OW + ox;
+        for (int k = 0; k < NT; ++k) {
+            const int p = (wn * NT + k) * 16 + l15;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int cb = co0 + (wm * MT + i) * 16 + q * 4;
-            if (cb >= a.cout_pad) continue;
-            f32x4 v = acc[i][k];
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + cb);
-            v += b;
+            for (int i = 0; i < MT; ++i)
+                if (i >= ip && i < ip + EMT)
+                    *reinterpret_cast<f32x4*>(smem + p * SW + (wm * EMT + (i - ip)) * 16 + q * 4) = acc[i][k];
+        }
+        __syncthreads();
+        for (int f = tid; f < TP * S4; f += 256) {
+            const int p = f / S4, c4 = f - p * S4;
+            const int wmc = c4 / (4 * EMT), ii = (c4 / 4) % EMT;
+            if (ip + ii >= MT) continue;
+            const int cb = co0 + (wmc * MT + ip + ii) * 16 + (c4 & 3) * 4;
+            const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+            if (cb >= a.cout_pad || gy >= a.GH || gx >= a.GW) continue;
+            const size_t pix = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
+            if (a.splitk > 1) {  // raw partial sums; bias / activation / fused operands are applied by the reducer
+                *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + pix) * a.cout_pad + cb) = v;
+                continue;
+            }
+            v += *reinterpret_cast<const f32x4*>(a.bias + cb);
             if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb);
             if (a.act == ACT_RELU) {
 #pragma unroll
@@ -258,7 +284,10 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     if (room < 1) return RGBD_ENOSPC;
     const int tps = (int)(room < max_taps ? room : max_taps);
     if (KC > 16 && tps < max_taps) return RGBD_ENOSPC;  // would break the canonical accumulation order
-    const size_t lds = patch_bytes + (size_t)tps * tap_bytes;
+    constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;
+    const size_t epi_bytes = (size_t)TP * (16 * WM * EMT + 4) * sizeof(float);
+    const size_t stage_bytes = patch_bytes + (size_t)tps * tap_bytes;
+    const size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, PF>;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
@@ -266,7 +295,8 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
                                     (int)(160 * 1024)));
         configured = 160 * 1024;
     }
-    dim3 grid((unsigned)(tiles_x * tiles_y * a.N), (unsigned)((a.cout_pad + TM - 1) / TM), (unsigned)a.nphase);
+    dim3 grid((unsigned)(tiles_x * tiles_y * a.N), (unsigned)((a.cout_pad + TM - 1) / TM),
+              (unsigned)(a.nphase * a.splitk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
@@ -305,7 +335,7 @@ Choice choose(const ConvArgs& a)
                                   {2, 1, 1}, {1, 3, 2}, {1, 2, 2}, {1, 1, 2}, {1, 3, 1}, {1, 2, 1}, {1, 1, 1}};
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
-    const double K = (double)max_taps * a.cin_pad;
+    const double K = (double)max_taps * a.cin_pad / a.splitk;
     Choice best{2, 4, 4, 16, 4, false};
     double best_cost = -1.0;
     long best_blocks = 0;
@@ -315,7 +345,7 @@ Choice choose(const ConvArgs& a)
         const int twl = pick_tw_log2(a.GW, a.GH, tp);
         const int TW = 1 << twl, TH = tp / TW;
         const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
-        const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase;
+        const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase * a.splitk;
         const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
         const int pr = tp >= 128 ? 12 : (tp >= 64 ? 6 : 4);
         if ((long)PH * PW * 4 > pr * 256 || (long)tm * 4 > 8 * 256) continue;  // register-staging limits (KC=16)
@@ -359,7 +389,53 @@ Choice choose(const ConvArgs& a)
 
 }  // namespace
 
-int launch_conv(const ConvArgs& a, hipStream_t s)
+// out = epilogue(P[0] + P[1] + ... in order): the second half of a split-K convolution
+__global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
+{
+    const int c4n = a.cout_pad / 4;
+    const size_t plane = (size_t)a.N * a.OH * a.OW * a.cout_pad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / c4n;
+        const int cb = (int)(i - pix * c4n) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.partial + pix * a.cout_pad + cb);
+        for (int s = 1; s < a.splitk; ++s) v += *reinterpret_cast<const f32x4*>(a.partial + s * plane + pix * a.cout_pad + cb);
+        v += *reinterpret_cast<const f32x4*>(a.bias + cb);
+        if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb);
+        if (a.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (a.act == ACT_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
+        } else if (a.act == ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        }
+        if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb);
+        if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb);
+        *reinterpret_cast<f32x4*>(a.y + pix * a.ycs + cb) = v;
+    }
+}
+
+static int launch_conv_main(const ConvArgs& a, hipStream_t s);
+
+int launch_conv(const ConvArgs& a_in, hipStream_t s)
+{
+    ConvArgs a = a_in;
+    if (a.splitk < 1) a.splitk = 1;
+    if (a.splitk > a.cin_pad / 16) a.splitk = a.cin_pad / 16;
+    if (a.splitk > 1 && !a.partial) return RGBD_EINVAL;
+    const int rc = launch_conv_main(a, s);
+    if (rc || a.splitk == 1) return rc;
+    const size_t total4 = (size_t)a.N * a.OH * a.OW * (a.cout_pad / 4);
+    size_t g = (total4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, total4);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+static int launch_conv_main(const ConvArgs& a, hipStream_t s)
 {
     if (a.cin_pad % 16 || a.cout_pad % 16 || a.xcs % 4 || a.ycs % 4) return RGBD_EINVAL;
     if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;

@@ -187,6 +187,7 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
 // lock in turn, so one instance's transforms overlap the OTHER instances' serial entropy-coding phases instead of
 // each other.
 std::mutex g_transform_phase;
+int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 
 // ------------------------------------------------------------------------------------------------
 // the model
@@ -319,7 +320,13 @@ struct rgbd_elic {
             fail(RGBD_EINVAL);
             return y;
         }
-        if (dry() || rc) return y;
+        if (dry()) {  // account for the split-K scratch of this layer (upper bound: 8 partial planes)
+            const size_t m0 = arena.top;
+            (void)arena.take((size_t)8 * x.n * OH * OW * pc->cout_pad * sizeof(float));
+            arena.top = m0;
+            return y;
+        }
+        if (rc) return y;
         ConvArgs a{};
         a.x = x.p;
         a.N = x.n;
@@ -351,6 +358,20 @@ struct rgbd_elic {
             a.res2 = ep.res2->p;
             a.r2cs = ep.res2->cs;
         }
+        // weight-heavy layers on the small latent grid (entropy model, hyper synthesis): split the reduction
+        static const char* const kSplitPrefixes[] = {"rgb_entropy_parameters", "depth_entropy_parameters",
+                                                     "rgb_channel_context", "depth_channel_context", "rgb_local_context",
+                                                     "depth_local_context", "h_s."};
+        a.splitk = 1;
+        for (const char* pre : kSplitPrefixes)
+            if (name.rfind(pre, 0) == 0) {
+                int mt = 1;
+                for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
+                a.splitk = g_force_splitk > 0 ? g_force_splitk : conv_splitk_for(a.cin_pad, mt);
+                break;
+            }
+        const size_t pmark = arena.top;
+        if (a.splitk > 1) a.partial = (float*)arena.take((size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) {
             if (ev_used + 2 > ev_pool.size()) {
@@ -376,6 +397,7 @@ struct rgbd_elic {
             ++prof_launches;
             ev_names.emplace_back(name, fl);
         }
+        arena.top = pmark;  // stream order protects the scratch: later kernels of this stream run after the reducer
         if (r) {
             fprintf(stderr, "[rgbd_amd] conv launch failed at %s (%d)\n", name.c_str(), r);
             fail(r);
@@ -1349,7 +1371,17 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
             a.res1 = res;
             a.r1cs = pc.cout_pad;
         }
+        float* part = nullptr;
+        a.splitk = g_force_splitk > 0 ? std::min(g_force_splitk, pc.cin_pad / 16) : 1;
+        if (a.splitk > 1) {
+            HIP_TRY(hipMalloc((void**)&part, (size_t)a.splitk * yb));
+            a.partial = part;
+        }
         rc = launch_conv(a, s);
+        if (part) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(part);
+        }
     }
     if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, cout, OH, OW, pc.cout_pad, y_dev, 0, s);
     hipError_t e = hipStreamSynchronize(s);
@@ -1360,6 +1392,12 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
     (void)hipFree(pc.w);
     (void)hipFree(pc.bias);
     return rc;
+}
+
+int rgbd_debug_force_splitk(int32_t s)
+{
+    g_force_splitk = s;
+    return RGBD_OK;
 }
 
 // Kernel-only timing of one conv shape on NHWC buffers (tools/conv_sweep.py); not part of the codec path.
@@ -1413,6 +1451,17 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
         a.res1 = r;
         a.r1cs = pc.cout_pad;
     }
+    float* part = nullptr;
+    {
+        int mt = 1;
+        for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
+        a.splitk = g_force_splitk > 0 ? std::min(g_force_splitk, pc.cin_pad / 16)
+                                      : (g_force_splitk < 0 ? conv_splitk_for(pc.cin_pad, mt) : 1);
+        if (a.splitk > 1) {
+            HIP_TRY(hipMalloc((void**)&part, (size_t)a.splitk * yb));
+            a.partial = part;
+        }
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -1430,6 +1479,7 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
     (void)hipFree(x);
     (void)hipFree(y);
     (void)hipFree(r);
+    (void)hipFree(part);
     (void)hipFree(pc.w);
     (void)hipFree(pc.bias);
     return rc;

@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native library is a build artefact (git-ignored): make sure it exists before any test imports it
+    try:
+        import rgbd_amd  # noqa: F401
+        from rgbd_amd import _lib
+
+        if not os.path.exists(_lib._SO) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            _lib.build()
+    except Exception as e:  # tests that need the library will report the real error
+        print(f"[conftest] could not build librgbd_amd.so: {e}")
 
 
 @pytest.fixture(scope="session")

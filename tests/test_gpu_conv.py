@@ -90,3 +90,33 @@ def test_conv_deterministic_and_batch_invariant():
     full = run(x)
     assert torch.equal(full, run(x))
     assert torch.equal(full[1:2], run(x[1:2]))  # same bits whatever the batch the image rides in
+
+
+@pytest.mark.parametrize("split", [2, 3, 8])
+def test_split_k_matches_and_is_deterministic(split):
+    """Split-K (used for the weight-heavy entropy-model layers): partial chains summed in a fixed order."""
+    dev = require_gpu()
+    from rgbd_amd._lib import check, lib
+
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 224, 16, 16, generator=g)
+    wt = (torch.randn(128, 224, 5, 5, generator=g) / 75).contiguous()
+    b = torch.randn(128, generator=g)
+    ref = torch.relu(F.conv2d(x, wt, b, padding=2))
+    f32p = ctypes.POINTER(ctypes.c_float)
+
+    def run(xx):
+        xd = xx.to(dev).contiguous()
+        yd = torch.empty((xx.shape[0], 128, 16, 16), device=dev)
+        check(lib().rgbd_conv2d_nchw(ctypes.c_void_p(xd.data_ptr()), xx.shape[0], 224, 16, 16, wt.numpy().ctypes.data_as(f32p),
+                                     b.numpy().ctypes.data_as(f32p), 128, 5, 1, 2, 0, 1, None, ctypes.c_void_p(yd.data_ptr()),
+                                     None), "conv2d")
+        return yd.cpu()
+
+    lib().rgbd_debug_force_splitk(split)
+    try:
+        got = run(x)
+        assert (got - ref).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1e-3)
+        assert torch.equal(got, run(x)) and torch.equal(got[1:2], run(x[1:2]))
+    finally:
+        lib().rgbd_debug_force_splitk(0)

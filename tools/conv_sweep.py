@@ -12,6 +12,7 @@ L = ctypes.CDLL(_SO)
 L.rgbd_conv_bench.restype = ctypes.c_int
 L.rgbd_conv_bench.argtypes = [ctypes.c_int32] * 11 + [ctypes.POINTER(ctypes.c_float)]
 B, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (8, 256, 256)
+SPLIT = int(os.environ.get("SWEEP_SPLITK", "0"))  # -1: the codec's automatic split for entropy-model layers
 h2, w2, h4, w4, h8, w8, h16, w16 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
 # name, cin, h, w, cout, k, stride, pad, transposed, residual, count per enc+dec
 S = [
@@ -37,6 +38,7 @@ S = [
 tot_ms = tot_gf = 0.0
 for name, cin, h, w, cout, k, s, p, tr, res, cnt in S:
     ms = ctypes.c_float(0)
+    L.rgbd_debug_force_splitk(SPLIT if name.split()[0] in ("ep", "chctx", "locctx", "hs") else 0)
     rc = L.rgbd_conv_bench(B, cin, h, w, cout, k, s, p, tr, res, 5, ctypes.byref(ms))
     if rc:
         print(name, "failed", rc)
