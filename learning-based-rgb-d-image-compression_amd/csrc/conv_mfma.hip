@@ -160,6 +160,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             if (tid + u * 256 < npatch4) *reinterpret_cast<f32x4*>(patch + w_lds0 + u * (256 / C4) * RS) = pp[u];
     };
 
+    // epilogue geometry (see below); with PF and a short tile the fused operands are requested up front as well, so a
+    // short-K (1x1) workgroup exposes one memory round trip instead of four
+    constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;  // cout tiles per pass
+    constexpr int SW = 16 * WM * EMT + 4;                                                   // staging row stride (floats)
+    constexpr int S4 = 4 * WM * EMT;                                                        // float4 per staged pixel row
+    constexpr int EU = TP * S4 / 256;
+    constexpr bool AUXPF = PF && EMT == MT && EU <= 8;
+    const int oy_off = a.nphase > 1 ? (phase >> 1) : 0;
+    const int ox_off = a.nphase > 1 ? (phase & 1) : 0;
+    f32x4 aux1[AUXPF ? EU : 1], aux2[AUXPF ? EU : 1], aux3[AUXPF ? EU : 1];
+    if (AUXPF && a.splitk == 1) {
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int f = tid + u * 256;
+            const int p = f / S4, c4 = f - p * S4;
+            const int cb = co0 + ((c4 / (4 * EMT)) * MT + (c4 / 4) % EMT) * 16 + (c4 & 3) * 4;
+            const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+            const bool okk = cb < a.cout_pad && gy < a.GH && gx < a.GW;
+            const size_t pix = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            aux1[u] = (okk && a.res1) ? *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb) : z;
+            aux2[u] = (okk && a.mul) ? *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb) : z;
+            aux3[u] = (okk && a.res2) ? *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb) : z;
+        }
+    }
     if (PF) {
         issue_p(0);
         issue_w(0);
@@ -185,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         // canonical accumulation order: 16-channel chunk -> tap -> channel.  A 64-channel stage therefore walks its
         // four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so the
         // fma chain of each output is the same for every KC / tile choice.
-#pragma unroll
-        for (int kk = 0; kk < KC / 16; ++kk) {
+        const int nkk = min(KC / 16, (ci_hi - ci_lo - (stage / ngroups) * KC) / 16);  // no MFMAs on the zero tail
+        for (int kk = 0; kk < nkk; ++kk) {
             for (int j = 0; j < tg; ++j) {
                 const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
                 const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
@@ -213,11 +238,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     // therefore staged through LDS as [pixel][cout] and written back by all 256 threads with consecutive lanes on
     // consecutive couts of the same pixel (full lines for TM >= 32 couts), which is also how the fused
     // residual / gate / skip operands are read.
-    constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;  // cout tiles per pass
-    constexpr int SW = 16 * WM * EMT + 4;                                                   // staging row stride (floats)
-    constexpr int S4 = 4 * WM * EMT;                                                        // float4 per staged pixel row
-    const int oy_off = a.nphase > 1 ? (phase >> 1) : 0;
-    const int ox_off = a.nphase > 1 ? (phase & 1) : 0;
     for (int ip = 0; ip < MT; ip += EMT) {
         __syncthreads();  // LDS is free: the last stage (or the previous pass) has been consumed
 #pragma unroll
@@ -229,34 +249,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                     *reinterpret_cast<f32x4*>(smem + p * SW + (wm * EMT + (i - ip)) * 16 + q * 4) = acc[i][k];
         }
         __syncthreads();
-        for (int f = tid; f < TP * S4; f += 256) {
-            const int p = f / S4, c4 = f - p * S4;
-            const int wmc = c4 / (4 * EMT), ii = (c4 / 4) % EMT;
-            if (ip + ii >= MT) continue;
-            const int cb = co0 + (wmc * MT + ip + ii) * 16 + (c4 & 3) * 4;
-            const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
-            if (cb >= a.cout_pad || gy >= a.GH || gx >= a.GW) continue;
-            const size_t pix = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
-            f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
-            if (a.splitk > 1) {  // raw partial sums; bias / activation / fused operands are applied by the reducer
-                *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + pix) * a.cout_pad + cb) = v;
-                continue;
+        // EU elements (float4) per thread, handled UB at a time: the fused operands of a batch are all requested before
+        // the first one is used, so the epilogue costs EU/UB memory round trips instead of EU
+        constexpr int UB = EU % 6 == 0 ? 6 : (EU % 4 == 0 ? 4 : (EU % 3 == 0 ? 3 : (EU % 2 == 0 ? 2 : 1)));
+        static_assert(TP * S4 % 256 == 0, "epilogue tiling");
+        for (int u0 = 0; u0 < EU; u0 += UB) {
+            f32x4 r1[UB], ml[UB], r2[UB], v[UB];
+            size_t pixs[UB];
+            int cbs[UB];
+            bool ok[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int f = tid + (u0 + u) * 256;
+                const int p = f / S4, c4 = f - p * S4;
+                const int wmc = c4 / (4 * EMT), ii = (c4 / 4) % EMT;
+                const int cb = co0 + (wmc * MT + ip + ii) * 16 + (c4 & 3) * 4;
+                const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+                ok[u] = ip + ii < MT && cb < a.cout_pad && gy < a.GH && gx < a.GW;
+                cbs[u] = cb;
+                pixs[u] = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
+                v[u] = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (AUXPF) {
+                    r1[u] = aux1[AUXPF ? u0 + u : 0];
+                    ml[u] = aux2[AUXPF ? u0 + u : 0];
+                    r2[u] = aux3[AUXPF ? u0 + u : 0];
+                } else {
+                    r1[u] = (ok[u] && a.res1) ? *reinterpret_cast<const f32x4*>(a.res1 + pixs[u] * a.r1cs + cb) : z;
+                    ml[u] = (ok[u] && a.mul) ? *reinterpret_cast<const f32x4*>(a.mul + pixs[u] * a.mcs + cb) : z;
+                    r2[u] = (ok[u] && a.res2) ? *reinterpret_cast<const f32x4*>(a.res2 + pixs[u] * a.r2cs + cb) : z;
+                }
             }
-            v += *reinterpret_cast<const f32x4*>(a.bias + cb);
-            if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb);
-            if (a.act == ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (a.act == ACT_LEAKY) {
+            for (int u = 0; u < UB; ++u) {
+                if (!ok[u]) continue;
+                const int cb = cbs[u];
+                f32x4 w = v[u];
+                if (a.splitk > 1) {  // raw partial sums; bias / activation / fused operands are applied by the reducer
+                    *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + pixs[u]) * a.cout_pad + cb) = w;
+                    continue;
+                }
+                w += *reinterpret_cast<const f32x4*>(a.bias + cb);
+                if (a.res1) w += r1[u];
+                if (a.act == ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
-            } else if (a.act == ACT_SIGMOID) {
+                    for (int e = 0; e < 4; ++e) w[e] = fmaxf(w[e], 0.f);
+                } else if (a.act == ACT_LEAKY) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+                    for (int e = 0; e < 4; ++e) w[e] = w[e] > 0.f ? w[e] : w[e] * 0.01f;
+                } else if (a.act == ACT_SIGMOID) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = 1.0f / (1.0f + expf(-w[e]));
+                }
+                if (a.mul) w *= ml[u];
+                if (a.res2) w += r2[u];
+                *reinterpret_cast<f32x4*>(a.y + pixs[u] * a.ycs + cb) = w;
             }
-            if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb);
-            if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb);
-            *reinterpret_cast<f32x4*>(a.y + pix * a.ycs + cb) = v;
         }
     }
 }
@@ -339,9 +387,13 @@ Choice choose(const ConvArgs& a)
     Choice best{2, 4, 4, 16, 4, false};
     double best_cost = -1.0;
     long best_blocks = 0;
+    // short reductions (1x1 convs): the workgroup is a handful of memory round trips around very little matrix work, so
+    // use the fully prefetched variant, whose register budget needs the 64-pixel tiles
+    const bool short_k = K <= 512 && a.splitk == 1;
     for (const auto& c : cand) {
         const int wm = c[0], mt = c[1], nt = c[2];
         const int tm = 16 * mt * wm, tp = 16 * nt * (wm == 2 ? 2 : 4);
+        (void)short_k;
         const int twl = pick_tw_log2(a.GW, a.GH, tp);
         const int TW = 1 << twl, TH = tp / TW;
         const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
@@ -440,7 +492,18 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     if (a.cin_pad % 16 || a.cout_pad % 16 || a.xcs % 4 || a.ycs % 4) return RGBD_EINVAL;
     if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;
     if (a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
-    const Choice c = choose(a);
+    Choice c = choose(a);
+    static const char* force = getenv("RGBD_CONV_FORCE");  // "wm,mt,nt[,kc[,pf]]" -- tuning experiments only
+    if (force) {
+        int wm = c.wm, mt = c.mt, nt = c.nt, kc = c.kc, pf = c.pf;
+        sscanf(force, "%d,%d,%d,%d,%d", &wm, &mt, &nt, &kc, &pf);
+        c.wm = wm;
+        c.mt = mt;
+        c.nt = nt;
+        c.kc = kc;
+        c.pf = pf != 0;
+        c.tw_log2 = pick_tw_log2(a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
+    }
     static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;
     if (debug)
         fprintf(stderr, "[conv] N=%d GH=%d GW=%d cin=%d cout=%d taps=%d IS=%d nph=%d -> WM=%d MT=%d NT=%d KC=%d tw=%d pf=%d\n", a.N,
