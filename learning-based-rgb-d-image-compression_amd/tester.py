@@ -18,6 +18,22 @@ from .ioutils import filesize, read_body, read_uints, write_body, write_uints
 from .metrics import AverageMeter, compute_metrics
 
 
+def save_image(x, path):
+    """utils/IOutils.py:101-104 (ToPILImage of the clamped tensor): uint8 PNG, value*255 truncated like torchvision's
+    `pic.mul(255).byte()`."""
+    from PIL import Image
+
+    a = x.detach().clamp(0, 1).squeeze(0).mul(255).byte().cpu().numpy()
+    Image.fromarray(a[0] if a.shape[0] == 1 else a.transpose(1, 2, 0)).save(path)
+
+
+def save_depth16(x, path, scale):
+    """tester_united.py:101-109: depth * 10000 (NYUv2) or * 100000 (SUN RGB-D) as a 16-bit PNG."""
+    from PIL import Image
+
+    Image.fromarray((x.detach() * scale).cpu().squeeze().numpy().astype("uint16")).save(path)
+
+
 def load_image(path, mode):
     """dataset/testDataset.py:36-61: RGB/255; depth scaled by 10000 / 100000 / 255 depending on its range."""
     from PIL import Image
@@ -150,6 +166,11 @@ class TesterUnited:
             xr, xd, dt = self.decompress_one_image_united(paths, rgb_name[0], mode=padding_mode)
             rp, rm = compute_metrics(xr, rgb)
             dp, dm = compute_metrics(xd, depth)
+            if getattr(self, "save_reconstructions", True):  # tester_united.py:98-109
+                save_image(xr, os.path.join(rec_dir, "rgb_rec", f"{rgb_name[0]}_{rb:.4f}_{rp:.4f}__rec.png"))
+                save_image(xd, os.path.join(rec_dir, "depth_rec", f"{rgb_name[0]}_{db:.4f}_{dp:.4f}__rec_8bit.png"))
+                save_depth16(xd, os.path.join(rec_dir, "depth_rec", f"{rgb_name[0]}_{db:.4f}_{dp:.4f}__rec_16bit.png"),
+                             100000 if rec_dir.find("sun") != -1 else 10000)
             for k, v in zip(names, (rp, rm, rb, dp, dm, db, dt, et)):
                 meters[k].update(v)
             self.logger_test.info(

@@ -61,6 +61,11 @@ def test_tester_united_on_files(net, tmp_path, monkeypatch):
     assert torch.equal(xr, rec["x_hat"]["r"][:, :, :100, :150]) and torch.equal(xd, rec["x_hat"]["d"][:, :, :100, :150])
     assert abs(eo.psnr(xr.cpu(), rgb) - rows[0]["rgb_psnr"]) < 1e-9
     assert abs(meters["avg_rgb_bpp"].avg - np.mean([r["rgb_bpp"] for r in rows])) < 1e-12
+    # reconstructions are written like the reference does (8-bit PNGs + 16-bit depth)
+    recs = sorted(os.listdir(os.path.join(rec_dir, "depth_rec")))
+    assert len(recs) == 4 and len(os.listdir(os.path.join(rec_dir, "rgb_rec"))) == 2
+    d16 = np.array(Image.open(os.path.join(rec_dir, "depth_rec", [f for f in recs if f.endswith("16bit.png")][0])))
+    assert d16.dtype == np.uint16 and d16.shape == (100, 150)
 
 
 def test_pool_matches_single_instance(net, synth_sd):
