@@ -112,6 +112,16 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
                          const int64_t* z_rgb_len, const uint8_t* const* z_depth, const int64_t* z_depth_len, int32_t B,
                          int32_t zh, int32_t zw, float* xr_dev, float* xd_dev, void* stream);
 
+/*
+ * Eval-mode forward(): replaces ELIC_united.forward / entropy_estimate_united / codeOnePart (models/elic_united.py:94-263)
+ * and the likelihood halves of EntropyBottleneck.forward / GaussianConditional.forward (entropy_models.py:391-428,
+ * 534-558).  x_hat is NOT clamped (as in the reference); likelihoods are lower-bounded at 1e-9.
+ * Outputs (device, NCHW fp32): xr [B,3,H,W], xd [B,1,H,W], lik_y_* [B,M,H/16,W/16], lik_z_* [B,N,H/64,W/64].
+ */
+int rgbd_elic_forward(rgbd_elic* m, const float* rgb_dev, const float* depth_dev, int32_t B, int32_t H, int32_t W,
+                      float* xr_dev, float* xd_dev, float* lik_y_rgb, float* lik_y_depth, float* lik_z_rgb,
+                      float* lik_z_depth, void* stream);
+
 /* Intermediate of the last compress()/decompress() as NCHW fp32 on the host (parity tests).  Names: y_r y_d z_r z_d
  * zhat_r zhat_d hyper_r hyper_d yhat_r yhat_d.  shape_out receives 4 ints; data may be NULL to query the shape. */
 int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t cap_floats, int32_t* shape_out);

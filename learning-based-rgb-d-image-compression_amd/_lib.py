@@ -71,6 +71,7 @@ def lib():
         "rgbd_elic_set_scale_table": (ctypes.c_int, [c_vp, f32p, c_i32]),
         "rgbd_elic_finalize": (ctypes.c_int, [c_vp]),
         "rgbd_elic_compress": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+        "rgbd_elic_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
         "rgbd_elic_stream_count": (ctypes.c_int, [c_vp, c_i32, c_i32]),
         "rgbd_elic_stream": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, ctypes.POINTER(u8p), i64p]),
         "rgbd_elic_decompress": (ctypes.c_int, [c_vp, u8pp, i64p, c_i32, u8pp, i64p, u8pp, i64p, u8pp, i64p, c_i32,
@@ -97,7 +98,7 @@ EXPORTS = ["rgbd_abi_version", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create"
            "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
            "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
-           "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_stream_count", "rgbd_elic_stream",
+           "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_profile",
            "rgbd_elic_profile_read", "rgbd_elic_set_exclusive_transforms", "rgbd_debug_force_splitk", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]

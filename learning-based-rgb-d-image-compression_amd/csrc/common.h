@@ -122,6 +122,10 @@ int launch_ckbd_index_part(const float* params, int pcs, const float* table, Par
                            const int64_t* stream_base, int64_t part_off_per_image, hipStream_t s);
 int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs, PartGeom g, const int32_t* sym,
                             const int64_t* stream_base, int64_t part_off_per_image, hipStream_t s);
+int launch_ckbd_estimate_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs, float* lik,
+                              int lcs, PartGeom g, hipStream_t s);
+int launch_eb_forward(const float* z, int zcs, int B, int h, int w, int C, const float* med, const float* prm, float* zhat,
+                      float* lik, hipStream_t s);
 int launch_z_quant(const float* z, int zcs, int B, int h, int w, int C, const float* medians, int32_t* sym,
                    int32_t* idx, hipStream_t s);
 int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float* medians, float* zhat, int zcs,

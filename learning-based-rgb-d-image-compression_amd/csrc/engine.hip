@@ -740,6 +740,8 @@ struct rgbd_elic {
     // ---- Bi-CEE loop (elic_united.py:265-348 / 454-541) -----------------------------------------
     struct Coding {
         bool encode = true;
+        bool estimate = false;      // eval-mode forward(): quantise + likelihood, no symbols
+        Act lik[2];                 // likelihood tensors [B,h,w,M] per modality (estimate mode)
         int per_image = 1;
         int64_t per_image_total = 0;  // symbols per image per modality
         int32_t* sym = nullptr;       // [2][B*per_image_total]
@@ -770,7 +772,11 @@ struct rgbd_elic {
         int32_t* idx = cd.idx + mod_off;
         const int64_t* sb = cd.stream_base;  // relative to the modality's region
         int r;
-        if (cd.encode) {
+        if (cd.estimate) {
+            const Act lk = view(cd.lik[mod], (int)(yhat_slice.p - (mod ? yhat_base[1] : yhat_base[0])), g.C);
+            r = launch_ckbd_estimate_part(y_slice.p, y_slice.cs, params.p, params.cs, yhat_slice.p, yhat_slice.cs, lk.p, lk.cs,
+                                          g, s);
+        } else if (cd.encode) {
             r = launch_ckbd_encode_part(y_slice.p, y_slice.cs, params.p, params.cs, yhat_slice.p, yhat_slice.cs,
                                         scale_table, g, sym, idx, sb, part_off, s);
         } else {
@@ -788,9 +794,13 @@ struct rgbd_elic {
         if (r) fail(r);
     }
 
+    float* yhat_base[2] = {nullptr, nullptr};
+
     void bicee(Coding& cd, const Act* y_r, const Act* y_d, const Act& hyp_r, const Act& hyp_d, const Act& yhat_r,
                const Act& yhat_d)
     {
+        yhat_base[0] = yhat_r.p;
+        yhat_base[1] = yhat_d.p;
         int c0 = 0;
         int64_t part_off = 0;
         const int B = hyp_r.n, h = hyp_r.h, w = hyp_r.w;
@@ -835,6 +845,8 @@ struct rgbd_elic {
     }
 
     int run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image);
+    int run_forward(const float* rgb_dev, const float* depth_dev, int B, int H, int W, float* xr_dev, float* xd_dev,
+                    float* ly_r, float* ly_d, float* lz_r, float* lz_d);
     int run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
                        const int64_t* zlen[2], int B, int zh, int zw, float* xr_dev, float* xd_dev);
     int ensure_arena(size_t bytes);
@@ -1000,6 +1012,73 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     }
     HIP_TRY(hipStreamSynchronize(s));
     return RGBD_OK;
+}
+
+// eval-mode forward(): models/elic_united.py:234-263 with quant == "ste" (round in eval), likelihoods as in
+// entropy_models.py:391-428 (factorised prior) and :534-558 (Gaussian conditional)
+int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, int H, int W, float* xr_dev, float* xd_dev,
+                           float* ly_r, float* ly_d, float* lz_r, float* lz_d)
+{
+    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    named.clear();
+    arena.top = 0;
+    rc = 0;
+    Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
+    if (!dry()) {
+        int r = launch_nchw_to_nhwc16(rgb_dev, B, 3, H, W, rgb.p, rgb.cs, s);
+        if (!r) r = launch_nchw_to_nhwc16(depth_dev, B, 1, H, W, depth.p, depth.cs, s);
+        if (r) return r;
+    }
+    Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
+    Act z_r, z_d;
+    {
+        const size_t mark = arena.top;
+        Act yr_t, yd_t;
+        g_a(rgb, depth, &yr_t, &yd_t);
+        copy_ch(yr_t, y_r);
+        copy_ch(yd_t, y_d);
+        arena.top = mark;
+    }
+    h_a(y_r, y_d, &z_r, &z_d);
+    Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+    Act zl_r = alloc(B, zh, zw, N), zl_d = alloc(B, zh, zw, N);
+    if (!dry() && !rc) {
+        const Act* zz[2] = {&z_r, &z_d};
+        const Act* zo[2] = {&zh_r, &zh_d};
+        const Act* zl[2] = {&zl_r, &zl_d};
+        const char* mods[2] = {"rgb", "depth"};
+        for (int m = 0; m < 2 && !rc; ++m) {
+            float* md = dense_of(std::string(mods[m]) + "_entropy_bottleneck.medians");
+            float* prm = dense_of(std::string(mods[m]) + "_entropy_bottleneck.cumulative");
+            if (!md || !prm) break;
+            const int r = launch_eb_forward(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, prm, zo[m]->p, zl[m]->p, s);
+            if (r) fail(r);
+        }
+    }
+    Act hyp_r, hyp_d;
+    h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+    Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+    Coding cd;
+    cd.estimate = true;
+    cd.lik[0] = alloc(B, h, w, M);
+    cd.lik[1] = alloc(B, h, w, M);
+    bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+    named["y_r"] = y_r;
+    named["y_d"] = y_d;
+    named["yhat_r"] = yhat_r;
+    named["yhat_d"] = yhat_d;
+    Act xr, xd;
+    g_s(yhat_r, yhat_d, &xr, &xd);
+    if (rc) return rc;
+    if (dry()) return RGBD_OK;
+    int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(cd.lik[0].p, B, M, h, w, cd.lik[0].cs, ly_r, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(cd.lik[1].p, B, M, h, w, cd.lik[1].cs, ly_d, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(zl_r.p, B, N, zh, zw, zl_r.cs, lz_r, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(zl_d.p, B, N, zh, zw, zl_d.cs, lz_d, 0, s);
+    if (!r) HIP_TRY(hipStreamSynchronize(s));
+    return r;
 }
 
 int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
@@ -1602,6 +1681,39 @@ int rgbd_elic_finalize(rgbd_elic* m)
             HIP_TRY(hipMalloc((void**)&d, C * sizeof(float)));
             HIP_TRY(hipMemcpy(d, med.data(), C * sizeof(float), hipMemcpyHostToDevice));
             m->dense[name.substr(0, name.size() - 9) + "medians"] = d;
+            // softplus(matrix_i) / bias_i / tanh(factor_i) per channel for the eval-mode likelihood (58 floats/channel)
+            const std::string pre = name.substr(0, name.size() - 9);
+            std::vector<float> prm((size_t)C * 58, 0.f);
+            const int fi[6] = {1, 3, 3, 3, 3, 1};
+            bool ok = true;
+            size_t off = 0;
+            for (int i = 0; i < 5 && ok; ++i) {
+                auto mi = m->raw.find(pre + "_matrix" + std::to_string(i));
+                auto bi = m->raw.find(pre + "_bias" + std::to_string(i));
+                auto fa = i < 4 ? m->raw.find(pre + "_factor" + std::to_string(i)) : m->raw.end();
+                if (mi == m->raw.end() || bi == m->raw.end() || (i < 4 && fa == m->raw.end())) {
+                    ok = false;
+                    break;
+                }
+                const int no = fi[i + 1], ni = fi[i];
+                for (int c = 0; c < C; ++c) {
+                    float* p = prm.data() + (size_t)c * 58 + off;
+                    for (int k = 0; k < no * ni; ++k) {
+                        const float v = mi->second.v[(size_t)c * no * ni + k];
+                        p[k] = v > 20.f ? v : std::log1p(std::exp(v));  // F.softplus (threshold 20)
+                    }
+                    for (int k = 0; k < no; ++k) p[no * ni + k] = bi->second.v[(size_t)c * no + k];
+                    if (i < 4)
+                        for (int k = 0; k < no; ++k) p[no * ni + no + k] = std::tanh(fa->second.v[(size_t)c * no + k]);
+                }
+                off += (size_t)no * ni + no + (i < 4 ? no : 0);
+            }
+            if (ok) {
+                float* dp = nullptr;
+                HIP_TRY(hipMalloc((void**)&dp, prm.size() * sizeof(float)));
+                HIP_TRY(hipMemcpy(dp, prm.data(), prm.size() * sizeof(float), hipMemcpyHostToDevice));
+                m->dense[pre + "cumulative"] = dp;
+            }
         }
     }
     m->finalized = true;
@@ -1634,6 +1746,26 @@ int rgbd_elic_compress(rgbd_elic* m, const float* rgb_dev, const float* depth_de
     r = m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
     if (m->profile) m->profile_collect();  // run_compress ends with a stream synchronise
     return r;
+}
+
+int rgbd_elic_forward(rgbd_elic* m, const float* rgb_dev, const float* depth_dev, int32_t B, int32_t H, int32_t W,
+                      float* xr_dev, float* xd_dev, float* lik_y_rgb, float* lik_y_depth, float* lik_z_rgb,
+                      float* lik_z_depth, void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (!rgb_dev || !depth_dev || !xr_dev || !xd_dev || !lik_y_rgb || !lik_y_depth || !lik_z_rgb || !lik_z_depth || B <= 0 ||
+        H <= 0 || W <= 0 || H % 64 || W % 64)
+        return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_forward(rgb_dev, depth_dev, B, H, W, xr_dev, xd_dev, lik_y_rgb, lik_y_depth, lik_z_rgb, lik_z_depth);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    return m->run_forward(rgb_dev, depth_dev, B, H, W, xr_dev, xd_dev, lik_y_rgb, lik_y_depth, lik_z_rgb, lik_z_depth);
 }
 
 int rgbd_elic_stream_count(const rgbd_elic* m, int32_t modality, int32_t kind)

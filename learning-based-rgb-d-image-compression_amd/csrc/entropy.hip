@@ -125,6 +125,115 @@ int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs,
 }
 
 // ---------------------------------------------------------------------------------------------
+// eval-mode forward() (models/elic_united.py:94-115, 234-263): same quantisation as the encoder, plus the Gaussian
+// likelihood of the quantised value (entropy_models.py:534-558) instead of symbols
+__global__ void ckbd_estimate_kernel(const float* __restrict__ y, int ycs, const float* __restrict__ params, int pcs,
+                                     float* __restrict__ yhat, int yhcs, float* __restrict__ lik, int lcs, PartGeom g)
+{
+    const int w2 = g.w / 2;
+    const size_t total = (size_t)g.B * g.h * w2 * g.C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.C);
+        size_t t = i / g.C;
+        const int k = (int)(t % w2);
+        t /= w2;
+        const int row = (int)(t % g.h);
+        const int b = (int)(t / g.h);
+        const int col = ckbd_col(row, k, g.anchor);
+        const size_t pix = ((size_t)b * g.h + row) * g.w + col;
+        const float scale = fmaxf(params[pix * pcs + c], 0.11f);  // LowerBound(0.11)
+        const float mean = params[pix * pcs + g.C + c];
+        const float out = __fadd_rn(rintf(y[pix * ycs + c] - mean), mean);  // quantize(..., "dequantize", means)
+        yhat[pix * yhcs + c] = out;
+        const float v = fabsf(__fsub_rn(out, mean));
+        const float cst = -0.70710678118654752440f;  // -(2 ** -0.5)
+        const float upper = 0.5f * erfcf(cst * ((0.5f - v) / scale));
+        const float lower = 0.5f * erfcf(cst * ((-0.5f - v) / scale));
+        lik[pix * lcs + c] = fmaxf(upper - lower, 1e-9f);
+        if (g.anchor) {
+            const size_t opix = ((size_t)b * g.h + row) * g.w + (col ^ 1);
+            yhat[opix * yhcs + c] = 0.f;
+        }
+    }
+}
+
+int launch_ckbd_estimate_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs, float* lik,
+                              int lcs, PartGeom g, hipStream_t s)
+{
+    if (g.w % 2) return RGBD_EINVAL;
+    hipLaunchKernelGGL(ckbd_estimate_kernel, dim3(part_grid(g)), dim3(256), 0, s, y, ycs, params, pcs, yhat, yhcs, lik, lcs,
+                       g);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// Factorised prior in eval mode (entropy_models.py:369-428): z_hat = round(z - median) + median and its likelihood
+// |sigmoid(s*u) - sigmoid(s*l)| from the per-channel cumulative (a 1-3-3-3-3-1 network).  `prm` holds, per channel,
+// softplus(matrix_i) / bias_i / tanh(factor_i) flattened in layer order: 3+3+3, (9+3+3)x3, 3+1  = 58 floats.
+__device__ __forceinline__ float eb_logits(const float* __restrict__ p, float x)
+{
+    float h[3], t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float l = p[j] * x + p[3 + j];
+        h[j] = l + p[6 + j] * tanhf(l);
+    }
+    p += 9;
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float l = p[j * 3] * h[0];
+            l += p[j * 3 + 1] * h[1];
+            l += p[j * 3 + 2] * h[2];
+            l += p[9 + j];
+            t[j] = l + p[12 + j] * tanhf(l);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) h[j] = t[j];
+        p += 15;
+    }
+    float l = p[0] * h[0];
+    l += p[1] * h[1];
+    l += p[2] * h[2];
+    return l + p[3];
+}
+
+__global__ void eb_forward_kernel(const float* __restrict__ z, int zcs, int B, int h, int w, int C,
+                                  const float* __restrict__ med, const float* __restrict__ prm, float* __restrict__ zhat,
+                                  float* __restrict__ lik)
+{
+    const size_t total = (size_t)B * h * w * zcs;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % zcs);
+        const size_t pix = i / zcs;
+        if (c >= C) {
+            zhat[pix * zcs + c] = 0.f;
+            lik[pix * zcs + c] = 0.f;
+            continue;
+        }
+        const float out = __fadd_rn(rintf(z[pix * zcs + c] - med[c]), med[c]);
+        zhat[pix * zcs + c] = out;
+        const float lo = eb_logits(prm + (size_t)c * 58, out - 0.5f);
+        const float up = eb_logits(prm + (size_t)c * 58, out + 0.5f);
+        const float sm = lo + up;
+        const float sg = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
+        const float a = 1.0f / (1.0f + expf(-(sg * up))), b = 1.0f / (1.0f + expf(-(sg * lo)));
+        lik[pix * zcs + c] = fmaxf(fabsf(a - b), 1e-9f);
+    }
+}
+
+int launch_eb_forward(const float* z, int zcs, int B, int h, int w, int C, const float* med, const float* prm, float* zhat,
+                      float* lik, hipStream_t s)
+{
+    const size_t work = (size_t)B * h * w * zcs;
+    hipLaunchKernelGGL(eb_forward_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, z, zcs, B, h, w, C, med, prm,
+                       zhat, lik);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // z path: sym = round(z - median_c), index = c, per-image streams in (c, row, col) order
 __global__ void z_quant_kernel(const float* __restrict__ z, int zcs, int B, int h, int w, int C,
                                const float* __restrict__ med, int32_t* __restrict__ sym, int32_t* __restrict__ idx)

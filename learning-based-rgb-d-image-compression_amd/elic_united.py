@@ -247,7 +247,25 @@ class ELIC_united:
         return {"x_hat": {"r": xr, "d": xd}, "cost_time": time.process_time() - t0}
 
     def forward(self, rgb, depth):
-        raise NotImplementedError("eval-mode forward()/likelihoods is a 'next' row (SURVEY.md §8f rank 2)")
+        """Eval-mode forward (models/elic_united.py:234-263): x_hat without entropy coding plus the likelihoods."""
+        if self.training:
+            raise NotImplementedError("training-mode forward (noise / STE gradients) is out of scope")
+        self._ready()
+        B, _, H, W = rgb.shape
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64")
+        rgb = rgb.to(self._device, torch.float32).contiguous()
+        depth = depth.to(self._device, torch.float32).contiguous()
+        dev = self._device
+        xr = torch.empty((B, 3, H, W), device=dev)
+        xd = torch.empty((B, 1, H, W), device=dev)
+        ly = [torch.empty((B, self.M, H // 16, W // 16), device=dev) for _ in range(2)]
+        lz = [torch.empty((B, self.N, H // 64, W // 64), device=dev) for _ in range(2)]
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        check(lib().rgbd_elic_forward(self._h, p(rgb), p(depth), B, H, W, p(xr), p(xd), p(ly[0]), p(ly[1]), p(lz[0]), p(lz[1]),
+                                      self._stream_ptr()), "forward")
+        return {"x_hat": {"r": xr, "d": xd}, "r_likelihoods": {"y": ly[0], "z": lz[0]},
+                "d_likelihoods": {"y": ly[1], "z": lz[1]}}
 
     __call__ = forward
 

@@ -388,6 +388,71 @@ class OracleCodec:
         return {"r_strings": [[ys["rgb"]], zs_r], "d_strings": [[ys["depth"]], zs_d],
                 "shape": tuple(z_r.shape[-2:])}
 
+    # -- eval-mode forward: elic_united.py:94-263 (quant == "ste": round in eval), entropy_models.py:391-428, 534-558
+    def _eb_forward(self, mod, z):
+        p = f"{mod}_entropy_bottleneck"
+        med = self.sd[f"{p}.quantiles"][:, :, 1:2]
+        x = z.permute(1, 2, 3, 0).contiguous()
+        shape = x.size()
+        v = x.reshape(x.size(0), 1, -1)
+        out = torch.round(v - med) + med
+        lower = _eb_logits(self.sd, p, out - 0.5)
+        upper = _eb_logits(self.sd, p, out + 0.5)
+        sign = -torch.sign(lower + upper)
+        lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        lik = torch.max(lik, torch.tensor([1e-9]))
+        return out.reshape(shape).permute(3, 0, 1, 2).contiguous(), lik.reshape(shape).permute(3, 0, 1, 2).contiguous()
+
+    @staticmethod
+    def _gc_likelihood(y, scales, means):
+        out = torch.round(y - means) + means
+        v = torch.abs(out - means)
+        s = torch.max(scales, torch.tensor([SCALE_BOUND]))
+        c = float(-(2 ** -0.5))
+        upper = 0.5 * torch.erfc(c * ((0.5 - v) / s))
+        lower = 0.5 * torch.erfc(c * ((-0.5 - v) / s))
+        return torch.max(upper - lower, torch.tensor([1e-9]))
+
+    @torch.no_grad()
+    def forward(self, rgb, depth):
+        sd = self.sd
+        y_r, y_d = g_a(sd, rgb, depth)
+        z_r, z_d = h_a(sd, y_r, y_d)
+        zh_r, zl_r = self._eb_forward("rgb", z_r)
+        zh_d, zl_d = self._eb_forward("depth", z_d)
+        hyp_r, hyp_d = h_s(sd, zh_r, zh_d)
+        yhat_r, yhat_d, lik_r, lik_d = [], [], [], []
+        for i, C in enumerate(self.slice_ch):
+            c0 = sum(self.slice_ch[:i])
+            yr, yd = y_r[:, c0:c0 + C], y_d[:, c0:c0 + C]
+            ctx0 = [hyp_r, hyp_d]
+            if i:
+                ctx0 = ctx0 + [_channel_context(sd, f"rgb_channel_context.{i}", torch.cat(yhat_r, dim=1)),
+                               _channel_context(sd, f"depth_channel_context.{i}", torch.cat(yhat_d, dim=1))]
+
+            def part(mod, anchor, ctx, y_full):
+                fam = f"{mod}_entropy_parameters_{'anchor' if anchor else 'nonanchor'}.{i}"
+                scales, means = _entropy_params(sd, fam, torch.cat(ctx, dim=1)).chunk(2, 1)
+                sc, mu = unpack(pack(scales, anchor), anchor), unpack(pack(means, anchor), anchor)
+                yp = unpack(pack(y_full, anchor), anchor)
+                return torch.round(yp - mu) + mu, sc, mu
+
+            ra, s_ra, m_ra = part("rgb", True, ctx0, yr)
+            r_loc = _conv(sd, f"rgb_local_context.{i}", ra)
+            da, s_da, m_da = part("depth", True, [r_loc] + ctx0, yd)
+            d_loc = _conv(sd, f"depth_local_context.{i}", da)
+            rn, s_rn, m_rn = part("rgb", False, [r_loc, d_loc] + ctx0, yr)
+            r_hat = rn + ra
+            r_loc2 = _conv(sd, f"rgb_local_context_anchor_with_nonanchor.{i}", r_hat)
+            dn, s_dn, m_dn = part("depth", False, [r_loc2, d_loc] + ctx0, yd)
+            yhat_r.append(r_hat)
+            yhat_d.append(dn + da)
+            lik_r.append(self._gc_likelihood(yr, s_ra + s_rn, m_ra + m_rn))
+            lik_d.append(self._gc_likelihood(yd, s_da + s_dn, m_da + m_dn))
+        xr, xd = g_s(sd, torch.cat(yhat_r, 1), torch.cat(yhat_d, 1))
+        return {"x_hat": {"r": xr, "d": xd}, "r_likelihoods": {"y": torch.cat(lik_r, 1), "z": zl_r},
+                "d_likelihoods": {"y": torch.cat(lik_d, 1), "z": zl_d}}
+
     @torch.no_grad()
     def decompress(self, r_strings, d_strings, shape):  # elic_united.py:429-452
         t0 = time.process_time()

@@ -148,6 +148,9 @@ def model_case(net, synth, name, B, H, W, config_id, full: bool):
             hp_r, hp_d = net.h_s(zh_r, zh_d)
             fw = net(rp, dp)
         assert torch.equal(fw["x_hat"]["r"].clamp(0, 1), dec["x_hat"]["r"])
+        g.update({"fw_xhat_r": fw["x_hat"]["r"].numpy(), "fw_xhat_d": fw["x_hat"]["d"].numpy(),
+                  "lik_y_r": fw["r_likelihoods"]["y"].numpy(), "lik_y_d": fw["d_likelihoods"]["y"].numpy(),
+                  "lik_z_r": fw["r_likelihoods"]["z"].numpy(), "lik_z_d": fw["d_likelihoods"]["z"].numpy()})
         g.update({"y_r": y_r.numpy(), "y_d": y_d.numpy(), "z_r": z_r.numpy(), "z_d": z_d.numpy(),
                   "zhat_r": zh_r.numpy(), "zhat_d": zh_d.numpy(), "hyper_r": hp_r.numpy(), "hyper_d": hp_d.numpy(),
                   "xhat_r": xr.numpy(), "xhat_d": xd.numpy()})

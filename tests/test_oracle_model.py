@@ -100,3 +100,14 @@ def test_pack_unpack_roundtrip():
     # anchors = (even row, odd col) U (odd row, even col): utils/ckbd.py:37-41
     assert eo.pack(x, True)[0, 0, 0].tolist() == [1.0, 3.0, 5.0]
     assert eo.pack(x, True)[0, 0, 1].tolist() == [6.0, 8.0, 10.0]
+
+
+def test_eval_forward_matches_reference(codec):
+    g = load_golden("a_128x192")
+    r, d, rp, dp = _inputs(g)
+    fw = codec.forward(rp, dp)
+    for k, v in (("fw_xhat_r", fw["x_hat"]["r"]), ("lik_y_r", fw["r_likelihoods"]["y"]), ("lik_y_d", fw["d_likelihoods"]["y"]),
+                 ("lik_z_r", fw["r_likelihoods"]["z"]), ("lik_z_d", fw["d_likelihoods"]["z"])):
+        np.testing.assert_allclose(v.numpy(), g[k], rtol=2e-5, atol=1e-7)
+    if np.array_equal(fw["r_likelihoods"]["z"].numpy(), g["lik_z_r"]):  # same CPU kernels as the golden machine
+        assert np.array_equal(fw["r_likelihoods"]["y"].numpy(), g["lik_y_r"])
