@@ -76,6 +76,10 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct rgbd_elic rgbd_elic;
 
+/* A second instance that borrows `src`'s packed device weights and tables (own workspace, own stream): several
+ * instances on one GPU then cost one weight copy.  `src` must outlive the clone. */
+int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out);
+
 /* config/config.py:5-10: N, M and the channel count of each latent slice. */
 int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out);
 void rgbd_elic_destroy(rgbd_elic* m);

@@ -66,6 +66,7 @@ def lib():
                                             c_i32, c_i32, c_vp, c_vp, c_vp]),
         "rgbd_elic_create": (ctypes.c_int, [c_i32, c_i32, i32p, c_i32, ctypes.POINTER(c_vp)]),
         "rgbd_elic_destroy": (None, [c_vp]),
+        "rgbd_elic_clone_shared": (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp)]),
         "rgbd_elic_set_tensor": (ctypes.c_int, [c_vp, ctypes.c_char_p, f32p, i64p, c_i32]),
         "rgbd_elic_set_tables": (ctypes.c_int, [c_vp, c_i32, i32p, c_i32, i32p, i32p, c_i32]),
         "rgbd_elic_set_scale_table": (ctypes.c_int, [c_vp, f32p, c_i32]),
@@ -97,7 +98,7 @@ def lib():
 EXPORTS = ["rgbd_abi_version", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
            "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
            "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_elic_create",
-           "rgbd_elic_destroy", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
+           "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_profile",
            "rgbd_elic_profile_read", "rgbd_elic_set_exclusive_transforms", "rgbd_debug_force_splitk", "rgbd_conv_bench",

@@ -241,6 +241,7 @@ struct rgbd_elic {
     int32_t* dbg_idx = nullptr;
     int64_t dbg_per_mod = 0;
 
+    bool owns_weights = true;  // false for instances created by rgbd_elic_clone_shared (they borrow device weights)
     bool exclusive_transforms = false;  // serialise g_a / g_s against other instances (see g_transform_phase)
 
     // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
@@ -1582,17 +1583,36 @@ int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_sl
     return RGBD_OK;
 }
 
+int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
+{
+    if (!src || !out || !src->finalized) return RGBD_EINVAL;
+    rgbd_elic* m = new rgbd_elic();
+    m->N = src->N;
+    m->M = src->M;
+    m->slice_ch = src->slice_ch;
+    m->convs = src->convs;    // device pointers are shared, read-only
+    m->dense = src->dense;
+    for (int i = 0; i < 4; ++i) m->tables[i] = src->tables[i];
+    m->scale_table = src->scale_table;
+    m->finalized = true;
+    m->owns_weights = false;
+    *out = m;
+    return RGBD_OK;
+}
+
 void rgbd_elic_destroy(rgbd_elic* m)
 {
     if (!m) return;
-    for (auto& kv : m->convs) {
-        (void)hipFree(kv.second.w);
-        (void)hipFree(kv.second.bias);
+    if (m->owns_weights) {
+        for (auto& kv : m->convs) {
+            (void)hipFree(kv.second.w);
+            (void)hipFree(kv.second.bias);
+        }
+        for (auto& kv : m->dense) (void)hipFree(kv.second);
+        for (auto& t : m->tables)
+            if (t.blob) (void)hipFree(t.blob);
+        if (m->scale_table) (void)hipFree(m->scale_table);
     }
-    for (auto& kv : m->dense) (void)hipFree(kv.second);
-    for (auto& t : m->tables)
-        if (t.blob) (void)hipFree(t.blob);
-    if (m->scale_table) (void)hipFree(m->scale_table);
     if (m->arena.base) (void)hipFree(m->arena.base);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;

@@ -288,6 +288,19 @@ class ELIC_united:
                                             n.value, ctypes.byref(n)), "debug_symbols")
         return sym, idx
 
+    def clone_shared(self):
+        """Another engine instance on the same GPU that borrows this one's device weights and tables (own workspace and
+        stream).  The clone keeps a reference to its parent so the weights outlive it."""
+        self._ready()
+        other = ELIC_united.__new__(ELIC_united)
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_h"})
+        h = ctypes.c_void_p()
+        check(lib().rgbd_elic_clone_shared(self._h, ctypes.byref(h)), "clone_shared")
+        other._h = h
+        other._parent = self
+        other._dirty = False
+        return other
+
     def set_exclusive_transforms(self, on: bool):
         check(lib().rgbd_elic_set_exclusive_transforms(self._h, 1 if on else 0), "set_exclusive_transforms")
 

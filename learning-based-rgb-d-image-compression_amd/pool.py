@@ -22,11 +22,14 @@ class CodecPool:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.nets: List[ELIC_united] = []
         self.streams = []
-        for _ in range(workers):
-            net = ELIC_united(config=config, channel=4).eval()
-            net.load_state_dict(state_dict)
-            net.update(force=True)
-            net = net.to(self.device)
+        for i in range(workers):
+            if i == 0:
+                net = ELIC_united(config=config, channel=4).eval()
+                net.load_state_dict(state_dict)
+                net.update(force=True)
+                net = net.to(self.device)
+            else:
+                net = self.nets[0].clone_shared()  # same packed weights in HBM, own workspace
             net.per_image_streams = per_image_streams
             net.set_exclusive_transforms(workers > 1 and os.environ.get("RGBD_EXCLUSIVE_TRANSFORMS", "0") == "1")
             self.nets.append(net)

@@ -196,3 +196,22 @@ def test_eval_forward(net, orc):
         # the estimate brackets the real stream within a few percent (the coder's tables are 16-bit quantised)
         key = "r_strings" if mod == "r" else "d_strings"
         assert abs(bits / 8 - len(out[key][0][0])) < 0.35 * len(out[key][0][0])
+
+
+def test_full_size_self_consistency(net):
+    """BASELINE config 3 geometry (480x640 -> replicate-padded 512x640): size-independent properties only --
+    decode(encode(x)) reproduces the encoder's y_hat and equals eval-mode forward(), streams are deterministic."""
+    r, d, rp, dp = _inputs(1, 480, 640, 3)
+    assert tuple(rp.shape[-2:]) == (512, 640)
+    out = net.compress(rp.cuda(), dp.cuda())
+    yhat = net.debug_tensor("yhat_r").copy()
+    assert tuple(out["shape"]) == (8, 10) and all(len(s) % 4 == 0 for s in out["r_strings"][0] + out["r_strings"][1])
+    rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert np.array_equal(net.debug_tensor("yhat_r"), yhat)
+    fw = net(rp.cuda(), dp.cuda())
+    assert torch.equal(fw["x_hat"]["r"].clamp(0, 1), rec["x_hat"]["r"]) and torch.equal(fw["x_hat"]["d"].clamp(0, 1), rec["x_hat"]["d"])
+    again = net.compress(rp.cuda(), dp.cuda())
+    assert again["r_strings"] == out["r_strings"] and again["d_strings"] == out["d_strings"]
+    bits = float(-torch.log2(fw["r_likelihoods"]["y"]).sum() - torch.log2(fw["r_likelihoods"]["z"]).sum())
+    real = 8 * (len(out["r_strings"][0][0]) + len(out["r_strings"][1][0]))
+    assert abs(bits - real) < 0.35 * real
