@@ -20,10 +20,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // KC = channels per LDS stage (16 or 64).  LDS rows are padded by one 16-byte slot when KC > 16 so that the 16 rows a
 // ds_read_b128 lane group touches fall on different banks (row stride 272 B instead of 256 B).
-// PF: software-pipelined staging -- the global loads of stage s+1 are issued before the MFMAs of stage s and stay in
-// flight under them (costs ~80 VGPRs; used when a launch has too few workgroups to overlap load and compute phases of
-// different workgroups on one CU).
-template <int WM, int WN, int MT, int NT, int KC, bool PF>
+// DMA (KC == 16 only): operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a
+// double-buffered LDS image; the loads of stage s+1 are in flight under the MFMAs of stage s and one barrier per stage
+// both retires them (vmcnt) and frees the other buffer.  Out-of-image patch slots are zeroed with ordinary LDS stores.
+// Without DMA the stage is staged through registers (all loads issued back to back, then committed).
+template <int WM, int WN, int MT, int NT, int KC, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
                                                          int taps_per_stage)
 {
@@ -57,8 +58,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 
     const int PH = (TH - 1) * a.IS + a.span_y;
     const int PW = (TW - 1) * a.IS + a.span_x;
-    float* patch = smem;                      // [PH*PW][RS]
-    float* wl = smem + (size_t)PH * PW * RS;  // [taps_per_stage][TM][RS]
+    const int patch_f = PH * PW * RS;                         // floats per patch buffer
+    const int wl_f = taps_per_stage * TM * RS;                 // floats per weight buffer
+    float* patch = smem;                                       // [DMA ? 2 : 1][PH*PW][RS]
+    float* wl = smem + (size_t)patch_f * (DMA ? 2 : 1);        // [DMA ? 2 : 1][taps_per_stage][TM][RS]
 
     const int ntaps = a.taps.n[phase];
     const int iy0 = ty0 * a.IS + a.min_dy;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     // Everything that does not change from stage to stage is computed once here: per staging slot u the thread's
     // global element offsets (weights: without the tap/chunk term; patch: pixel offset or -1 outside the image) --
     // the per-stage work is then one add and one 16-byte load per slot.  LDS destinations are affine in u.
-    f32x4 pw[WR], pp[PR];
+    f32x4 pw[DMA ? 1 : WR], pp[DMA ? 1 : PR];
     int gw_base[WR];   // (co0+m) * ntaps_total * cin_pad + c4*4, or -1 when the row is outside cout_pad
     int gw_j[WR];      // tap slot inside the stage
     int gp_off[PR];    // ((n*H + iy)*W + ix) * xcs + c4*4, or -1 when outside the image / patch
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             const int c4x4 = ((tid + u * 256) % C4) * 4;
             if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
                 v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + (int)a.taps.wt[phase][t0 + gw_j[u]] * a.cin_pad + ci0);
-            pw[u] = v;
+            pw[DMA ? 0 : u] = v;
         }
     };
     auto commit_w = [&](int stage) {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 #pragma unroll
         for (int u = 0; u < WR; ++u)
             if (tid / C4 + u * (256 / C4) < nrows)
-                *reinterpret_cast<f32x4*>(wl + w_lds0 + u * (256 / C4) * RS) = pw[u];
+                *reinterpret_cast<f32x4*>(wl + w_lds0 + u * (256 / C4) * RS) = pw[DMA ? 0 : u];
     };
     auto issue_p = [&](int chunk) {
         const int ci0 = ci_lo + chunk * KC;
@@ -151,61 +154,79 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             const int c4x4 = ((tid + u * 256) % C4) * 4;
             if (gp_off[u] >= 0 && (KC == 16 || ci0 + c4x4 < ci_hi))
                 v = *reinterpret_cast<const f32x4*>(a.x + gp_off[u] + ci0);
-            pp[u] = v;
+            pp[DMA ? 0 : u] = v;
         }
     };
     auto commit_p = [&]() {
 #pragma unroll
         for (int u = 0; u < PR; ++u)
-            if (tid + u * 256 < npatch4) *reinterpret_cast<f32x4*>(patch + w_lds0 + u * (256 / C4) * RS) = pp[u];
+            if (tid + u * 256 < npatch4) *reinterpret_cast<f32x4*>(patch + w_lds0 + u * (256 / C4) * RS) = pp[DMA ? 0 : u];
+    };
+    // DMA variants: LDS slot f = tid + u*256 is 16 bytes at f*16 (RS == 16: the image is lane-linear), so a wave's
+    // destination base is uniform and lane i lands at base + 16*i
+    const int wave_slot0 = (__builtin_amdgcn_readfirstlane(tid) >> 6) * 64;
+    auto dma_w = [&](int stage, int buf) {
+        const int ci0 = ci_lo + (stage / ngroups) * KC;
+        const int t0 = (stage % ngroups) * taps_per_stage;
+        const int tg = min(taps_per_stage, ntaps - t0);
+#pragma unroll
+        for (int u = 0; u < WR; ++u)
+            if (gw_base[u] >= 0 && gw_j[u] < tg)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(a.w + gw_base[u] + (int)a.taps.wt[phase][t0 + gw_j[u]] * a.cin_pad + ci0),
+                    (__attribute__((address_space(3))) void*)(wl + buf * wl_f + (wave_slot0 + u * 256) * 4), 16, 0, 0);
+    };
+    auto dma_p = [&](int chunk, int buf) {
+        const int ci0 = ci_lo + chunk * KC;
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const int f = tid + u * 256;
+            if (f < npatch4) {
+                if (gp_off[u] >= 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + gp_off[u] + ci0),
+                                                     (__attribute__((address_space(3))) void*)(patch + buf * patch_f + (wave_slot0 + u * 256) * 4),
+                                                     16, 0, 0);
+                else
+                    *reinterpret_cast<f32x4*>(patch + buf * patch_f + f * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
     };
 
-    // epilogue geometry (see below); with PF and a short tile the fused operands are requested up front as well, so a
-    // short-K (1x1) workgroup exposes one memory round trip instead of four
+    // epilogue geometry (see below)
     constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;  // cout tiles per pass
     constexpr int SW = 16 * WM * EMT + 4;                                                   // staging row stride (floats)
     constexpr int S4 = 4 * WM * EMT;                                                        // float4 per staged pixel row
     constexpr int EU = TP * S4 / 256;
-    constexpr bool AUXPF = PF && EMT == MT && EU <= 8;
     const int oy_off = a.nphase > 1 ? (phase >> 1) : 0;
     const int ox_off = a.nphase > 1 ? (phase & 1) : 0;
-    f32x4 aux1[AUXPF ? EU : 1], aux2[AUXPF ? EU : 1], aux3[AUXPF ? EU : 1];
-    if (AUXPF && a.splitk == 1) {
-#pragma unroll
-        for (int u = 0; u < EU; ++u) {
-            const int f = tid + u * 256;
-            const int p = f / S4, c4 = f - p * S4;
-            const int cb = co0 + ((c4 / (4 * EMT)) * MT + (c4 / 4) % EMT) * 16 + (c4 & 3) * 4;
-            const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
-            const bool okk = cb < a.cout_pad && gy < a.GH && gx < a.GW;
-            const size_t pix = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
-            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-            aux1[u] = (okk && a.res1) ? *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb) : z;
-            aux2[u] = (okk && a.mul) ? *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb) : z;
-            aux3[u] = (okk && a.res2) ? *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb) : z;
-        }
-    }
-    if (PF) {
-        issue_p(0);
-        issue_w(0);
+    if (DMA && nstages > 0) {
+        dma_p(0, 0);
+        dma_w(0, 0);
     }
     for (int stage = 0; stage < nstages; ++stage) {
         const int t0 = (stage % ngroups) * taps_per_stage;
         const int tg = min(taps_per_stage, ntaps - t0);
-        if (!PF) {
+        const float* cur_w = wl;
+        const float* cur_p = patch;
+        if (DMA) {
+            const int buf = stage & 1, pbuf = (stage / ngroups) & 1;
+            __syncthreads();  // retires this stage's DMA (vmcnt) and frees the other buffers (everyone left stage-1)
+            if (stage + 1 < nstages) {
+                dma_w(stage + 1, buf ^ 1);
+                if ((stage + 1) % ngroups == 0) dma_p((stage + 1) / ngroups, pbuf ^ 1);
+            }
+            cur_w = wl + buf * wl_f;
+            cur_p = patch + pbuf * patch_f;
+        } else {
             // all global loads of the stage are issued back to back (one memory round trip per stage), then committed
             // to LDS; the staging registers are dead during the MFMA phase so two workgroups fit per CU and hide each
             // other's load phase
             issue_w(stage);
             if (t0 == 0) issue_p(stage / ngroups);
-        }
-        __syncthreads();  // every wave has finished reading the previous stage from LDS
-        if (t0 == 0) commit_p();
-        commit_w(stage);
-        __syncthreads();
-        if (PF && stage + 1 < nstages) {
-            issue_w(stage + 1);
-            if ((stage + 1) % ngroups == 0) issue_p((stage + 1) / ngroups);
+            __syncthreads();  // every wave has finished reading the previous stage from LDS
+            if (t0 == 0) commit_p();
+            commit_w(stage);
+            __syncthreads();
         }
         // canonical accumulation order: 16-channel chunk -> tap -> channel.  A 64-channel stage therefore walks its
         // four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so the
@@ -219,9 +240,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-                    af[i] = *reinterpret_cast<const f32x4*>(wl + (j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
+                    af[i] = *reinterpret_cast<const f32x4*>(cur_w + (j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
 #pragma unroll
-                for (int k = 0; k < NT; ++k) bf[k] = *reinterpret_cast<const f32x4*>(patch + brow0[k] + toff);
+                for (int k = 0; k < NT; ++k) bf[k] = *reinterpret_cast<const f32x4*>(cur_p + brow0[k] + toff);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -270,15 +291,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 pixs[u] = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
                 v[u] = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (AUXPF) {
-                    r1[u] = aux1[AUXPF ? u0 + u : 0];
-                    ml[u] = aux2[AUXPF ? u0 + u : 0];
-                    r2[u] = aux3[AUXPF ? u0 + u : 0];
-                } else {
-                    r1[u] = (ok[u] && a.res1) ? *reinterpret_cast<const f32x4*>(a.res1 + pixs[u] * a.r1cs + cb) : z;
-                    ml[u] = (ok[u] && a.mul) ? *reinterpret_cast<const f32x4*>(a.mul + pixs[u] * a.mcs + cb) : z;
-                    r2[u] = (ok[u] && a.res2) ? *reinterpret_cast<const f32x4*>(a.res2 + pixs[u] * a.r2cs + cb) : z;
-                }
+                r1[u] = (ok[u] && a.res1) ? *reinterpret_cast<const f32x4*>(a.res1 + pixs[u] * a.r1cs + cb) : z;
+                ml[u] = (ok[u] && a.mul) ? *reinterpret_cast<const f32x4*>(a.mul + pixs[u] * a.mcs + cb) : z;
+                r2[u] = (ok[u] && a.res2) ? *reinterpret_cast<const f32x4*>(a.res2 + pixs[u] * a.r2cs + cb) : z;
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -313,7 +328,7 @@ namespace {
 
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
-template <int WM, int WN, int MT, int NT, int KC, bool PF>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA>
 int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
 {
     constexpr int TM = 16 * MT * WM;
@@ -328,15 +343,19 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
     constexpr int PR = TP >= 128 ? 12 : (TP >= 64 ? 6 : 4);
     if ((long)PH * PW * (KC / 4) > PR * 256) return RGBD_ENOSPC;  // patch registers
-    long room = (8 * 256) / ((long)TM * (KC / 4));               // weight registers (WR)
+    long room = (8 * 256) / ((long)TM * (KC / 4));               // weight slots per stage (WR)
+    if (DMA) {
+        const long lds_room = ((long)LDS_BUDGET - 2 * (long)patch_bytes) / (2 * (long)tap_bytes);
+        room = room < lds_room ? room : lds_room;
+    }
     if (room < 1) return RGBD_ENOSPC;
     const int tps = (int)(room < max_taps ? room : max_taps);
     if (KC > 16 && tps < max_taps) return RGBD_ENOSPC;  // would break the canonical accumulation order
     constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;
     const size_t epi_bytes = (size_t)TP * (16 * WM * EMT + 4) * sizeof(float);
-    const size_t stage_bytes = patch_bytes + (size_t)tps * tap_bytes;
+    const size_t stage_bytes = (patch_bytes + (size_t)tps * tap_bytes) * (DMA ? 2 : 1);
     const size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-    auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, PF>;
+    auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -369,7 +388,7 @@ int pick_tw_log2(int GW, int GH, int TP)
 
 struct Choice {
     int wm, mt, nt, kc, tw_log2;
-    bool pf;
+    bool dma;
 };
 
 Choice choose(const ConvArgs& a)
@@ -428,16 +447,26 @@ Choice choose(const ConvArgs& a)
             w4 <= 8 * 256)
             best.kc = 64;
     }
-    best.pf = best_blocks <= 512;  // at most ~2 workgroups per CU: overlap load and compute inside the workgroup
+    // direct-to-LDS double buffering whenever two patch images and at least two taps of weights fit in the budget
+    {
+        const int tp = 16 * best.nt * (best.wm == 2 ? 2 : 4);
+        const int TW = 1 << best.tw_log2, TH = tp / TW;
+        const long patch = (long)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 64;
+        const long tap = (long)16 * best.mt * best.wm * 64;
+        const int need = max_taps < 2 ? max_taps : 2;
+        best.dma = best.kc == 16 && 2 * patch + 2 * need * tap <= (long)LDS_BUDGET;
+        static const char* nodma = getenv("RGBD_CONV_NODMA");
+        if (nodma) best.dma = false;
+    }
+    (void)best_blocks;
     return best;
 }
 
 #define RGBD_CASE(WM_, WN_, MT_, NT_)                                              \
     if (c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                                 \
-        return c.kc == 64 ? (c.pf ? launch_cfg<WM_, WN_, MT_, NT_, 64, true>(a, c.tw_log2, s)    \
-                                  : launch_cfg<WM_, WN_, MT_, NT_, 64, false>(a, c.tw_log2, s)) \
-                          : (c.pf ? launch_cfg<WM_, WN_, MT_, NT_, 16, true>(a, c.tw_log2, s)    \
-                                  : launch_cfg<WM_, WN_, MT_, NT_, 16, false>(a, c.tw_log2, s));
+        return c.kc == 64 ? launch_cfg<WM_, WN_, MT_, NT_, 64, false>(a, c.tw_log2, s)            \
+                          : (c.dma ? launch_cfg<WM_, WN_, MT_, NT_, 16, true>(a, c.tw_log2, s)    \
+                                   : launch_cfg<WM_, WN_, MT_, NT_, 16, false>(a, c.tw_log2, s));
 
 }  // namespace
 
@@ -495,19 +524,19 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     Choice c = choose(a);
     static const char* force = getenv("RGBD_CONV_FORCE");  // "wm,mt,nt[,kc[,pf]]" -- tuning experiments only
     if (force) {
-        int wm = c.wm, mt = c.mt, nt = c.nt, kc = c.kc, pf = c.pf;
-        sscanf(force, "%d,%d,%d,%d,%d", &wm, &mt, &nt, &kc, &pf);
+        int wm = c.wm, mt = c.mt, nt = c.nt, kc = c.kc, dm = c.dma;
+        sscanf(force, "%d,%d,%d,%d,%d", &wm, &mt, &nt, &kc, &dm);
         c.wm = wm;
         c.mt = mt;
         c.nt = nt;
         c.kc = kc;
-        c.pf = pf != 0;
+        c.dma = dm != 0 && kc == 16;
         c.tw_log2 = pick_tw_log2(a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
     }
     static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "[conv] N=%d GH=%d GW=%d cin=%d cout=%d taps=%d IS=%d nph=%d -> WM=%d MT=%d NT=%d KC=%d tw=%d pf=%d\n", a.N,
-                a.GH, a.GW, a.cin_pad, a.cout_pad, a.taps.n[0], a.IS, a.nphase, c.wm, c.mt, c.nt, c.kc, 1 << c.tw_log2, (int)c.pf);
+        fprintf(stderr, "[conv] N=%d GH=%d GW=%d cin=%d cout=%d taps=%d IS=%d nph=%d -> WM=%d MT=%d NT=%d KC=%d tw=%d dma=%d\n", a.N,
+                a.GH, a.GW, a.cin_pad, a.cout_pad, a.taps.n[0], a.IS, a.nphase, c.wm, c.mt, c.nt, c.kc, 1 << c.tw_log2, (int)c.dma);
     RGBD_CASE(2, 2, 5, 4) RGBD_CASE(2, 2, 4, 4) RGBD_CASE(2, 2, 3, 4) RGBD_CASE(2, 2, 2, 4) RGBD_CASE(2, 2, 1, 4)
     RGBD_CASE(2, 2, 5, 2) RGBD_CASE(2, 2, 4, 2) RGBD_CASE(2, 2, 3, 2) RGBD_CASE(2, 2, 2, 2) RGBD_CASE(2, 2, 1, 2)
     RGBD_CASE(2, 2, 5, 1) RGBD_CASE(2, 2, 4, 1) RGBD_CASE(2, 2, 3, 1) RGBD_CASE(2, 2, 2, 1) RGBD_CASE(2, 2, 1, 1)
