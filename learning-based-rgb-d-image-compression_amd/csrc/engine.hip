@@ -565,6 +565,13 @@ struct rgbd_elic {
         if (r) fail(r);
     }
 
+    void scale_to(const Act& x, const float* sc, int mode, const Act& y)
+    {
+        if (dry() || rc) return;
+        const int r = launch_channel_scale_to(x.p, x.n, x.h * x.w, x.cs, x.c, sc, mode, y.p, y.cs, s);
+        if (r) fail(r);
+    }
+
     // ---- transforms -----------------------------------------------------------------------------
     // analysis.py:116-174
     void g_a(const Act& rgb_in, const Act& depth_in, Act* y_r, Act* y_d)
@@ -696,23 +703,19 @@ struct rgbd_elic {
         *hd = hs_block("h_s.d_h_s3", d2, r2, true);
     }
 
-    // entropy.py:69-78 on the concatenation of `segs`
-    Act entropy_params(const std::string& p, const std::vector<Act>& segs)
+    // entropy.py:69-78.  `ctx` is a channel-slice view of the slice's context buffer
+    // [r_loc | d_loc | hyper_r | hyper_d | ch_ctx_r | ch_ctx_d]: every EntropyParametersEX input of the reference
+    // (elic_united.py:288-333) is a suffix of that layout, so no concatenation copy is needed; SE-rescaling writes the
+    // rescaled copy the 1x1 conv reads (params + se(params), keeping the reference's association).
+    Act entropy_params(const std::string& p, const Act& ctx, const Act* dst = nullptr)
     {
-        int cin = 0;
-        for (const Act& a : segs) cin += a.c;
         const PackedConv* last = conv_of(p + ".fusion.4.weight");
         if (!last) return Act();
-        Act out = alloc(segs[0].n, segs[0].h, segs[0].w, last->cout);
+        Act out = dst ? *dst : alloc(ctx.n, ctx.h, ctx.w, last->cout);
         const size_t mark = arena.top;
-        Act cat = alloc(segs[0].n, segs[0].h, segs[0].w, cin);
-        int c0 = 0;
-        for (const Act& a : segs) {
-            copy_ch(a, view(cat, c0, a.c));
-            c0 += a.c;
-        }
-        float* sc = se_weights(p + ".se", cat);
-        scale_inplace(cat, sc, 1);  // params + se(params)
+        Act cat = alloc(ctx.n, ctx.h, ctx.w, ctx.c);
+        float* sc = se_weights(p + ".se", ctx);
+        scale_to(ctx, sc, 1, cat);
         Epi relu;
         relu.act = ACT_RELU;
         Act t = conv(p + ".fusion.0", cat, 1, 0, relu);
@@ -723,11 +726,11 @@ struct rgbd_elic {
     }
 
     // context.py:10-30
-    Act channel_context(const std::string& p, const Act& x)
+    Act channel_context(const std::string& p, const Act& x, const Act* dst = nullptr)
     {
         const PackedConv* last = conv_of(p + ".fushion.4.weight");
         if (!last) return Act();
-        Act out = alloc(x.n, x.h, x.w, last->cout);
+        Act out = dst ? *dst : alloc(x.n, x.h, x.w, last->cout);
         const size_t mark = arena.top;
         Epi relu;
         relu.act = ACT_RELU;
@@ -810,34 +813,44 @@ struct rgbd_elic {
             const int C = slice_ch[i];
             const size_t mark = arena.top;
             const std::string si = std::to_string(i);
-            std::vector<Act> ctx0 = {hyp_r, hyp_d};
+            // context buffer of this slice: [r_loc 2C | d_loc 2C | hyper_r 2M | hyper_d 2M | ch_r 2C | ch_d 2C]
+            const int HC = hyp_r.c;  // 2M
+            const int wide = 4 * C + 2 * HC + (i ? 4 * C : 0);
+            Act ctx = alloc(hyp_r.n, h, w, wide);
+            copy_ch(hyp_r, view(ctx, 4 * C, HC));
+            copy_ch(hyp_d, view(ctx, 4 * C + HC, HC));
             if (i) {
-                ctx0.push_back(channel_context("rgb_channel_context." + si, view(yhat_r, 0, c0)));
-                ctx0.push_back(channel_context("depth_channel_context." + si, view(yhat_d, 0, c0)));
+                const Act cr = view(ctx, 4 * C + 2 * HC, 2 * C), cdv = view(ctx, 6 * C + 2 * HC, 2 * C);
+                channel_context("rgb_channel_context." + si, view(yhat_r, 0, c0), &cr);
+                channel_context("depth_channel_context." + si, view(yhat_d, 0, c0), &cdv);
             }
             const Act yr = y_r ? view(*y_r, c0, C) : Act();
             const Act yd = y_d ? view(*y_d, c0, C) : Act();
             const Act hr = view(yhat_r, c0, C), hd = view(yhat_d, c0, C);
             const int64_t part_syms = (int64_t)C * h * (w / 2);
-            auto with = [&](std::initializer_list<Act> head) {
-                std::vector<Act> v(head);
-                v.insert(v.end(), ctx0.begin(), ctx0.end());
-                return v;
-            };
-            // rgb anchor
-            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, with({}));
+            const Act r_loc = view(ctx, 0, 2 * C), d_loc = view(ctx, 2 * C, 2 * C);
+            // rgb anchor: [hyper, ch ctx]
+            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(ctx, 4 * C, wide - 4 * C));
             code_part(cd, 0, 1, p_ra, yr, hr, part_off);
-            Act r_loc = conv("rgb_local_context." + si, hr, 1, 2);
-            // depth anchor
-            Act p_da = entropy_params("depth_entropy_parameters_anchor." + si, with({r_loc}));
+            conv("rgb_local_context." + si, hr, 1, 2, Epi(), &r_loc);
+            // depth anchor: [r_loc, hyper, ch ctx] -- d_loc's slot sits between them, so this one input is gathered
+            Act p_da = alloc(hyp_r.n, h, w, 2 * C);
+            {
+                const size_t m2 = arena.top;
+                Act in = alloc(hyp_r.n, h, w, wide - 2 * C);
+                copy_ch(r_loc, view(in, 0, 2 * C));
+                copy_ch(view(ctx, 4 * C, wide - 4 * C), view(in, 2 * C, wide - 4 * C));
+                entropy_params("depth_entropy_parameters_anchor." + si, in, &p_da);
+                arena.top = m2;
+            }
             code_part(cd, 1, 1, p_da, yd, hd, part_off);
-            Act d_loc = conv("depth_local_context." + si, hd, 1, 2);
-            // rgb non-anchor
-            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, with({r_loc, d_loc}));
+            conv("depth_local_context." + si, hd, 1, 2, Epi(), &d_loc);
+            // rgb non-anchor: the whole buffer
+            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, ctx);
             code_part(cd, 0, 0, p_rn, yr, hr, part_off + part_syms);
-            Act r_loc2 = conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2);
+            conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2, Epi(), &r_loc);  // replaces r_loc
             // depth non-anchor
-            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, with({r_loc2, d_loc}));
+            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, ctx);
             code_part(cd, 1, 0, p_dn, yd, hd, part_off + part_syms);
             part_off += 2 * part_syms;
             c0 += C;

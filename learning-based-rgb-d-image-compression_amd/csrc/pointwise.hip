@@ -261,6 +261,37 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int scs, flo
     }
 }
 
+__global__ void channel_scale_to_kernel(const float* __restrict__ x, int HW, int xcs, int C, const float* __restrict__ scale,
+                                        int mode, float* __restrict__ y, int ycs, size_t total4, int c4n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t pix = i / c4n;
+        const size_t n = pix / HW;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * xcs + c4 * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n * C + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = __fmul_rn(v[e], sc[e]);
+            o[e] = mode ? __fadd_rn(v[e], t) : t;
+        }
+        *reinterpret_cast<f32x4*>(y + pix * ycs + c4 * 4) = o;
+    }
+}
+
+// y[:, :C] = x * s (mode 0) or x + x * s (mode 1) with independent channel strides (C multiple of 4)
+int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const float* scale, int mode, float* y, int ycs,
+                            hipStream_t s)
+{
+    if (C % 4) return RGBD_EINVAL;
+    const size_t total4 = (size_t)N * HW * (C / 4);
+    hipLaunchKernelGGL(channel_scale_to_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, HW, xcs, C, scale, mode, y, ycs,
+                       total4, C / 4);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
 int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s)
 {
     if (C % 4 || scs % 4 || dcs % 4) return RGBD_EINVAL;
