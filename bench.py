@@ -160,6 +160,11 @@ def main():
                          "avg_launch_us": round(prof["conv_ms"] * 1e3 / max(prof["launches"], 1), 2),
                          "conv_ms_per_step": round(prof["conv_ms"] / max(args.steps, 1), 3),
                          "gflop_per_step": round(prof["flops"] / max(args.steps, 1) / 1e9, 2),
+                         "job_level": {"achieved": round(prof["flops"] / elapsed / 1e12, 3),
+                                       "frac": round(prof["flops"] / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                       "note": "conv FLOPs of the timed steps / wall time of the timed region, per GPU "
+                                               "(lower bound on MFMA utilisation: the wall clock also holds every "
+                                               "other kernel)"},
                          "isolated": {"achieved": round(prof1["flops"] / (prof1["conv_ms"] / 1e3) / 1e12, 3),
                                       "frac": round(prof1["flops"] / (prof1["conv_ms"] / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                       "conv_ms_per_step": round(prof1["conv_ms"] / 2, 3),

@@ -425,7 +425,9 @@ Choice choose(const ConvArgs& a)
         const double mfma = (double)mt * nt * (K / 4.0) * 32.0 / ilp + 3000.0;      // cycles per workgroup (+ prologue)
         const double load = (K * tm * 4.0 + (double)PH * PW * a.cin_pad * 4.0) / 12.0;  // ~12 B/clk/CU from L2
         const long nb = (blocks + 255) / 256;
-        const double cost = nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load);
+        static const bool cu_time = getenv("RGBD_CONV_OBJ_CUTIME") != nullptr;  // experiment: minimise CU-time, not latency
+        const double cost = cu_time ? (double)blocks * (mfma + 0.5 * load)
+                                    : (nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load));
         if (best_cost < 0 || cost < best_cost * 0.999) {
             best_cost = cost;
             best = Choice{wm, mt, nt, 16, twl, false};

@@ -4,6 +4,7 @@
 // index and bitstream resident in HBM; the only device->host traffic is the finished streams.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -368,7 +369,8 @@ struct rgbd_elic {
             if (name.rfind(pre, 0) == 0) {
                 int mt = 1;
                 for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
-                a.splitk = g_force_splitk > 0 ? g_force_splitk : conv_splitk_for(a.cin_pad, mt);
+                static const bool nosplit = getenv("RGBD_NO_SPLITK") != nullptr;  // experiment only
+                a.splitk = g_force_splitk > 0 ? g_force_splitk : (nosplit ? 1 : conv_splitk_for(a.cin_pad, mt));
                 break;
             }
         const size_t pmark = arena.top;
