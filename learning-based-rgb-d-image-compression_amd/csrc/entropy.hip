@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int lut_n = (1 << t.lut_bits) + 1;
-    uint2* sl = reinterpret_cast<uint2*>(dsm);                                          // [nrows][lut_n]
+    uint2* sl = reinterpret_cast<uint2*>(dsm);                                          // [nrows][lut_n] bucket table
     uint2* rowinfo = sl + ((t.nrows * lut_n + 1) & ~1);                                  // [nrows] packed row info
     uint16_t* cdf = reinterpret_cast<uint16_t*>(rowinfo + ((t.nrows + 1) & ~1));        // [t.total]
 
@@ -465,12 +465,18 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     const int tid = threadIdx.x;
     for (int i = tid; i < t.total; i += 256) cdf[i] = t.cdf[i];
     {
+        // bucket entries: {first candidate | its start << 16, its frequency}; a candidate that is the row's escape slot
+        // gets frequency 0 so the one range check of the fast path also routes escapes to the slow path
         const uint2* gl = reinterpret_cast<const uint2*>(t.lut);
-        for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = gl[i];
+        for (int i = tid; i < t.nrows * lut_n; i += 256) {
+            uint2 e = gl[i];
+            const int row = i / lut_n;
+            if ((int)(e.x & 0xFFFFu) == t.sizes[row] - 2) e.y = 0u;
+            sl[i] = e;
+        }
     }
-    for (int i = tid; i < t.nrows; i += 256)  // {row start : 16 | cdf_length : 16}, {offset (signed) : 16 | table base : 16}
-        rowinfo[i] = make_uint2((uint32_t)t.row_off[i] | ((uint32_t)t.sizes[i] << 16),
-                                ((uint32_t)t.offsets[i] & 0xFFFFu) | ((uint32_t)(i * lut_n) << 16));
+    for (int i = tid; i < t.nrows; i += 256)  // {row start : 16 | cdf_length : 16}, {offset (signed) : 16 | unused}
+        rowinfo[i] = make_uint2((uint32_t)t.row_off[i] | ((uint32_t)t.sizes[i] << 16), (uint32_t)t.offsets[i] & 0xFFFFu);
     __syncthreads();
     if (tid >= 64) return;
     const int lane = tid;
@@ -491,50 +497,142 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     const int64_t base = sym_base[s] + part_off;
     const int shift = 16 - t.lut_bits;
 
-    // stream words: lane k of wcur holds word wpos0 + k; wnext is the following 64 words (already in flight)
+    // stream words: lane k of wcur holds word wpos0 + k, wnext the following 64 words (already in flight); wi = index
+    // of the next unread word inside wcur.  The window is re-aligned (wi = 0) at the start of every 64-symbol batch and
+    // after every escape, so the ordinary symbols of a batch (at most one word each) can never run past lane 63 and
+    // the hot loop reads words with a bare readlane.
     int64_t wpos0 = pos;
+    int wi = 0;
     uint32_t wcur = (wpos0 + lane < nwords) ? st[wpos0 + lane] : 0u;
     uint32_t wnext = (wpos0 + 64 + lane < nwords) ? st[wpos0 + 64 + lane] : 0u;
-    auto next_word = [&]() -> uint32_t {
-        const uint32_t wv = rdl(wcur, (int)(pos - wpos0));
-        ++pos;
-        if (pos - wpos0 == 64) {
+    auto realign = [&]() {
+        if (wi == 0) return;
+        const int src = ((lane + wi) & 63) << 2;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)wcur);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)wnext);
+        wcur = (lane + wi < 64) ? a : c;
+        wpos0 += wi;
+        wi = 0;
+        wnext = (wpos0 + 64 + lane < nwords) ? st[wpos0 + 64 + lane] : 0u;
+    };
+    auto next_word_checked = [&]() -> uint32_t {  // escape path only: may cross the window
+        if (wi == 64) {
+            wi = 0;
             wpos0 += 64;
             wcur = wnext;
             wnext = (wpos0 + 64 + lane < nwords) ? st[wpos0 + 64 + lane] : 0u;
         }
-        return wv;
+        return rdl(wcur, wi++);
     };
+    typedef __attribute__((address_space(3))) const uint2 lds_u2;
+    const uint32_t dsm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm;
 
     const int64_t nb = (count + 63) >> 6;
     int ti_next = (lane < count) ? idx[base + lane] : 0;
     for (int64_t b = 0; b < nb; ++b) {
         const int cnt = (int)((count - b * 64) < 64 ? (count - b * 64) : 64);
-        const uint2 ri = rowinfo[ti_next];  // per-lane gather of the 64 symbols' row info
-        if (b + 1 < nb) ti_next = ((b + 1) * 64 + lane < count) ? idx[base + (b + 1) * 64 + lane] : 0;  // prefetch
+        const int ti = ti_next;
+        const uint32_t lutbase = dsm_addr + (uint32_t)(ti * lut_n) * 8u;  // LDS address of this lane's symbol's bucket row
+        const uint2 rinfo = rowinfo[ti];  // this lane's row: {start : 16 | cdf_length : 16}, {offset : 16}
         uint32_t outv = 0;
-        for (int j = 0; j < cnt; ++j) {
-            const uint32_t m0 = rdl(ri.x, j), m1 = rdl(ri.y, j);
-            const int ro = (int)(m0 & 0xFFFFu), last = (int)(m0 >> 16) - 2;  // last = escape slot
-            const uint32_t cum = (uint32_t)x & 0xFFFFu;
-            const uint2 ev = sl[(m1 >> 16) + (cum >> shift)];
-            const uint32_t e0 = rfl(ev.x), e1 = rfl(ev.y);
-            int a = (int)(e0 & 0xFFFFu);
-            uint32_t start = e0 >> 16, freq = e1;
-            while (cum - start >= freq) {  // a symbol boundary inside the bucket: walk forward (rare, short)
-                ++a;
-                start += freq;
-                const uint32_t next = (a == last) ? 65536u : rfl((uint32_t)cdf[ro + a + 1]);
-                freq = next - start;
+        int j = 0;
+        realign();  // before the prefetch below: its wait then only covers loads issued a whole batch ago
+        if (b + 1 < nb) ti_next = ((b + 1) * 64 + lane < count) ? idx[base + (b + 1) * 64 + lane] : 0;  // prefetch
+        while (j < cnt) {
+            // hot loop: symbols the bucket entry resolves in one read.  The word window is loop-invariant here; anything
+            // else (a symbol boundary inside the bucket, the escape slot) leaves the loop, is finished below and the loop
+            // is re-entered behind it.
+            // Written in ISA: the loop is one dependent scalar chain (x -> bucket address -> LDS -> x) and every
+            // instruction the compiler adds for control flow costs a full issue slot of the only wave.
+            //   s[84:85] = x, s[86:87] = scratch pair, v[62:63] = bucket entry
+            uint32_t a, start, freq, cum, more;
+            {
+                uint32_t lb, t0, t1, e0;
+                asm volatile(
+                    "s_mov_b64 s[84:85], %[x]\n"
+                    "s_mov_b32 m0, %[j]\n"                    // symbol index lives in m0 (lane select of both lane ops)
+                    "s_cmp_ge_i32 m0, %[cnt]\n"
+                    "s_cbranch_scc1 3f\n"
+                    "1:\n"
+                    "v_readlane_b32 %[lb], %[lutbase], m0\n"
+                    "s_and_b32 %[cum], s84, 0xffff\n"
+                    "s_lshr_b32 %[t0], %[cum], %[shift]\n"
+                    "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n"
+                    "v_mov_b32 v62, %[lb]\n"
+                    "ds_read_b64 v[62:63], v62\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_readfirstlane_b32 %[e0], v62\n"
+                    "v_readfirstlane_b32 %[freq], v63\n"
+                    "s_lshr_b32 %[start], %[e0], 16\n"
+                    "s_sub_u32 %[t0], %[cum], %[start]\n"
+                    "s_cmp_ge_u32 %[t0], %[freq]\n"
+                    "s_cbranch_scc1 2f\n"                      // not resolved by the bucket entry
+                    "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
+                    "s_mul_i32 %[t1], s87, %[freq]\n"
+                    "s_mul_hi_u32 s85, s86, %[freq]\n"
+                    "s_mul_i32 s84, s86, %[freq]\n"
+                    "s_add_u32 %[t1], %[t1], s85\n"
+                    "s_add_u32 s84, s84, %[t0]\n"
+                    "s_addc_u32 s85, %[t1], 0\n"
+                    "s_and_b32 %[a], %[e0], 0xffff\n"
+                    "v_writelane_b32 %[outv], %[a], m0\n"
+                    "s_lshr_b64 s[86:87], s[84:85], 31\n"      // renormalise when x < 2^31
+                    "s_cmp_lg_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 4f\n"
+                    "s_mov_b32 s85, s84\n"
+                    "v_readlane_b32 s84, %[wcur], %[wi]\n"
+                    "s_add_u32 %[wi], %[wi], 1\n"
+                    "4:\n"
+                    "s_add_u32 m0, m0, 1\n"
+                    "s_cmp_lt_i32 m0, %[cnt]\n"
+                    "s_cbranch_scc1 1b\n"
+                    "3:\n"
+                    "s_mov_b32 %[more], 0\n"
+                    "s_branch 5f\n"
+                    "2:\n"
+                    "s_mov_b32 %[more], 1\n"
+                    "s_and_b32 %[a], %[e0], 0xffff\n"
+                    "5:\n"
+                    "s_mov_b64 %[x], s[84:85]\n"
+                    "s_mov_b32 %[j], m0\n"
+                    : [x] "+s"(x), [j] "+s"(j), [wi] "+s"(wi), [outv] "+v"(outv), [a] "=&s"(a), [start] "=&s"(start),
+                      [freq] "=&s"(freq), [cum] "=&s"(cum), [more] "=&s"(more), [lb] "=&s"(lb), [t0] "=&s"(t0),
+                      [t1] "=&s"(t1), [e0] "=&s"(e0)
+                    : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur)
+                    : "m0", "s84", "s85", "s86", "s87", "v62", "v63", "scc", "memory");
             }
-            x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);  // rans64.h:131-133
-            if ((x >> 31) == 0) x = (x << 32) | next_word();
-            int v = a;
-            if (a == last) {  // escape: rans_interface.cpp:323-345 (4-bit nibbles, 80-96)
+            if (!rfl(more)) break;
+            a = rfl(a), start = rfl(start), freq = rfl(freq), cum = rfl(cum);
+            const uint32_t r0 = rdl(rinfo.x, j);
+            const int ro = (int)(r0 & 0xFFFFu), last = (int)(r0 >> 16) - 2;  // last = escape slot
+            if ((int)a == last) freq = 65536u - start;                        // undo the fast-path marker
+            if (cum - start >= freq) {
+                // the symbol lies behind the bucket's first candidate: the 64 lanes compare the next 64 row entries with
+                // cum at once (one LDS read + ballot per 64 candidates instead of one dependent read per candidate)
+                uint32_t lo = a + 1, prev = start;
+                for (;;) {
+                    const int ci = (int)lo + lane;
+                    const uint32_t c = (ci <= last) ? (uint32_t)cdf[ro + ci] : 65536u;  // entry i = start of symbol i
+                    const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c <= cum));
+                    if (k == 64) {
+                        prev = rdl(c, 63);
+                        lo += 64;
+                        continue;
+                    }
+                    a = lo + (uint32_t)k - 1u;
+                    start = k ? rdl(c, k - 1) : prev;
+                    freq = rdl(c, k) - start;
+                    break;
+                }
+            }
+            x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);
+            if ((uint32_t)(x >> 31) == 0u) x = (x << 32) | rdl(wcur, wi++);
+            int v = (int)a;
+            if ((int)a == last) {  // escape: rans_interface.cpp:323-345 (4-bit nibbles, 80-96)
                 auto bits = [&]() -> int {
                     const int val = (int)((uint32_t)x & ESC_MAX);
                     x >>= ESC_BITS;
-                    if ((x >> 31) == 0) x = (x << 32) | next_word();
+                    if ((uint32_t)(x >> 31) == 0u) x = (x << 32) | next_word_checked();
                     return val;
                 };
                 int nib = bits();
@@ -551,14 +649,18 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 v = raw >> 1;
                 if (raw & 1) v = -v - 1;
                 else v += last;
+                realign();  // an escape may have used many words: restore the window invariant
             }
-            outv = wrl((uint32_t)(v + (int)(int16_t)(m1 & 0xFFFFu)), j, outv);
+            outv = wrl((uint32_t)v, j, outv);
+            ++j;
         }
-        if (lane < cnt) sym[base + b * 64 + lane] = (int32_t)outv;  // one coalesced store per 64 symbols
+        // table offset of each symbol (entropy_models' _offset) added by its own lane, then one coalesced store
+        const int off = (int)(int16_t)(rinfo.y & 0xFFFFu);
+        if (lane < cnt) sym[base + b * 64 + lane] = (int32_t)outv + off;
     }
     if (lane == 0) {
         state[2 * s] = x;
-        state[2 * s + 1] = (uint64_t)pos;
+        state[2 * s + 1] = (uint64_t)(wpos0 + wi);
     }
 }
 
