@@ -29,8 +29,9 @@ WORKLOADS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (dense f32 matrix)
 
 
-def cpu_baseline(sd, seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference path: PyTorch-CPU eager + C coder) timed on this host, B=1."""
+def cpu_baseline(sd, H, W, cid, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path: PyTorch-CPU eager + C coder) timed on this host, B=1, on single
+    pairs of the workload's image size (replicate-padded to multiples of 64 like the harness does)."""
     import torch
 
     from oracle import elic_oracle as eo
@@ -40,11 +41,11 @@ def cpu_baseline(sd, seconds_budget=25.0):
     torch.set_num_threads(cores)
     orc = eo.OracleCodec(sd)
     orc.update()
-    H = W = 256
     done, spent, best = 0, 0.0, None
     while spent < seconds_budget and done < 6:
-        r, d = synth.synthetic_batch(1, H, W, config_id=2, start=done)
+        r, d = synth.synthetic_batch(1, H, W, config_id=cid, start=done)
         r, d = torch.from_numpy(r), torch.from_numpy(d)
+        r, d = eo.pad_replicate0(r), eo.pad_replicate0(d)
         t0 = time.time()
         out = orc.compress(r, d)
         orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
@@ -53,7 +54,7 @@ def cpu_baseline(sd, seconds_budget=25.0):
         done += 1
         best = dt if best is None else min(best, dt)
     return {"value": round(H * W / best / 1e6, 5), "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "sample": f"best of {done} single 256x256 pairs, enc+dec, B=1 (tester semantics), torch CPU {cores} threads"}
+            "sample": f"best of {done} single {H}x{W} pairs, enc+dec, B=1 (tester semantics), torch CPU {cores} threads"}
 
 
 def main():
@@ -171,7 +172,7 @@ def main():
                                       "note": "same launches, single engine instance, no concurrent kernels"}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd)
+            res["cpu_baseline"] = cpu_baseline(sd, H, W, cid)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

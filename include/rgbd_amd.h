@@ -117,6 +117,20 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
                          int32_t zh, int32_t zw, float* xr_dev, float* xd_dev, void* stream);
 
 /*
+ * The Bi-CEE entropy stage alone (BASELINE config 4): replaces ELIC_united.compress_united (models/elic_united.py:350-401,
+ * with compress_one_slice :265-348) and decompress_united (:543-578, decompress_one_slice :454-541).  Latents y
+ * [B,M,h,w] and hyper parameters [B,2M,h,w] are NCHW fp32 device tensors (w even); only y-streams are produced
+ * (fetch them with rgbd_elic_stream(kind = 0)); decompress_united writes y_hat [B,M,h,w] per modality.
+ */
+int rgbd_elic_compress_united(rgbd_elic* m, const float* y_rgb_dev, const float* hyper_rgb_dev, const float* y_depth_dev,
+                              const float* hyper_depth_dev, int32_t B, int32_t h, int32_t w, int32_t per_image_streams,
+                              void* stream);
+int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_t* y_rgb_len, int32_t n_y,
+                                const uint8_t* const* y_depth, const int64_t* y_depth_len, const float* hyper_rgb_dev,
+                                const float* hyper_depth_dev, int32_t B, int32_t h, int32_t w, float* yhat_rgb_dev,
+                                float* yhat_depth_dev, void* stream);
+
+/*
  * Eval-mode forward(): replaces ELIC_united.forward / entropy_estimate_united / codeOnePart (models/elic_united.py:94-263)
  * and the likelihood halves of EntropyBottleneck.forward / GaussianConditional.forward (entropy_models.py:391-428,
  * 534-558).  x_hat is NOT clamped (as in the reference); likelihoods are lower-bounded at 1e-9.

@@ -860,9 +860,19 @@ struct rgbd_elic {
         }
     }
 
-    int run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image);
+    // lat != nullptr: the Bi-CEE stage alone (compress_united / decompress_united): latents and hyper parameters come
+    // from the caller as NCHW device tensors, the transforms and the z path are skipped
+    struct Latents {
+        const float* y[2];    // [B,M,h,w]     (compress only)
+        const float* hyp[2];  // [B,2M,h,w]
+        float* yhat[2];       // [B,M,h,w]     (decompress only)
+    };
+    int run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image,
+                     const Latents* lat = nullptr);
     int run_forward(const float* rgb_dev, const float* depth_dev, int B, int H, int W, float* xr_dev, float* xd_dev,
                     float* ly_r, float* ly_d, float* lz_r, float* lz_d);
+    int run_decompress_impl(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
+                            const int64_t* zlen[2], int B, int h, int w, float* xr_dev, float* xd_dev, const Latents* lat);
     int run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
                        const int64_t* zlen[2], int B, int zh, int zw, float* xr_dev, float* xd_dev);
     int ensure_arena(size_t bytes);
@@ -883,9 +893,10 @@ int rgbd_elic::ensure_arena(size_t bytes)
     return RGBD_OK;
 }
 
-int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image)
+int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B, int H, int W, int per_image,
+                            const Latents* lat)
 {
-    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    const int h = H / 16, w = W / 16, zh = lat ? 1 : H / 64, zw = lat ? 1 : W / 64;
     const int Ctot = M;
     const int64_t T = (int64_t)Ctot * h * w;  // y symbols per image per modality
     const int64_t Tz = (int64_t)N * zh * zw;
@@ -927,57 +938,73 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
         HIP_TRY(hipMemsetAsync(err, 0, 256, s));
     }
 
-    // ---- analysis
-    Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
-    if (!dry()) {
-        int r = launch_nchw_to_nhwc16(rgb_dev, B, 3, H, W, rgb.p, rgb.cs, s);
-        if (!r) r = launch_nchw_to_nhwc16(depth_dev, B, 1, H, W, depth.p, depth.cs, s);
-        if (r) return r;
-    }
     Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
-    Act z_r, z_d;
-    {
-        std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
-        if (exclusive_transforms && !dry()) phase.lock();
-        const size_t mark = arena.top;
-        Act yr_t, yd_t;
-        g_a(rgb, depth, &yr_t, &yd_t);
-        copy_ch(yr_t, y_r);
-        copy_ch(yd_t, y_d);
-        arena.top = mark;
-        if (phase.owns_lock()) HIP_TRY(hipStreamSynchronize(s));  // the phase ends when the GPU has finished it
-    }
-    h_a(y_r, y_d, &z_r, &z_d);
-    named["y_r"] = y_r;
-    named["y_d"] = y_d;
-    named["z_r"] = z_r;
-    named["z_d"] = z_d;
-
-    // ---- z: quantise, encode, dequantise (entropy_models.py:437-446)
-    Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
-    if (!dry() && !rc) {
-        const Act* zz[2] = {&z_r, &z_d};
-        const Act* zo[2] = {&zh_r, &zh_d};
-        const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
-        for (int m = 0; m < 2 && !rc; ++m) {
-            float* md = dense_of(med[m]);
-            if (!md) break;
-            int32_t* zs = zsym + (size_t)m * B * Tz;
-            int32_t* zi = zidx + (size_t)m * B * Tz;
-            int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
-            if (!r)
-                r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
-                                       zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
-            if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
-            if (r) fail(r);
-        }
-    }
-    named["zhat_r"] = zh_r;
-    named["zhat_d"] = zh_d;
-
-    // ---- hyper synthesis + Bi-CEE
     Act hyp_r, hyp_d;
-    h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+    if (lat) {
+        hyp_r = alloc(B, h, w, 2 * M);
+        hyp_d = alloc(B, h, w, 2 * M);
+        if (!dry()) {
+            int r = launch_nchw_to_nhwc16(lat->y[0], B, M, h, w, y_r.p, y_r.cs, s);
+            if (!r) r = launch_nchw_to_nhwc16(lat->y[1], B, M, h, w, y_d.p, y_d.cs, s);
+            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[0], B, 2 * M, h, w, hyp_r.p, hyp_r.cs, s);
+            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s);
+            if (r) return r;
+        }
+        named["y_r"] = y_r;
+        named["y_d"] = y_d;
+    } else {
+        // ---- analysis
+        Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
+        if (!dry()) {
+            int r = launch_nchw_to_nhwc16(rgb_dev, B, 3, H, W, rgb.p, rgb.cs, s);
+            if (!r) r = launch_nchw_to_nhwc16(depth_dev, B, 1, H, W, depth.p, depth.cs, s);
+            if (r) return r;
+        }
+        Act z_r, z_d;
+        {
+            std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
+            if (exclusive_transforms && !dry()) phase.lock();
+            const size_t mark = arena.top;
+            Act yr_t, yd_t;
+            g_a(rgb, depth, &yr_t, &yd_t);
+            copy_ch(yr_t, y_r);
+            copy_ch(yd_t, y_d);
+            arena.top = mark;
+            if (phase.owns_lock()) HIP_TRY(hipStreamSynchronize(s));  // the phase ends when the GPU has finished it
+        }
+        h_a(y_r, y_d, &z_r, &z_d);
+        named["y_r"] = y_r;
+        named["y_d"] = y_d;
+        named["z_r"] = z_r;
+        named["z_d"] = z_d;
+
+        // ---- z: quantise, encode, dequantise (entropy_models.py:437-446)
+        Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+        if (!dry() && !rc) {
+            const Act* zz[2] = {&z_r, &z_d};
+            const Act* zo[2] = {&zh_r, &zh_d};
+            const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
+            for (int m = 0; m < 2 && !rc; ++m) {
+                float* md = dense_of(med[m]);
+                if (!md) break;
+                int32_t* zs = zsym + (size_t)m * B * Tz;
+                int32_t* zi = zidx + (size_t)m * B * Tz;
+                int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
+                if (!r)
+                    r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
+                                           zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
+                if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+                if (r) fail(r);
+            }
+        }
+        named["zhat_r"] = zh_r;
+        named["zhat_d"] = zh_d;
+
+        // ---- hyper synthesis + Bi-CEE
+        h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        named["hyper_r"] = hyp_r;
+        named["hyper_d"] = hyp_d;
+    }
     named["hyper_r"] = hyp_r;
     named["hyper_d"] = hyp_d;
     Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
@@ -1100,7 +1127,14 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
 int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y, const uint8_t* const* zs[2],
                               const int64_t* zlen[2], int B, int zh, int zw, float* xr_dev, float* xd_dev)
 {
-    const int h = zh * 4, w = zw * 4, H = zh * 64, W = zw * 64;
+    return run_decompress_impl(ys, ylen, n_y, zs, zlen, B, zh * 4, zw * 4, xr_dev, xd_dev, nullptr);
+}
+
+int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* ylen[2], int n_y,
+                                   const uint8_t* const* zs[2], const int64_t* zlen[2], int B, int h, int w,
+                                   float* xr_dev, float* xd_dev, const Latents* lat)
+{
+    const int zh = lat ? 1 : h / 4, zw = lat ? 1 : w / 4, H = h * 16, W = w * 16;
     const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
     const int per_image = (n_y == B && !(B == 1)) ? 1 : (n_y == 1 ? (B == 1 ? 1 : 0) : -1);
     if (per_image < 0) return RGBD_EINVAL;
@@ -1109,7 +1143,7 @@ int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2
     rc = 0;
 
     // ---- upload streams: words region = [y rgb | y depth | z rgb | z depth]
-    const int ns_y = n_y, ns_z = B;
+    const int ns_y = n_y, ns_z = lat ? 0 : B;
     std::vector<int64_t> hmeta;  // y: off[2][ns_y], len[2][ns_y]; z: off[2][B], len[2][B]; y base[B]; z base[B]
     std::vector<uint32_t> hwords;
     auto push_streams = [&](const uint8_t* const* arr, const int64_t* len, int n, std::vector<int64_t>& off,
@@ -1129,7 +1163,7 @@ int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2
         const int r = push_streams(ys[m], ylen[m], ns_y, yoff, ylen_w);
         if (r) return r;
     }
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 2 && ns_z; ++m) {
         const int r = push_streams(zs[m], zlen[m], ns_z, zoff, zlen_w);
         if (r) return r;
     }
@@ -1164,34 +1198,46 @@ int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2
     const int64_t* d_ybase = meta64 + o_ybase;
     const int64_t* d_zbase = meta64 + o_zbase;
 
-    // ---- z decode (entropy_models.py:442-446)
-    Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
-    if (!dry()) {
-        const Act* zo[2] = {&zh_r, &zh_d};
-        const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
-        for (int m = 0; m < 2 && !rc; ++m) {
-            float* md = dense_of(med[m]);
-            if (!md) break;
-            int32_t* zs_ = zsym + (size_t)m * B * Tz;
-            int32_t* zi_ = zidx + (size_t)m * B * Tz;
-            // indexes = channel id in (c, row, col) order: the quantiser's index writer on a zeroed tensor
-            int r = launch_fill_zero(zo[m]->p, zo[m]->elems(), s);
-            if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s);
-            if (!r)
-                r = launch_rans_decode(words, d_zoff + (size_t)m * ns_z, d_zlen + (size_t)m * ns_z, ns_z,
-                                       state + (size_t)4 * ns_y + (size_t)m * ns_z * 2, 1, zi_, zs_, d_zbase, 0, Tz,
-                                       tables[2 + m].d, s);
-            if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
-            if (r) fail(r);
-        }
-    }
-    named["zhat_r"] = zh_r;
-    named["zhat_d"] = zh_d;
-
     Act hyp_r, hyp_d;
-    h_s(zh_r, zh_d, &hyp_r, &hyp_d);
-    named["hyper_r"] = hyp_r;
-    named["hyper_d"] = hyp_d;
+    if (lat) {
+        hyp_r = alloc(B, h, w, 2 * M);
+        hyp_d = alloc(B, h, w, 2 * M);
+        if (!dry()) {
+            int r = launch_nchw_to_nhwc16(lat->hyp[0], B, 2 * M, h, w, hyp_r.p, hyp_r.cs, s);
+            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s);
+            if (r) return r;
+        }
+        named["hyper_r"] = hyp_r;
+        named["hyper_d"] = hyp_d;
+    } else {
+        // ---- z decode (entropy_models.py:442-446)
+        Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+        if (!dry()) {
+            const Act* zo[2] = {&zh_r, &zh_d};
+            const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
+            for (int m = 0; m < 2 && !rc; ++m) {
+                float* md = dense_of(med[m]);
+                if (!md) break;
+                int32_t* zs_ = zsym + (size_t)m * B * Tz;
+                int32_t* zi_ = zidx + (size_t)m * B * Tz;
+                // indexes = channel id in (c, row, col) order: the quantiser's index writer on a zeroed tensor
+                int r = launch_fill_zero(zo[m]->p, zo[m]->elems(), s);
+                if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s);
+                if (!r)
+                    r = launch_rans_decode(words, d_zoff + (size_t)m * ns_z, d_zlen + (size_t)m * ns_z, ns_z,
+                                           state + (size_t)4 * ns_y + (size_t)m * ns_z * 2, 1, zi_, zs_, d_zbase, 0, Tz,
+                                           tables[2 + m].d, s);
+                if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+                if (r) fail(r);
+            }
+        }
+        named["zhat_r"] = zh_r;
+        named["zhat_d"] = zh_d;
+
+        h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        named["hyper_r"] = hyp_r;
+        named["hyper_d"] = hyp_d;
+    }
     Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
     named["yhat_r"] = yhat_r;
     named["yhat_d"] = yhat_d;
@@ -1208,6 +1254,13 @@ int rgbd_elic::run_decompress(const uint8_t* const* ys[2], const int64_t* ylen[2
     cd.state = state;
     cd.nstreams = ns_y;
     bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
+    if (lat) {  // decompress_united ends here: y_hat back to the caller (NCHW)
+        if (rc) return rc;
+        if (dry()) return RGBD_OK;
+        int r = launch_nhwc_to_nchw_clamp(yhat_r.p, B, M, h, w, yhat_r.cs, lat->yhat[0], 0, s);
+        if (!r) r = launch_nhwc_to_nchw_clamp(yhat_d.p, B, M, h, w, yhat_d.cs, lat->yhat[1], 0, s);
+        return r;
+    }
 
     Act xr, xd;
     std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
@@ -1842,6 +1895,61 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
     r = m->ensure_arena(m->arena.peak);
     if (r) return r;
     r = m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
+    if (m->profile && !r) {
+        if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
+        m->profile_collect();
+    }
+    return r;
+}
+
+int rgbd_elic_compress_united(rgbd_elic* m, const float* y_rgb_dev, const float* hyper_rgb_dev, const float* y_depth_dev,
+                              const float* hyper_depth_dev, int32_t B, int32_t h, int32_t w, int32_t per_image_streams,
+                              void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (!y_rgb_dev || !hyper_rgb_dev || !y_depth_dev || !hyper_depth_dev || B <= 0 || h <= 0 || w <= 0 || (w & 1))
+        return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    const int per_image = (per_image_streams || B == 1) ? 1 : 0;
+    rgbd_elic::Latents lat = {{y_rgb_dev, y_depth_dev}, {hyper_rgb_dev, hyper_depth_dev}, {nullptr, nullptr}};
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_compress(nullptr, nullptr, B, h * 16, w * 16, per_image, &lat);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    r = m->run_compress(nullptr, nullptr, B, h * 16, w * 16, per_image, &lat);
+    if (m->profile) m->profile_collect();
+    return r;
+}
+
+int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_t* y_rgb_len, int32_t n_y,
+                                const uint8_t* const* y_depth, const int64_t* y_depth_len, const float* hyper_rgb_dev,
+                                const float* hyper_depth_dev, int32_t B, int32_t h, int32_t w, float* yhat_rgb_dev,
+                                float* yhat_depth_dev, void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (!y_rgb || !y_depth || !hyper_rgb_dev || !hyper_depth_dev || !yhat_rgb_dev || !yhat_depth_dev || B <= 0 || h <= 0 ||
+        w <= 0 || (w & 1))
+        return RGBD_EINVAL;
+    if (n_y != 1 && n_y != B) return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    const uint8_t* const* ys[2] = {y_rgb, y_depth};
+    const int64_t* yl[2] = {y_rgb_len, y_depth_len};
+    const uint8_t* const* zs[2] = {nullptr, nullptr};
+    const int64_t* zl[2] = {nullptr, nullptr};
+    rgbd_elic::Latents lat = {{nullptr, nullptr}, {hyper_rgb_dev, hyper_depth_dev}, {yhat_rgb_dev, yhat_depth_dev}};
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_decompress_impl(ys, yl, n_y, zs, zl, B, h, w, nullptr, nullptr, &lat);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    r = m->run_decompress_impl(ys, yl, n_y, zs, zl, B, h, w, nullptr, nullptr, &lat);
     if (m->profile && !r) {
         if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
         m->profile_collect();

@@ -200,20 +200,76 @@ class ELIC_united:
         L = lib()
         check(L.rgbd_elic_compress(self._h, ctypes.c_void_p(rgb.data_ptr()), ctypes.c_void_p(depth.data_ptr()), B, H, W,
                                    1 if self.per_image_streams else 0, self._stream_ptr()), "compress")
-        out = []
-        for mod in (0, 1):
-            lists = []
-            for kind in (0, 1):
-                n = L.rgbd_elic_stream_count(self._h, mod, kind)
-                strings = []
-                for i in range(n):
-                    p = ctypes.POINTER(ctypes.c_uint8)()
-                    ln = ctypes.c_int64(0)
-                    check(L.rgbd_elic_stream(self._h, mod, kind, i, ctypes.byref(p), ctypes.byref(ln)), "stream")
-                    strings.append(ctypes.string_at(p, ln.value))
-                lists.append(strings)
-            out.append(lists)
+        out = [[self._fetch_streams(mod, kind) for kind in (0, 1)] for mod in (0, 1)]
         return {"r_strings": out[0], "d_strings": out[1], "shape": torch.Size((H // 64, W // 64))}
+
+    def _fetch_streams(self, mod, kind):
+        L = lib()
+        strings = []
+        for i in range(L.rgbd_elic_stream_count(self._h, mod, kind)):
+            p = ctypes.POINTER(ctypes.c_uint8)()
+            ln = ctypes.c_int64(0)
+            check(L.rgbd_elic_stream(self._h, mod, kind, i, ctypes.byref(p), ctypes.byref(ln)), "stream")
+            strings.append(ctypes.string_at(p, ln.value))
+        return strings
+
+    @staticmethod
+    def _pack_strings(strings):
+        bufs = [np.frombuffer(bytes(s), dtype=np.uint8) for s in strings]
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        ptrs = (u8p * len(bufs))(*[b.ctypes.data_as(u8p) for b in bufs])
+        lens = (ctypes.c_int64 * len(bufs))(*[int(b.shape[0]) for b in bufs])
+        return bufs, ptrs, lens
+
+    # ---- the Bi-CEE stage alone (models/elic_united.py:350-401, 543-578) ------------------------------------
+    def _check_latents(self, y, hyper, what):
+        if y is not None and (y.dim() != 4 or y.size(1) != self.M):
+            raise ValueError(f"{what} y: expected [B,{self.M},h,w]")
+        if hyper.dim() != 4 or hyper.size(1) != 2 * self.M:
+            raise ValueError(f"{what} hyper parameters: expected [B,{2 * self.M},h,w]")
+        if y is not None and (y.shape[0] != hyper.shape[0] or y.shape[-2:] != hyper.shape[-2:]):
+            raise ValueError(f"{what}: y and hyper parameters disagree in batch or spatial size")
+        if hyper.shape[-1] % 2:
+            raise ValueError("latent width must be even (checkerboard packing, utils/ckbd.py:51-64)")
+
+    def compress_united(self, rgb_y, rgb_hyper_params, depth_y, depth_hyper_params):
+        """Latents + hyper parameters -> (rgb_y_strings, depth_y_strings), each a list of byte strings (one for the whole
+        batch like the reference, or one per image when per_image_streams is set)."""
+        self._ready()
+        self._check_latents(rgb_y, rgb_hyper_params, "rgb")
+        self._check_latents(depth_y, depth_hyper_params, "depth")
+        if rgb_y.shape != depth_y.shape:
+            raise ValueError("rgb and depth latents must have the same shape")
+        t = [x.to(self._device, torch.float32).contiguous() for x in (rgb_y, rgb_hyper_params, depth_y, depth_hyper_params)]
+        B, _, h, w = t[0].shape
+        p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        check(lib().rgbd_elic_compress_united(self._h, p(t[0]), p(t[1]), p(t[2]), p(t[3]), B, h, w,
+                                              1 if self.per_image_streams else 0, self._stream_ptr()), "compress_united")
+        return self._fetch_streams(0, 0), self._fetch_streams(1, 0)
+
+    def decompress_united(self, rgb_y_strings, rgb_hyper_params, depth_y_strings, depth_hyper_params):
+        """(y strings, hyper parameters) per modality -> (rgb_y_hat, depth_y_hat).  A string argument may be one bytes
+        object (what the reference passes: strings[0][0]) or a list of them (one per image)."""
+        self._ready()
+        self._check_latents(None, rgb_hyper_params, "rgb")
+        self._check_latents(None, depth_hyper_params, "depth")
+        y_r = [rgb_y_strings] if isinstance(rgb_y_strings, (bytes, bytearray)) else list(rgb_y_strings)
+        y_d = [depth_y_strings] if isinstance(depth_y_strings, (bytes, bytearray)) else list(depth_y_strings)
+        hr = rgb_hyper_params.to(self._device, torch.float32).contiguous()
+        hd = depth_hyper_params.to(self._device, torch.float32).contiguous()
+        B, _, h, w = hr.shape
+        if hd.shape != hr.shape or len(y_r) != len(y_d) or len(y_r) not in (1, B):
+            raise ValueError("Invalid strings parameters")
+        out_r = torch.empty((B, self.M, h, w), dtype=torch.float32, device=self._device)
+        out_d = torch.empty_like(out_r)
+        k1, pyr, lyr = self._pack_strings(y_r)
+        k2, pyd, lyd = self._pack_strings(y_d)
+        p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+        check(lib().rgbd_elic_decompress_united(self._h, pyr, lyr, len(y_r), pyd, lyd, p(hr), p(hd), B, h, w, p(out_r),
+                                                p(out_d), self._stream_ptr()), "decompress_united")
+        torch.cuda.synchronize()
+        del k1, k2
+        return out_r, out_d
 
     def decompress(self, rgb_strings, depth_strings, shape):
         self._ready()
@@ -228,13 +284,7 @@ class ELIC_united:
         xr = torch.empty((B, 3, zh * 64, zw * 64), dtype=torch.float32, device=self._device)
         xd = torch.empty((B, 1, zh * 64, zw * 64), dtype=torch.float32, device=self._device)
 
-        def pack(strings):
-            bufs = [np.frombuffer(bytes(s), dtype=np.uint8) for s in strings]
-            u8p = ctypes.POINTER(ctypes.c_uint8)
-            ptrs = (u8p * len(bufs))(*[b.ctypes.data_as(u8p) for b in bufs])
-            lens = (ctypes.c_int64 * len(bufs))(*[int(b.shape[0]) for b in bufs])
-            return bufs, ptrs, lens
-
+        pack = self._pack_strings
         k1, pyr, lyr = pack(y_r)
         k2, pyd, lyd = pack(y_d)
         k3, pzr, lzr = pack(z_r)

@@ -151,3 +151,12 @@ def synthetic_batch(B: int, H: int, W: int, config_id: int = 0, start: int = 0, 
         rs.append(r)
         ds.append(d)
     return np.stack(rs), np.stack(ds)
+
+
+def synthetic_latents(B: int, h: int, w: int, M: int = 320, seed: int = 0):
+    """Inputs of the Bi-CEE stage in isolation (BASELINE config 4, SURVEY §8d "C4"): y ~ N(0, 4^2) [B,M,h,w] and hyper
+    parameters ~ N(0, 1) [B,2M,h,w] per modality.  Returns (rgb_y, rgb_hyper, depth_y, depth_hyper) as float32."""
+    return (normal_like(f"c4.rgb_y.{B}x{h}x{w}", seed, (B, M, h, w), 4.0),
+            normal_like(f"c4.rgb_hyper.{B}x{h}x{w}", seed, (B, 2 * M, h, w), 1.0),
+            normal_like(f"c4.depth_y.{B}x{h}x{w}", seed, (B, M, h, w), 4.0),
+            normal_like(f"c4.depth_hyper.{B}x{h}x{w}", seed, (B, 2 * M, h, w), 1.0))

@@ -374,6 +374,14 @@ class OracleCodec:
         zs_d, _ = self._z_compress("depth", z_d)
         zh_d = self._z_decompress("depth", zs_d, z_d.shape[-2:])
         hyp_r, hyp_d = h_s(self.sd, zh_r, zh_d)
+        ys_r, ys_d = self.compress_united(y_r, hyp_r, y_d, hyp_d)
+        if self.trace is not None:
+            self.trace.update({"y_r": y_r, "y_d": y_d, "z_r": z_r, "z_d": z_d, "zhat_r": zh_r, "zhat_d": zh_d,
+                               "hyper_r": hyp_r, "hyper_d": hyp_d})
+        return {"r_strings": [ys_r, zs_r], "d_strings": [ys_d, zs_d], "shape": tuple(z_r.shape[-2:])}
+
+    @torch.no_grad()
+    def compress_united(self, y_r, hyp_r, y_d, hyp_d):  # elic_united.py:350-401
         enc = {"rgb": ([], []), "depth": ([], [])}
         yhat_r, yhat_d = [], []
         for i in range(len(self.slice_ch)):
@@ -382,11 +390,18 @@ class OracleCodec:
         for mod in ("rgb", "depth"):
             ys[mod] = coder.rans_encode(np.concatenate(enc[mod][0]), np.concatenate(enc[mod][1]), self.gc)
         if self.trace is not None:
-            self.trace.update({"y_r": y_r, "y_d": y_d, "z_r": z_r, "z_d": z_d, "zhat_r": zh_r, "zhat_d": zh_d,
-                               "hyper_r": hyp_r, "hyper_d": hyp_d, "yhat_r": torch.cat(yhat_r, 1),
-                               "yhat_d": torch.cat(yhat_d, 1)})
-        return {"r_strings": [[ys["rgb"]], zs_r], "d_strings": [[ys["depth"]], zs_d],
-                "shape": tuple(z_r.shape[-2:])}
+            self.trace.update({"yhat_r": torch.cat(yhat_r, 1), "yhat_d": torch.cat(yhat_d, 1)})
+        return [ys["rgb"]], [ys["depth"]]
+
+    @torch.no_grad()
+    def decompress_united(self, y_string_r, hyp_r, y_string_d, hyp_d):  # elic_united.py:543-578
+        dec = {"rgb": coder.RansDecoder(), "depth": coder.RansDecoder()}
+        dec["rgb"].set_stream(y_string_r)
+        dec["depth"].set_stream(y_string_d)
+        yhat_r, yhat_d = [], []
+        for i in range(len(self.slice_ch)):
+            self._slice(i, None, None, hyp_r, hyp_d, yhat_r, yhat_d, None, dec)
+        return torch.cat(yhat_r, 1), torch.cat(yhat_d, 1)
 
     # -- eval-mode forward: elic_united.py:94-263 (quant == "ste": round in eval), entropy_models.py:391-428, 534-558
     def _eb_forward(self, mod, z):
@@ -459,13 +474,8 @@ class OracleCodec:
         zh_r = self._z_decompress("rgb", r_strings[1], shape)
         zh_d = self._z_decompress("depth", d_strings[1], shape)
         hyp_r, hyp_d = h_s(self.sd, zh_r, zh_d)
-        dec = {"rgb": coder.RansDecoder(), "depth": coder.RansDecoder()}
-        dec["rgb"].set_stream(r_strings[0][0])
-        dec["depth"].set_stream(d_strings[0][0])
-        yhat_r, yhat_d = [], []
-        for i in range(len(self.slice_ch)):
-            self._slice(i, None, None, hyp_r, hyp_d, yhat_r, yhat_d, None, dec)
-        xr, xd = g_s(self.sd, torch.cat(yhat_r, 1), torch.cat(yhat_d, 1))
+        yhat_r, yhat_d = self.decompress_united(r_strings[0][0], hyp_r, d_strings[0][0], hyp_d)
+        xr, xd = g_s(self.sd, yhat_r, yhat_d)
         return {"x_hat": {"r": xr.clamp_(0, 1), "d": xd.clamp_(0, 1)}, "cost_time": time.process_time() - t0}
 
 

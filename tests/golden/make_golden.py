@@ -7,6 +7,7 @@ Outputs (data only -- inputs are regenerated from rgbd_amd.synth, never stored):
     tests/golden/coder_kat.npz      pure-coder known answers from the reference's C++ (KAT tiny / B2 / tables)
     tests/golden/model_*.npz        ELIC_united streams, latents and reconstructions from the reference's
                                     compress()/decompress() on synthetic weights + inputs
+    tests/golden/bicee_*.npz        Bi-CEE stage alone (BASELINE config 4): compress_united / decompress_united outputs
     tests/golden/harness.json       pad / container / bpp / PSNR tuples (TesterUnited arithmetic)
 
 The reference runs on PyTorch CPU kernels; float tensors are therefore specific to this container's
@@ -163,6 +164,19 @@ def model_case(net, synth, name, B, H, W, config_id, full: bool):
     return g
 
 
+def bicee_case(net, synth, name, B, h, w, seed):
+    """BASELINE config 4: the reference's compress_united / decompress_united on given latents + hyper parameters."""
+    yr, hr, yd, hd = [torch.from_numpy(a) for a in synth.synthetic_latents(B, h, w, 320, seed)]
+    with torch.no_grad():
+        sr, sdp = net.compress_united(yr, hr, yd, hd)
+        yhat_r, yhat_d = net.decompress_united(sr[0], hr, sdp[0], hd)
+    g = {"B": B, "h": h, "w": w, "seed": seed, "r_y": np.frombuffer(sr[0], np.uint8), "d_y": np.frombuffer(sdp[0], np.uint8),
+         "yhat_r": yhat_r.numpy(), "yhat_d": yhat_d.numpy()}
+    np.savez_compressed(os.path.join(HERE, f"bicee_{name}.npz"), **g)
+    print("bicee", name, len(sr[0]), len(sdp[0]), float(yhat_r.abs().mean()))
+    return g
+
+
 def main():
     ELIC, model_config, ext = rl.load_reference()
     import rgbd_amd  # noqa: F401
@@ -187,6 +201,10 @@ def main():
                          "shape": g["shape"].tolist(), "psnr": g["psnr"].tolist(),
                          "bpp": g["bpp"].tolist() if "bpp" in g else None,
                          "y_len": [int(g["r_y"].shape[0]), int(g["d_y"].shape[0])]}
+    for name, B, h, w, seed in (("c4_16x16", 1, 16, 16, 4), ("c4_b2_8x12", 2, 8, 12, 5)):
+        g = bicee_case(net, synth, name, B, h, w, seed)
+        summary["bicee_" + name] = {"B": B, "h": h, "w": w, "seed": seed,
+                                    "y_len": [int(g["r_y"].shape[0]), int(g["d_y"].shape[0])]}
     with open(os.path.join(HERE, "harness.json"), "w") as f:
         json.dump({"weights_seed": 0, "torch": torch.__version__, "cases": summary}, f, indent=1)
 

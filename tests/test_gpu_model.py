@@ -51,6 +51,39 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def _walk_parts(tr, gsym, gidx, orc, y_of):
+    """Flips against the oracle's float path: walk the 20 parts in coding order.  A flipped symbol changes every later
+    context, so only the FIRST differing part is informative: each difference there must sit on a decision boundary
+    (|frac(y - mu)| = 0.5 or sigma on a scale-table threshold) to within the float tolerance.  Returns the number of
+    parts identical to the oracle before the first flip."""
+    pos = {0: 0, 1: 0}
+    table = eo.scale_table().numpy()
+    clean_parts = 0
+    for p in tr["parts"]:
+        mod = 0 if p["mod"] == "rgb" else 1
+        n = p["symbols"].numel()
+        a, b = pos[mod], pos[mod] + n
+        pos[mod] = b
+        osym, oidx = p["symbols"].reshape(-1).numpy(), p["indexes"].reshape(-1).numpy()
+        ds, di = gsym[mod][a:b] != osym, gidx[mod][a:b] != oidx
+        if not ds.any() and not di.any():
+            clean_parts += 1
+            continue
+        assert ds.sum() + di.sum() <= max(4, n // 1000), (p["slice"], p["mod"], p["anchor"], int(ds.sum()), int(di.sum()))
+        if ds.any():
+            yv = eo.pack(y_of[mod][:, sum(orc.slice_ch[:p["slice"]]):sum(orc.slice_ch[:p["slice"] + 1])],
+                         p["anchor"]).reshape(-1).numpy()
+            v = yv - p["means"].reshape(-1).numpy()
+            frac = np.abs(v - np.round(v))[ds]
+            assert (frac > 0.5 - 2e-3).all(), frac
+        if di.any():
+            sc = np.maximum(p["scales"].reshape(-1).numpy()[di], 0.11)
+            near = np.min(np.abs(sc[:, None] - table[None, :]) / table[None, :], axis=1)
+            assert (near < 1e-4).all(), near
+        break
+    return clean_parts
+
+
 def test_case_a_layers_and_streams(net, orc):
     g = load_golden("a_128x192")
     r, d, rp, dp = _inputs(1, 128, 192, 9)
@@ -73,34 +106,7 @@ def test_case_a_layers_and_streams(net, orc):
     for mod, key in ((0, "r_strings"), (1, "d_strings")):
         gsym[mod], gidx[mod] = net.debug_symbols(mod)
         assert coder.rans_encode(gsym[mod], gidx[mod], orc.gc) == out[key][0][0]
-    # flips against the oracle's float path: walk the 20 parts in coding order.  A flipped symbol changes every later
-    # context, so only the FIRST differing part is informative: each difference there must sit on a decision boundary
-    # (|frac(y - mu)| = 0.5 or sigma on a scale-table threshold) to within the float tolerance.
-    pos = {0: 0, 1: 0}
-    table = eo.scale_table().numpy()
-    clean_parts = 0
-    for p in tr["parts"]:
-        mod = 0 if p["mod"] == "rgb" else 1
-        n = p["symbols"].numel()
-        a, b = pos[mod], pos[mod] + n
-        pos[mod] = b
-        osym, oidx = p["symbols"].reshape(-1).numpy(), p["indexes"].reshape(-1).numpy()
-        ds, di = gsym[mod][a:b] != osym, gidx[mod][a:b] != oidx
-        if not ds.any() and not di.any():
-            clean_parts += 1
-            continue
-        assert ds.sum() + di.sum() <= max(4, n // 1000), (p["slice"], p["mod"], p["anchor"], int(ds.sum()), int(di.sum()))
-        if ds.any():
-            yv = eo.pack(tr["y_r" if mod == 0 else "y_d"][:, sum(orc.slice_ch[:p["slice"]]):sum(orc.slice_ch[:p["slice"] + 1])],
-                         p["anchor"]).reshape(-1).numpy()
-            v = yv - p["means"].reshape(-1).numpy()
-            frac = np.abs(v - np.round(v))[ds]
-            assert (frac > 0.5 - 2e-3).all(), frac
-        if di.any():
-            sc = np.maximum(p["scales"].reshape(-1).numpy()[di], 0.11)
-            near = np.min(np.abs(sc[:, None] - table[None, :]) / table[None, :], axis=1)
-            assert (near < 1e-4).all(), near
-        break
+    clean_parts = _walk_parts(tr, gsym, gidx, orc, {0: tr["y_r"], 1: tr["y_d"]})
     print(f"parts identical to the oracle float path before the first boundary flip: {clean_parts} of {len(tr['parts'])}")
     assert clean_parts >= 1
     same = out["r_strings"] == ref["r_strings"] and out["d_strings"] == ref["d_strings"]
@@ -122,6 +128,60 @@ def test_case_a_layers_and_streams(net, orc):
     assert abs(eo.psnr(xr, r) - eo.psnr(oxr, r)) < 1e-4 and abs(eo.psnr(xd, d) - eo.psnr(oxd, d)) < 1e-4
     if same:
         assert abs(eo.psnr(xr, r) - g["psnr"][0]) < 1e-4 and abs(eo.psnr(xd, d) - g["psnr"][1]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["c4_16x16", "c4_b2_8x12"])
+def test_bicee_alone(net, orc, name):
+    """BASELINE config 4: the Bi-CEE stage in isolation (compress_united / decompress_united on given latents and hyper
+    parameters; the largest coding unit is the 192-channel slice) against the oracle and the reference's golden."""
+    import os
+
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"bicee_{name}.npz"))
+    B, h, w = int(g["B"]), int(g["h"]), int(g["w"])
+    yr, hr, yd, hd = [torch.from_numpy(a) for a in synth.synthetic_latents(B, h, w, 320, int(g["seed"]))]
+    net.per_image_streams = False  # the reference's format: one stream per modality for the whole batch
+    try:
+        sr, sdp = net.compress_united(yr.cuda(), hr.cuda(), yd.cuda(), hd.cuda())
+        assert len(sr) == 1 and len(sdp) == 1
+        # integer stage: the oracle coder reproduces the GPU streams from the GPU's own symbols / indexes
+        gsym, gidx = {}, {}
+        for mod, strings in ((0, sr), (1, sdp)):
+            gsym[mod], gidx[mod] = net.debug_symbols(mod)
+            assert gsym[mod].shape[0] == B * 320 * h * w
+            assert coder.rans_encode(gsym[mod], gidx[mod], orc.gc) == strings[0]
+        # float stage vs the oracle, part by part
+        orc.trace = {}
+        osr, osd = orc.compress_united(yr, hr, yd, hd)
+        tr, orc.trace = orc.trace, None
+        clean = _walk_parts(tr, gsym, gidx, orc, {0: yr, 1: yd})
+        same = sr == osr and sdp == osd
+        print(f"bicee {name}: parts identical before the first boundary flip: {clean} of {len(tr['parts'])};",
+              "streams identical to oracle:", same, "| to the reference golden:",
+              sr[0] == g["r_y"].tobytes() and sdp[0] == g["d_y"].tobytes())
+        assert clean >= 1
+        assert abs(len(sr[0]) - g["r_y"].shape[0]) <= 64 and abs(len(sdp[0]) - g["d_y"].shape[0]) <= 64
+        # the decoder reproduces the encoder's y_hat bit for bit
+        yhat_enc = [net.debug_tensor("yhat_r").copy(), net.debug_tensor("yhat_d").copy()]
+        yhat_r, yhat_d = net.decompress_united(sr[0], hr.cuda(), sdp[0], hd.cuda())
+        assert np.array_equal(yhat_r.cpu().numpy(), yhat_enc[0]) and np.array_equal(yhat_d.cpu().numpy(), yhat_enc[1])
+        if same:
+            assert _rel(yhat_enc[0], g["yhat_r"]) < 2e-5 and _rel(yhat_enc[1], g["yhat_d"]) < 2e-5
+        # per-image streams == B separate calls
+        if B > 1:
+            net.per_image_streams = True
+            pr, pd = net.compress_united(yr.cuda(), hr.cuda(), yd.cuda(), hd.cuda())
+            assert len(pr) == B and len(pd) == B
+            for i in range(B):
+                one_r, one_d = net.compress_united(yr[i:i + 1].cuda(), hr[i:i + 1].cuda(), yd[i:i + 1].cuda(), hd[i:i + 1].cuda())
+                assert one_r[0] == pr[i] and one_d[0] == pd[i]
+            yh_r, yh_d = net.decompress_united(pr, hr.cuda(), pd, hd.cuda())
+            assert np.array_equal(yh_r.cpu().numpy(), yhat_enc[0]) and np.array_equal(yh_d.cpu().numpy(), yhat_enc[1])
+        with pytest.raises(ValueError):
+            net.compress_united(yr[:, :100].cuda(), hr.cuda(), yd.cuda(), hd.cuda())
+    finally:
+        net.per_image_streams = False
 
 
 def test_batch_formats_and_invariance(net, orc):
