@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workers", type=int, default=8, help="engine instances (HIP streams) per GPU; 1 = no overlap")
+    ap.add_argument("--workers", type=int, default=12, help="engine instances (HIP streams) per GPU; 1 = no overlap")
     args = ap.parse_args()
 
     import torch

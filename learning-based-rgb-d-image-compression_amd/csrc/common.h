@@ -66,15 +66,24 @@ struct ConvArgs {
     TapTable taps;
 };
 
-// split factor of a layer: a function of the layer geometry only (never of batch or image size), so the summation
-// order of every output is fixed once and for all
-static inline int conv_splitk_for(int cin_pad, int taps_per_phase)
+// split factor of a layer: a function of the layer and of the per-image output grid only -- never of the batch size -- so
+// the summation order of every output is the same in the encoder, the decoder and for any batching of the same images
+extern char g_conv_force[64];
+static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_per_image, int nphase)
 {
     const long K = (long)cin_pad * taps_per_phase;
-    int s = (int)((K + 800) / 1600);
-    if (s < 1) s = 1;
-    if (s > 8) s = 8;
+    int s;
+    if (nphase == 1 && out_px_per_image <= 512) {
+        // 16x16-class latent grids (tools/tile_sweep.py): few output tiles, so the reduction is cut until every CU has
+        // work; 1x1 layers (pure weight streaming) profit from the deepest cut
+        if (taps_per_phase == 1) s = K >= 1500 ? 8 : (K >= 700 ? 4 : (K >= 350 ? 2 : 1));
+        else s = K >= 5000 ? 8 : (K >= 1000 ? 4 : (K >= 500 ? 2 : 1));
+    } else {
+        s = (int)((K + 800) / 1600);
+        if (s > 8) s = 8;
+    }
     if (s > cin_pad / 16) s = cin_pad / 16;
+    if (s < 1) s = 1;
     return s;
 }
 

@@ -502,6 +502,8 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
 
 static int launch_conv_main(const ConvArgs& a, hipStream_t s);
 
+char g_conv_force[64] = {0};  // rgbd_debug_force_tile (tools/tile_sweep.py)
+
 int launch_conv(const ConvArgs& a_in, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -524,7 +526,8 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;
     if (a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
     Choice c = choose(a);
-    static const char* force = getenv("RGBD_CONV_FORCE");  // "wm,mt,nt[,kc[,pf]]" -- tuning experiments only
+    static const char* force_env = getenv("RGBD_CONV_FORCE");  // "wm,mt,nt[,kc[,dma]]" -- tuning experiments only
+    const char* force = g_conv_force[0] ? g_conv_force : force_env;
     if (force) {
         int wm = c.wm, mt = c.mt, nt = c.nt, kc = c.kc, dm = c.dma;
         sscanf(force, "%d,%d,%d,%d,%d", &wm, &mt, &nt, &kc, &dm);

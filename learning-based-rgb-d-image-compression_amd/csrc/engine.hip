@@ -370,7 +370,8 @@ struct rgbd_elic {
                 int mt = 1;
                 for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
                 static const bool nosplit = getenv("RGBD_NO_SPLITK") != nullptr;  // experiment only
-                a.splitk = g_force_splitk > 0 ? g_force_splitk : (nosplit ? 1 : conv_splitk_for(a.cin_pad, mt));
+                a.splitk = g_force_splitk > 0 ? g_force_splitk
+                                              : (nosplit ? 1 : conv_splitk_for(a.cin_pad, mt, (long)OH * OW, a.nphase));
                 break;
             }
         const size_t pmark = arena.top;
@@ -1542,6 +1543,12 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
     return rc;
 }
 
+int rgbd_debug_force_tile(const char* cfg)
+{
+    snprintf(g_conv_force, sizeof(g_conv_force), "%s", cfg ? cfg : "");
+    return RGBD_OK;
+}
+
 int rgbd_debug_force_splitk(int32_t s)
 {
     g_force_splitk = s;
@@ -1604,7 +1611,7 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
         int mt = 1;
         for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
         a.splitk = g_force_splitk > 0 ? std::min(g_force_splitk, pc.cin_pad / 16)
-                                      : (g_force_splitk < 0 ? conv_splitk_for(pc.cin_pad, mt) : 1);
+                                      : (g_force_splitk < 0 ? conv_splitk_for(pc.cin_pad, mt, (long)OH * OW, a.nphase) : 1);
         if (a.splitk > 1) {
             HIP_TRY(hipMalloc((void**)&part, (size_t)a.splitk * yb));
             a.partial = part;
