@@ -153,6 +153,8 @@ int rgbd_elic_set_exclusive_transforms(rgbd_elic* m, int32_t on);
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
 int rgbd_debug_force_splitk(int32_t s);
+int rgbd_debug_conv_log(int32_t on);                      /* record the shape of every conv launch (tools/tune_tiles.py) */
+int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap); /* CSV text of the recorded shapes; returns the size needed */
 int rgbd_debug_force_tile(const char* cfg); /* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */
 int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                     int32_t transposed, int32_t with_residual, int32_t iters, float* ms_out);

@@ -28,7 +28,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into librgbd_amd.so (in-tree, next to this file)."""
     csrc = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in _SRCS]
-    deps = srcs + [os.path.join(csrc, "common.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
+    deps = srcs + [os.path.join(csrc, "common.h"), os.path.join(csrc, "tile_table.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -86,6 +86,8 @@ def lib():
         "rgbd_elic_set_exclusive_transforms": (ctypes.c_int, [c_vp, c_i32]),
         "rgbd_debug_force_splitk": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_tile": (ctypes.c_int, [ctypes.c_char_p]),
+        "rgbd_debug_conv_log": (ctypes.c_int, [c_i32]),
+        "rgbd_debug_conv_log_read": (c_i64, [ctypes.c_char_p, c_i64]),
         "rgbd_conv_bench": (ctypes.c_int, [c_i32] * 11 + [f32p]),
         "rgbd_elic_profile_dump": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
         "rgbd_elic_profile_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), i64p,
@@ -105,5 +107,5 @@ EXPORTS = ["rgbd_abi_version", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create"
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_profile",
-           "rgbd_elic_profile_read", "rgbd_elic_set_exclusive_transforms", "rgbd_debug_force_splitk", "rgbd_debug_force_tile", "rgbd_conv_bench",
+           "rgbd_elic_profile_read", "rgbd_elic_set_exclusive_transforms", "rgbd_debug_force_splitk", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]

@@ -88,6 +88,8 @@ static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_p
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s);
+int conv_log_enable(int on);            // shape log for tools/tune_tiles.py
+long conv_log_read(char* buf, long cap);  // CSV text; returns the size needed
 
 // ---- pointwise kernels (pointwise.hip) --------------------------------------------------------
 int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s);

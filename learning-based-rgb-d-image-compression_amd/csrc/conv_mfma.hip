@@ -13,6 +13,11 @@
 // the layer (chunk -> tap -> channel), never on tiling or batch size: results are run-to-run, batch- and
 // tile-invariant, which the entropy decoder relies on to reproduce the encoder's means/scales bit for bit.
 #include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
 
 #include "common.h"
 
@@ -504,6 +509,56 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s);
 
 char g_conv_force[64] = {0};  // rgbd_debug_force_tile (tools/tile_sweep.py)
 
+// ---- measured tile table -------------------------------------------------------------------------------------------
+// tools/tune_tiles.py times every tile shape / stage depth / staging mode for the layer shapes of a workload and writes
+// tile_table.h; a launch whose shape is listed takes the measured winner, everything else the cost model.  The choice
+// never changes results (every output keeps its fma chain), so the table is a pure performance database.
+struct TunedTile {
+    int N, H, W, cin_pad, cout_pad, ntaps, stride, nphase, splitk;  // key
+    int wm, mt, nt, kc, dma;                                        // measured best
+};
+static const TunedTile kTuned[] = {
+#include "tile_table.h"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+
+static const TunedTile* tuned_lookup(const ConvArgs& a)
+{
+    static const bool off = getenv("RGBD_NO_TILE_TABLE") != nullptr;
+    if (off) return nullptr;
+    const int stride = a.nphase > 1 ? a.OS : a.IS;
+    for (const TunedTile* t = kTuned; t->N; ++t)
+        if (t->N == a.N && t->H == a.H && t->W == a.W && t->cin_pad == a.cin_pad && t->cout_pad == a.cout_pad &&
+            t->ntaps == a.ntaps_total && t->stride == stride && t->nphase == a.nphase && t->splitk == a.splitk)
+            return t;
+    return nullptr;
+}
+
+// shape log for the tuner (rgbd_debug_conv_log): key -> launches
+static std::mutex g_log_mu;
+static bool g_log_on = false;
+static std::map<std::string, int> g_log;
+
+int conv_log_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    g_log_on = on != 0;
+    if (on) g_log.clear();
+    return RGBD_OK;
+}
+
+long conv_log_read(char* buf, long cap)
+{
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    std::string out = "N,H,W,cin_pad,cout_pad,ntaps,stride,nphase,splitk,launches\n";
+    for (const auto& kv : g_log) out += kv.first + "," + std::to_string(kv.second) + "\n";
+    if (buf && cap > 0) {
+        const size_t n = out.size() < (size_t)cap - 1 ? out.size() : (size_t)cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (long)out.size() + 1;
+}
+
 int launch_conv(const ConvArgs& a_in, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -526,6 +581,21 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     if (a.nphase != 1 && a.nphase != 4) return RGBD_EINVAL;
     if (a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
     Choice c = choose(a);
+    if (const TunedTile* t = tuned_lookup(a)) {
+        c.wm = t->wm;
+        c.mt = t->mt;
+        c.nt = t->nt;
+        c.kc = t->kc;
+        c.dma = t->dma != 0;
+        c.tw_log2 = pick_tw_log2(a.GW, a.GH, 16 * t->nt * (t->wm == 2 ? 2 : 4));
+    }
+    if (g_log_on) {
+        char key[160];
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", a.N, a.H, a.W, a.cin_pad, a.cout_pad, a.ntaps_total,
+                 a.nphase > 1 ? a.OS : a.IS, a.nphase, a.splitk);
+        std::lock_guard<std::mutex> lk(g_log_mu);
+        ++g_log[key];
+    }
     static const char* force_env = getenv("RGBD_CONV_FORCE");  // "wm,mt,nt[,kc[,dma]]" -- tuning experiments only
     const char* force = g_conv_force[0] ? g_conv_force : force_env;
     if (force) {

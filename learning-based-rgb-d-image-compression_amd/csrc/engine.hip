@@ -1549,6 +1549,9 @@ int rgbd_debug_force_tile(const char* cfg)
     return RGBD_OK;
 }
 
+int rgbd_debug_conv_log(int32_t on) { return conv_log_enable(on); }
+int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap) { return conv_log_read(buf, (long)cap); }
+
 int rgbd_debug_force_splitk(int32_t s)
 {
     g_force_splitk = s;

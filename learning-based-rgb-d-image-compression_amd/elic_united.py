@@ -267,13 +267,15 @@ class ELIC_united:
         p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
         check(lib().rgbd_elic_decompress_united(self._h, pyr, lyr, len(y_r), pyd, lyd, p(hr), p(hd), B, h, w, p(out_r),
                                                 p(out_d), self._stream_ptr()), "decompress_united")
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         del k1, k2
         return out_r, out_d
 
     def decompress(self, rgb_strings, depth_strings, shape):
         self._ready()
-        torch.cuda.synchronize()
+        # the reference brackets decompress() with torch.cuda.synchronize() (elic_united.py:431,449); here only the
+        # calling stream is waited for, so engine instances on other streams (CodecPool) are not dragged into it
+        torch.cuda.current_stream().synchronize()
         t0 = time.process_time()
         y_r, z_r = list(rgb_strings[0]), list(rgb_strings[1])
         y_d, z_d = list(depth_strings[0]), list(depth_strings[1])
@@ -292,7 +294,7 @@ class ELIC_united:
         check(lib().rgbd_elic_decompress(self._h, pyr, lyr, len(y_r), pyd, lyd, pzr, lzr, pzd, lzd, B, zh, zw,
                                          ctypes.c_void_p(xr.data_ptr()), ctypes.c_void_p(xd.data_ptr()),
                                          self._stream_ptr()), "decompress")
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         del k1, k2, k3, k4
         return {"x_hat": {"r": xr, "d": xd}, "cost_time": time.process_time() - t0}
 
