@@ -60,8 +60,8 @@ def cpu_baseline(sd, H, W, cid, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workers", type=int, default=12, help="engine instances (HIP streams) per GPU; 1 = no overlap")
