@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the profiles committed under profiles/ (run on the GPU box from the repo root):
+#   1. kernel trace + stats of the default bench command       -> <tag>_bench_default_{kernel_stats.csv,summary.txt}
+#   2. kernel trace + stats of a single engine instance         -> <tag>_bench_w1_summary.txt   (matches roofline.isolated)
+#   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs, no trace domains) -> <tag>_pmc_*.{csv,json}
+# Usage: bash profiles/collect.sh r01
+set -e -o pipefail
+tag=${1:-r01}
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --no-cpu-baseline > "$out/stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_w1" -o run -- python3 "$root/bench.py" --workers 1 --steps 6 --warmup 2 --no-cpu-baseline > "$out/stats_w1.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o run -- python3 "$root/bench.py" --steps 2 --warmup 1 --workers 1 --no-cpu-baseline > "$out/fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o run -- python3 "$root/bench.py" --steps 2 --warmup 1 --workers 1 --no-cpu-baseline > "$out/write.log" 2>&1
+cd "$root"
+steps=$(python3 -c "import json,sys;print(json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1])['steps'])")
+{ python3 profiles/summarize.py "$out/stats" "$steps"; python3 profiles/timeline.py "$out/stats"; grep '^{' "$out/stats.log"; } > "$out/${tag}_bench_default_summary.txt"
+{ python3 profiles/summarize.py "$out/stats_w1" 6; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
+cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_default_kernel_stats.csv"
+python3 profiles/pmc_traffic.py "$out/fetch" "$out/write" "$out/$tag" 28420875.4
+ls "$out"

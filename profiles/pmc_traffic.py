@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Aggregate the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) into
+HBM bytes per conv launch.  Usage: pmc_traffic.py <fetch_dir> <write_dir> <out_prefix> [algorithmic_bytes_per_launch]"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+fetch_dir, write_dir, prefix = sys.argv[1:4]
+algo = float(sys.argv[4]) if len(sys.argv) > 4 else None
+
+
+def load(d, counter):
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    per = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"][:60]
+        per[k][0] += 1
+        per[k][1] += float(r["Counter_Value"])
+    return per
+
+
+def dump(per, name, path):
+    with open(path, "w") as f:
+        f.write(f"kernel,launches,{name}_sum_KiB,per_launch_KiB\n")
+        for k, (n, v) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"\"{k}\",{n},{v:.1f},{v / n:.1f}\n")
+
+
+fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+dump(fe, "FETCH_SIZE", prefix + "_pmc_fetch_by_kernel.csv")
+dump(wr, "WRITE_SIZE", prefix + "_pmc_write_by_kernel.csv")
+cf = [v for k, v in fe.items() if "conv_mfma_kernel" in k]
+cw = [v for k, v in wr.items() if "conv_mfma_kernel" in k]
+n = sum(v[0] for v in cf)
+fetch_kib, write_kib = sum(v[1] for v in cf) / n, sum(v[1] for v in cw) / max(sum(v[0] for v in cw), 1)
+out = {
+    "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
+               "--steps 2 --warmup 1 --workers 1 --no-cpu-baseline",
+    "kernel": "conv_mfma_kernel (all instantiations; split-K reducers not included)",
+    "launches": n,
+    "fetch_size_kib_per_launch_raw": fetch_kib,
+    "write_size_kib_per_launch": write_kib,
+    "correction": "gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads: doubled "
+                  "(MI355X_MICROARCH.md, HBM section)",
+    "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+    "algorithmic_bytes_per_launch": algo,
+}
+json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
