@@ -15,9 +15,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o run -- python3 "$root/bench.py" --steps 2 --warmup 1 --workers 1 --no-cpu-baseline > "$out/fetch.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o run -- python3 "$root/bench.py" --steps 2 --warmup 1 --workers 1 --no-cpu-baseline > "$out/write.log" 2>&1
 cd "$root"
-steps=$(python3 -c "import json,sys;print(json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1])['steps'])")
+# every run executes warm-up steps, the timed steps and two single-instance steps (roofline.isolated): divide by all of them
+steps=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1]);print(j['steps']+max(j['warmup'],min(j['config']['engine_instances'],j['steps']))+2)")
 { python3 profiles/summarize.py "$out/stats" "$steps"; python3 profiles/timeline.py "$out/stats"; grep '^{' "$out/stats.log"; } > "$out/${tag}_bench_default_summary.txt"
-{ python3 profiles/summarize.py "$out/stats_w1" 6; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
+{ python3 profiles/summarize.py "$out/stats_w1" 10; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_default_kernel_stats.csv"
 python3 profiles/pmc_traffic.py "$out/fetch" "$out/write" "$out/$tag" 28420875.4
 ls "$out"
