@@ -119,6 +119,10 @@ struct DevTables {  // packed CDF rows for the device coder
     int lut_bits;
     int nrows;
     int total;  // total packed entries
+    // encoder side, one entry per packed cdf entry (= per symbol of a row): exact division by the symbol frequency as a
+    // multiply-high (Alverson; ryg_rans rans64.h:167-278 does the same for its Rans64EncSymbol):
+    //   {m_lo, m_hi, bias | shift << 17, freq},  q = mulhi64(x, m) >> shift,  x' = x + bias + q * (65536 - freq)
+    const uint32_t* enc;
 };
 
 struct PartGeom {

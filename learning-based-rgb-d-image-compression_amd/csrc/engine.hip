@@ -59,10 +59,39 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
             lut[((size_t)r * LN + b) * 2 + 1] = (uint32_t)(row[j + 1] - row[j]);
         }
     }
+    // encoder entries: m = ceil(2^(63+s) / freq), s = ceil(log2 freq): floor(x * m / 2^(63+s)) == x / freq for every
+    // x < 2^63 (the coder keeps x < freq << 47); freq == 1 uses m = 2^64 - 1 (q = x - 1) with the bias making up for it
+    std::vector<uint32_t> enc((size_t)total * 4);
+    for (int r = 0; r < nrows; ++r) {
+        const int32_t* row = cdf + (size_t)r * stride;
+        for (int j = 0; j < sizes[r] - 1; ++j) {
+            const uint32_t start = (uint32_t)row[j], freq = (uint32_t)(row[j + 1] - row[j]);
+            uint64_t m;
+            uint32_t shift, bias;
+            if (freq == 1) {
+                m = ~0ull;
+                shift = 0;
+                bias = start + 65535u;
+            } else {
+                int sl = 0;
+                while ((1u << sl) < freq) ++sl;
+                const unsigned __int128 num = ((unsigned __int128)1 << (63 + sl)) + freq - 1;
+                m = (uint64_t)(num / freq);
+                shift = (uint32_t)(sl - 1);
+                bias = start;
+            }
+            uint32_t* e = &enc[((size_t)row_off[r] + j) * 4];
+            e[0] = (uint32_t)m;
+            e[1] = (uint32_t)(m >> 32);
+            e[2] = bias | (shift << 17);
+            e[3] = freq;
+        }
+    }
+    const size_t b_enc = (size_t)total * 16;
     const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
     const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
-    const size_t bytes = b_cdf + b_lut + 3 * b_i32;
+    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc;
     if (ts->blob) (void)hipFree(ts->blob);
     ts->blob = nullptr;
     HIP_TRY(hipMalloc(&ts->blob, bytes));
@@ -73,6 +102,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     memcpy(p + b_cdf + b_lut, row_off.data(), (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + b_i32, sizes, (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);
+    memcpy(p + b_cdf + b_lut + 3 * b_i32, enc.data(), b_enc);
     HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
     unsigned char* dp = (unsigned char*)ts->blob;
     ts->d.cdf = (const uint16_t*)dp;
@@ -81,6 +111,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     ts->d.row_off = (const int32_t*)(dp + b_cdf + b_lut);
     ts->d.sizes = (const int32_t*)(dp + b_cdf + b_lut + b_i32);
     ts->d.offsets = (const int32_t*)(dp + b_cdf + b_lut + 2 * b_i32);
+    ts->d.enc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32);
     ts->d.nrows = nrows;
     ts->d.total = total;
     ts->ready = true;

@@ -309,25 +309,42 @@ __device__ __forceinline__ uint32_t wrl(uint32_t val, int sel, uint32_t old)
 // ---------------------------------------------------------------------------------------------
 // Encoder: one wavefront per stream, symbols consumed from the back (rans_interface.cpp:167-185 pops from the back).
 struct EncBatch {
-    uint32_t sf;   // start | freq << 16
-    uint32_t raw;  // escape payload
-    uint32_t rlo;  // low word of (double)1/freq
-    uint32_t rhi;  // high word, bit 31 set when the symbol hit the escape slot
+    uint32_t mlo, mhi;  // reciprocal multiplier of the symbol's frequency (DevTables::enc)
+    uint32_t w2;        // bias | shift << 17 | escape << 31
+    uint32_t freq;
+    uint32_t raw;       // escape payload
 };
 
-__device__ __forceinline__ EncBatch enc_prepare(const DevTables& t, const int32_t* __restrict__ sym,
-                                                const int32_t* __restrict__ idx, int64_t pos, bool valid)
+// The per-symbol operands are produced 64 at a time by the lanes, two batches ahead of the serial loop and in two steps,
+// so that neither of the two dependent global loads (symbol/index, then the symbol's table entry) is ever waited for:
+//   enc_load   (batch b-2): symbol and table index from HBM
+//   enc_finish (batch b-1): row geometry from LDS, escape split, gather of the reciprocal entry
+struct EncRaw {
+    int ti, sv;
+    bool valid;
+};
+
+__device__ __forceinline__ EncRaw enc_load(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx, int64_t pos,
+                                           bool valid)
+{
+    EncRaw r;
+    r.valid = valid;
+    r.ti = valid ? idx[pos] : 0;
+    r.sv = valid ? sym[pos] : 0;
+    return r;
+}
+
+__device__ __forceinline__ EncBatch enc_finish(const DevTables& t, const int3* __restrict__ rowmeta, const EncRaw& r)
 {
     EncBatch b;
-    b.sf = 1u << 16;
+    b.mlo = b.mhi = ~0u;
+    b.w2 = 65535u;
+    b.freq = 1u;
     b.raw = 0;
-    b.rlo = 0;
-    b.rhi = 0x3FF00000u;  // 1.0
-    if (valid) {
-        const int ti = idx[pos];
-        const int top = t.sizes[ti] - 2;
-        const int ro = t.row_off[ti];
-        int v = sym[pos] - t.offsets[ti];
+    if (r.valid) {
+        const int3 rm = rowmeta[r.ti];  // {row_off, cdf_length, offset}
+        const int top = rm.y - 2;
+        int v = r.sv - rm.z;
         uint32_t raw = 0;
         if (v < 0) {
             raw = (uint32_t)(-2 * v - 1);
@@ -336,14 +353,12 @@ __device__ __forceinline__ EncBatch enc_prepare(const DevTables& t, const int32_
             raw = (uint32_t)(2 * (v - top));
             v = top;
         }
-        const uint32_t start = t.cdf[ro + v];
-        const uint32_t next = (v == top) ? 65536u : (uint32_t)t.cdf[ro + v + 1];
-        const uint32_t freq = next - start;
-        const uint64_t rb = (uint64_t)__double_as_longlong(1.0 / (double)freq);
-        b.sf = start | (freq << 16);
+        const uint4 e = reinterpret_cast<const uint4*>(t.enc)[rm.x + v];
+        b.mlo = e.x;
+        b.mhi = e.y;
+        b.w2 = e.z | ((v == top) ? 0x80000000u : 0u);
+        b.freq = e.w;
         b.raw = raw;
-        b.rlo = (uint32_t)rb;
-        b.rhi = (uint32_t)(rb >> 32) | ((v == top) ? 0x80000000u : 0u);
     }
     return b;
 }
@@ -354,61 +369,125 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                                                          DevTables t1, uint32_t* __restrict__ out, int64_t cap_words,
                                                          int64_t* __restrict__ out_words, int* __restrict__ err)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
+    int3* rowmeta = reinterpret_cast<int3*>(esm);
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
     const DevTables& t = s < split ? t0 : t1;
     const int64_t n = counts[s];
     const int64_t base = sym_base[s];
-    uint32_t* o = out + (size_t)s * cap_words;  // cap_words is a multiple of 64
+    uint32_t* o = out + (size_t)s * cap_words;  // cap_words is a multiple of 64 (and < 2^31: checked by the launcher)
     uint64_t x = RANS_LOW;
-    int64_t w = cap_words;  // next free slot is w-1; slot k lives in lane (k & 63) of `ov` until its 64-block is full
+    int w = (int)cap_words;  // next free slot is w-1; slot k lives in lane (k & 63) of `ov` until its 64-block is full
     uint32_t ov = 0;
     int bad = 0;
 
-    auto emit = [&]() {
+    auto emit = [&]() {  // escape path only; the symbol loop below has its own copy in ISA
         --w;
-        ov = wrl((uint32_t)x, (int)(w & 63), ov);
+        ov = wrl((uint32_t)x, w & 63, ov);
         x >>= 32;
         if ((w & 63) == 0) o[w + lane] = ov;  // block [w, w+64) complete: one coalesced 256-byte store
     };
 
+    for (int i = lane; i < t.nrows; i += 64) rowmeta[i] = make_int3(t.row_off[i], t.sizes[i], t.offsets[i]);
+    __syncthreads();
     const int64_t nb = (n + 63) >> 6;
-    EncBatch cur = enc_prepare(t, sym, idx, base + (nb - 1) * 64 + lane, nb > 0 && (nb - 1) * 64 + lane < n);
+    EncBatch cur = enc_finish(t, rowmeta, enc_load(sym, idx, base + (nb - 1) * 64 + lane, nb > 0 && (nb - 1) * 64 + lane < n));
+    EncRaw raw1 = enc_load(sym, idx, base + (nb - 2) * 64 + lane, nb > 1);
     for (int64_t b = nb - 1; b >= 0; --b) {
-        // batch b-1 is prepared while batch b is coded: its loads are only consumed after the serial loop
-        const EncBatch nxt = enc_prepare(t, sym, idx, base + (b - 1) * 64 + lane, b > 0);
+        const EncBatch nxt = enc_finish(t, rowmeta, raw1);                   // batch b-1: its symbols arrived last round
+        raw1 = enc_load(sym, idx, base + (b - 2) * 64 + lane, b > 1);         // batch b-2: in flight during this round
         const int cnt = (int)((n - b * 64) < 64 ? (n - b * 64) : 64);
         if (w < 64 + 10 * 64) {  // worst case for one batch: 64 * (1 + 1 + 8) items
             bad = 1;
             break;
         }
-        for (int j = cnt - 1; j >= 0; --j) {
-            const uint32_t sf = rdl(cur.sf, j), rhi = rdl(cur.rhi, j), rlo = rdl(cur.rlo, j);
-            if (rhi >> 31) {  // escape payload first (reverse of rans_interface.cpp:147-162)
-                const uint32_t raw = rdl(cur.raw, j);
-                int nn = 0;
-                while (nn < 8 && (raw >> (nn * ESC_BITS)) != 0) ++nn;
-                for (int k = nn - 1; k >= -1; --k) {
-                    const uint32_t val = k >= 0 ? ((raw >> (k * ESC_BITS)) & ESC_MAX) : (uint32_t)nn;
-                    if (x >= (1ull << 59)) emit();  // ((RANS_LOW >> 16) << 32) << 12, rans_interface.cpp:67-68
-                    x = (x << ESC_BITS) | val;
-                }
+        int j = cnt - 1;
+        while (j >= 0) {
+            // The symbol loop in ISA; the state lives in a VGPR pair (all lanes hold the same value) because the exact
+            // division is four v_mad_u64_u32:  q = mulhi64(x, m) >> shift,  x = x + bias + q * (65536 - freq)
+            // (rans64.h:77-94 with the reciprocal of rans64.h:167-278).  It leaves the loop for the two rare events:
+            //   code 1: symbol j carries an escape payload (coded below, then the loop resumes at j)
+            //   code 2: a 64-word output block is complete and wants storing
+            // v[60:61] = x, v[62:67] scratch (v65 stays 0).  VALU->VALU reads of vcc need 2 wait states on gfx950.
+            uint32_t code, w2, fr, ml, mh, tt;
+            j = (int)rfl((uint32_t)j);
+            w = (int)rfl((uint32_t)w);
+            asm volatile(
+                "v_mov_b64 v[60:61], %[x]\n"
+                "v_mov_b32 v65, 0\n"
+                "s_mov_b32 m0, %[j]\n"
+                "1:\n"
+                "v_readlane_b32 %[w2], %[vw2], m0\n"
+                "v_readlane_b32 %[fr], %[vfr], m0\n"
+                "v_readlane_b32 %[ml], %[vml], m0\n"
+                "v_readlane_b32 %[mh], %[vmh], m0\n"
+                "s_cmp_lt_i32 %[w2], 0\n"
+                "s_cbranch_scc1 7f\n"
+                "v_lshrrev_b64 v[62:63], 47, v[60:61]\n"   // x >= freq << 47 ?  (rans64.h:82-83)
+                "v_cmp_le_u32 vcc, %[fr], v62\n"
+                "s_cbranch_vccz 2f\n"
+                "s_sub_u32 %[w], %[w], 1\n"                // emit the low word into slot w-1
+                "s_and_b32 %[tt], %[w], 63\n"
+                "v_cmp_eq_u32 vcc, %[tt], %[lane]\n"
+                "s_nop 1\n"
+                "v_cndmask_b32 %[ov], %[ov], v60, vcc\n"
+                "v_mov_b32 v60, v61\n"
+                "v_mov_b32 v61, 0\n"
+                "s_cmp_eq_u32 %[tt], 0\n"
+                "s_cbranch_scc1 8f\n"
+                "2:\n"
+                "v_mad_u64_u32 v[62:63], vcc, v60, %[ml], 0\n"           // xl*ml
+                "v_lshrrev_b64 v[62:63], 32, v[62:63]\n"
+                "v_mad_u64_u32 v[62:63], vcc, v61, %[ml], v[62:63]\n"    // xh*ml + hi
+                "v_mov_b32 v64, v62\n"
+                "v_mad_u64_u32 v[66:67], vcc, v60, %[mh], v[64:65]\n"    // xl*mh + lo
+                "v_mov_b32 v64, v63\n"
+                "v_mad_u64_u32 v[62:63], vcc, v61, %[mh], v[64:65]\n"    // xh*mh + hi
+                "v_mad_u64_u32 v[62:63], vcc, v67, 1, v[62:63]\n"        // + hi          = mulhi64(x, m)
+                "s_bfe_u32 %[tt], %[w2], 0x50011\n"                       // shift = (w2 >> 17) & 31
+                "v_lshrrev_b64 v[62:63], %[tt], v[62:63]\n"              // q
+                "s_and_b32 %[w2], %[w2], 0x1ffff\n"                       // bias
+                "s_sub_u32 %[fr], 0x10000, %[fr]\n"                       // 65536 - freq
+                "v_mad_u64_u32 v[60:61], vcc, %[w2], 1, v[60:61]\n"      // x += bias
+                "v_mad_u64_u32 v[60:61], vcc, v62, %[fr], v[60:61]\n"    // x += q.lo * (65536 - freq)
+                "v_mad_u32_u24 v61, v63, %[fr], v61\n"                    // x.hi += q.hi * (65536 - freq)   (q < 2^47)
+                "s_sub_u32 m0, m0, 1\n"
+                "s_cmp_ge_i32 m0, 0\n"
+                "s_cbranch_scc1 1b\n"
+                "s_mov_b32 %[code], 0\n"
+                "s_branch 9f\n"
+                "7:\n"
+                "s_mov_b32 %[code], 1\n"
+                "s_branch 9f\n"
+                "8:\n"
+                "s_mov_b32 %[code], 2\n"
+                "9:\n"
+                "s_mov_b32 %[j], m0\n"
+                "v_mov_b64 %[x], v[60:61]\n"
+                : [x] "+v"(x), [j] "+s"(j), [w] "+s"(w), [ov] "+v"(ov), [code] "=&s"(code), [w2] "=&s"(w2), [fr] "=&s"(fr),
+                  [ml] "=&s"(ml), [mh] "=&s"(mh), [tt] "=&s"(tt)
+                : [vw2] "v"(cur.w2), [vfr] "v"(cur.freq), [vml] "v"(cur.mlo), [vmh] "v"(cur.mhi), [lane] "v"(lane)
+                : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "m0", "vcc", "scc", "memory");
+            x = rfl64(x);
+            code = rfl(code);
+            j = (int)rfl((uint32_t)j);
+            w = (int)rfl((uint32_t)w);
+            if (code == 0) break;
+            if (code == 2) {  // block [w, w+64) complete: one coalesced 256-byte store
+                o[w + lane] = ov;
+                continue;
             }
-            const uint32_t start = sf & 0xFFFFu, freq = sf >> 16;
-            if (x >= ((uint64_t)freq << 47)) emit();  // ((RANS_LOW >> 16) << 32) * freq, rans64.h:82-83
-            // exact x / freq: fp64 estimate (|error| <= 1 since x < 2^63, q < 2^47) and an integer fix-up
-            const double rcp = __longlong_as_double((long long)(((uint64_t)(rhi & 0x7FFFFFFFu) << 32) | rlo));
-            uint64_t qn = rfl64((uint64_t)((double)x * rcp));
-            int64_t r = (int64_t)(x - qn * (uint64_t)freq);
-            while (r < 0) {
-                --qn;
-                r += freq;
+            // escape payload first (reverse of rans_interface.cpp:147-162), then the loop codes the escape slot itself
+            const uint32_t raw = rdl(cur.raw, j);
+            int nn = 0;
+            while (nn < 8 && (raw >> (nn * ESC_BITS)) != 0) ++nn;
+            for (int k = nn - 1; k >= -1; --k) {
+                const uint32_t val = k >= 0 ? ((raw >> (k * ESC_BITS)) & ESC_MAX) : (uint32_t)nn;
+                if (x >= (1ull << 59)) emit();  // ((RANS_LOW >> 16) << 32) << 12, rans_interface.cpp:67-68
+                x = (x << ESC_BITS) | val;
             }
-            while (r >= (int64_t)freq) {
-                ++qn;
-                r -= freq;
-            }
-            x = (qn << PROB_BITS) + (uint64_t)r + start;
+            cur.w2 = wrl(rdl(cur.w2, j) & 0x7FFFFFFFu, j, cur.w2);  // payload done: lane j is an ordinary symbol now
         }
         cur = nxt;
     }
@@ -421,12 +500,12 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
     }
     // rans64.h:96-103: the two state words go in front
     --w;
-    ov = wrl((uint32_t)(x >> 32), (int)(w & 63), ov);
+    ov = wrl((uint32_t)(x >> 32), w & 63, ov);
     if ((w & 63) == 0) o[w + lane] = ov;
     --w;
-    ov = wrl((uint32_t)x, (int)(w & 63), ov);
+    ov = wrl((uint32_t)x, w & 63, ov);
     if ((w & 63) == 0) o[w + lane] = ov;
-    else if (lane >= (int)(w & 63)) o[(w & ~(int64_t)63) + lane] = ov;  // partial leading block
+    else if (lane >= (w & 63)) o[(w & ~63) + lane] = ov;  // partial leading block
     if (lane == 0) out_words[s] = cap_words - w;
 }
 
@@ -435,8 +514,10 @@ int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sy
                        int64_t* out_words, int* err, hipStream_t s)
 {
     if (nstreams <= 0) return RGBD_OK;
-    if (cap_words % 64) return RGBD_EINVAL;
-    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), 0, s, sym, idx, sym_base, counts, split, t0, t1, out,
+    if (cap_words % 64 || cap_words >= ((int64_t)1 << 31)) return RGBD_EINVAL;
+    const size_t lds = (size_t)(t0.nrows > t1.nrows ? t0.nrows : t1.nrows) * sizeof(int3);
+    if (lds > 60 * 1024) return RGBD_ENOSPC;
+    hipLaunchKernelGGL(rans_encode_kernel, dim3(nstreams), dim3(64), lds, s, sym, idx, sym_base, counts, split, t0, t1, out,
                        cap_words, out_words, err);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
