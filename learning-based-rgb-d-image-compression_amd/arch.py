@@ -255,6 +255,56 @@ def elic_united_entries(config=None) -> "OrderedDict[str, Entry]":
     return b.entries
 
 
+def elic_entries(config=None, channel: int = 3) -> "OrderedDict[str, Entry]":
+    """Every state_dict entry of the single-modal ELIC (reference: models/elic.py:15-57; 409 tensors, 36,932,427
+    parameters for channel=3) -- BASELINE config 1 / SURVEY §8f rank 4."""
+    cfg = model_config() if config is None else config
+    N, M = int(cfg["N"]), int(cfg["M"])
+    slice_ch = list(cfg["slice_ch"])
+    b = _Builder()
+    # modules/transform/analysis.py:29-52
+    p = "g_a.analysis_transform"
+    b.conv(f"{p}.0", channel, N, 5)
+    for j in (1, 2, 3, 5, 6, 7, 10, 11, 12):
+        b.bottleneck(f"{p}.{j}", N)
+    b.conv(f"{p}.4", N, N, 5)
+    b.attention(f"{p}.8", N)
+    b.conv(f"{p}.9", N, N, 5)
+    b.conv(f"{p}.13", N, M, 5)
+    b.attention(f"{p}.14", M)
+    # modules/transform/synthesis.py:32-51
+    p = "g_s.synthesis_transform"
+    b.attention(f"{p}.0", M)
+    b.deconv(f"{p}.1", M, N, 5)
+    for j in (2, 3, 4, 7, 8, 9, 11, 12, 13):
+        b.bottleneck(f"{p}.{j}", N)
+    b.deconv(f"{p}.5", N, N, 5)
+    b.attention(f"{p}.6", N)
+    b.deconv(f"{p}.10", N, N, 5)
+    b.deconv(f"{p}.14", N, channel, 5)
+    # analysis.py:207-216, synthesis.py:276-285
+    b.conv("h_a.reduction.0", M, N, 3)
+    b.conv("h_a.reduction.2", N, N, 5)
+    b.conv("h_a.reduction.4", N, N, 5)
+    b.deconv("h_s.increase.0", N, M, 5)
+    b.deconv("h_s.increase.2", M, M * 3 // 2, 5)
+    b.deconv("h_s.increase.4", M * 3 // 2, 2 * M, 3)
+    # models/elic.py:32-53; EntropyParameters (entropy.py:7-17) is three 1x1 convolutions
+    for i, c in enumerate(slice_ch):
+        b.conv(f"local_context.{i}", c, 2 * c, 5)
+    for i in range(1, len(slice_ch)):
+        b.channel_context(f"channel_context.{i}", sum(slice_ch[:i]), 2 * slice_ch[i])
+    for fam, extra in (("entropy_parameters_anchor", 0), ("entropy_parameters_nonanchor", 2)):
+        for i, c in enumerate(slice_ch):
+            in_dim, out = 2 * M + (extra + (2 if i else 0)) * c, 2 * c
+            b.conv(f"{fam}.{i}.fusion.0", in_dim, out * 5 // 3, 1)
+            b.conv(f"{fam}.{i}.fusion.2", out * 5 // 3, out * 4 // 3, 1)
+            b.conv(f"{fam}.{i}.fusion.4", out * 4 // 3, out, 1)
+    b.entropy_bottleneck("entropy_bottleneck", N)
+    b.gaussian_conditional("gaussian_conditional")
+    return b.entries
+
+
 def count_parameters(entries) -> int:
     n = 0
     for e in entries.values():

@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .arch import Entry, elic_united_entries, model_config
+from .arch import Entry, elic_entries, elic_united_entries, model_config
 
 _IH_STD = math.sqrt(4.0 * (65536.0**2 - 1.0) / 12.0)  # std of the sum of four uniform 16-bit ints
 _IH_MEAN = 2.0 * 65535.0
@@ -88,15 +88,19 @@ def make_tensor(name: str, e: Entry, seed: int) -> np.ndarray:
     raise ValueError(f"unknown entry kind {e.kind} for {name}")
 
 
-def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_torch: bool = True):
-    """Full ELIC_united state_dict (parameters + buffers) with deterministic synthetic values."""
+def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_torch: bool = True,
+                         model: str = "ELIC_united", channel: int = 3):
+    """Full state_dict (parameters + buffers) of ELIC_united (default) or the single-modal ELIC with deterministic
+    synthetic values."""
     cfg = model_config() if config is None else config
-    entries = elic_united_entries(cfg)
+    entries = elic_united_entries(cfg) if model == "ELIC_united" else elic_entries(cfg, channel)
     sd = OrderedDict()
     for name, e in entries.items():
         sd[name] = make_tensor(name, e, seed)
-    if stress:
+    if stress and model == "ELIC_united":
         _apply_stress(sd, cfg)
+    elif stress:
+        _apply_stress_single(sd, cfg)
     if as_torch:
         import torch
 
@@ -114,6 +118,18 @@ def _apply_stress(sd, cfg):
         sd[f"h_s.{m}_h_s3.deconv.weight"] *= np.float32(40.0)
     for fam in ("rgb_entropy_parameters_anchor", "depth_entropy_parameters_anchor",
                 "rgb_entropy_parameters_nonanchor", "depth_entropy_parameters_nonanchor"):
+        for i, c in enumerate(slice_ch):
+            sd[f"{fam}.{i}.fusion.4.weight"] *= np.float32(6.0)
+            sd[f"{fam}.{i}.fusion.4.bias"][:c] = np.float32(1.0)  # scale half
+
+
+def _apply_stress_single(sd, cfg):
+    # same idea as _apply_stress for the single-modal ELIC (its entropy-parameter nets end in a 1x1 convolution)
+    slice_ch = list(cfg["slice_ch"])
+    sd["g_a.analysis_transform.13.weight"] *= np.float32(48.0)
+    sd["h_a.reduction.4.weight"] *= np.float32(24.0)
+    sd["h_s.increase.4.weight"] *= np.float32(40.0)
+    for fam in ("entropy_parameters_anchor", "entropy_parameters_nonanchor"):
         for i, c in enumerate(slice_ch):
             sd[f"{fam}.{i}.fusion.4.weight"] *= np.float32(6.0)
             sd[f"{fam}.{i}.fusion.4.bias"][:c] = np.float32(1.0)  # scale half

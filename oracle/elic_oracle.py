@@ -480,6 +480,129 @@ class OracleCodec:
 
 
 # --------------------------------------------------------------------------------------------------
+# single-modal ELIC (models/elic.py) -- BASELINE config 1 / SURVEY §8f rank 4
+# --------------------------------------------------------------------------------------------------
+_GA1 = ["conv", "rb", "rb", "rb", "conv", "rb", "rb", "rb", "attn", "conv", "rb", "rb", "rb", "conv", "attn"]
+_GS1 = ["attn", "deconv", "rb", "rb", "rb", "deconv", "attn", "rb", "rb", "rb", "deconv", "rb", "rb", "rb", "deconv"]
+
+
+def _stack1(sd, prefix, kinds, x):  # analysis.py:29-52 / synthesis.py:32-70
+    for i, k in enumerate(kinds):
+        n = f"{prefix}.{i}"
+        if k == "conv":
+            x = _conv(sd, n, x, stride=2)
+        elif k == "deconv":
+            x = _deconv(sd, n, x, stride=2)
+        elif k == "rb":
+            x = _bottleneck(sd, n, x)
+        else:
+            x = _attention(sd, n, x)
+    return x
+
+
+def _entropy_params1(sd, p, x):  # entropy.py:7-29 (three 1x1 convolutions)
+    t = torch.relu(_conv(sd, p + ".fusion.0", x))
+    t = torch.relu(_conv(sd, p + ".fusion.2", t))
+    return _conv(sd, p + ".fusion.4", t)
+
+
+class OracleCodecSingle:
+    """Functional mirror of ELIC.{update,compress,decompress} (models/elic.py:161-351)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config=None):
+        self.sd = {k: v.detach().to(torch.float32) if v.is_floating_point() else v for k, v in state_dict.items()}
+        cfg = config or {"N": 192, "M": 320, "slice_ch": [16, 16, 32, 64, 192]}
+        self.slice_ch = list(cfg["slice_ch"])
+        self.table = scale_table()
+        self.gc = None
+        self.eb = None
+        self.trace = None
+
+    def update(self):  # elic.py:327-332
+        self.gc = gaussian_tables(self.table)
+        self.eb = bottleneck_tables(self.sd, "entropy_bottleneck")
+        return True
+
+    def _median(self):
+        return self.sd["entropy_bottleneck.quantiles"][:, :, 1:2].reshape(1, -1, 1, 1)
+
+    def _z_compress(self, z):  # entropy_models.py:195-224, 431-440
+        sym = torch.round(z - self._median()).int()
+        c = z.shape[1]
+        idx = torch.arange(c, dtype=torch.int32).view(1, c, 1, 1).expand_as(sym)
+        return [coder.rans_encode(sym[i].reshape(-1).numpy(), idx[i].reshape(-1).numpy(), self.eb)
+                for i in range(z.shape[0])]
+
+    def _z_decompress(self, strings, shape):  # entropy_models.py:226-266, 442-446
+        c = self.eb.cdf.shape[0]
+        idx = torch.arange(c, dtype=torch.int32).view(c, 1, 1).expand(c, shape[0], shape[1]).reshape(-1).numpy()
+        outs = [torch.from_numpy(coder.rans_decode(s, idx, self.eb).astype(np.float32)).reshape(c, shape[0], shape[1])
+                for s in strings]
+        return torch.stack(outs) + self._median()
+
+    def _slices(self, y, hyper, enc, dec):  # elic.py:180-251 / 268-316
+        sd, yhat = self.sd, []
+
+        def part(i, anchor, ctx, y_slice):
+            fam = f"entropy_parameters_{'anchor' if anchor else 'nonanchor'}.{i}"
+            scales, means = _entropy_params1(sd, fam, torch.cat(ctx, dim=1)).chunk(2, 1)
+            s_sq, m_sq = pack(scales, anchor), pack(means, anchor)
+            idx = scale_indexes(s_sq, self.table)
+            if enc is not None:
+                sym = quantize_symbols(pack(y_slice, anchor), m_sq)
+                enc[0].append(sym.reshape(-1).numpy())
+                enc[1].append(idx.reshape(-1).numpy())
+            else:
+                sym = torch.from_numpy(dec.decode_stream(idx.reshape(-1).numpy(), self.gc)).reshape(idx.shape)
+            if self.trace is not None:
+                self.trace.setdefault("parts", []).append(
+                    {"slice": i, "mod": "rgb", "anchor": anchor, "scales": s_sq.clone(), "means": m_sq.clone(),
+                     "symbols": sym.clone(), "indexes": idx.clone()})
+            return unpack(sym.float() + m_sq, anchor)
+
+        c0 = 0
+        for i, c in enumerate(self.slice_ch):
+            ys = y[:, c0:c0 + c] if y is not None else None
+            ctx = ([_channel_context(sd, f"channel_context.{i}", torch.cat(yhat, dim=1))] if i else []) + [hyper]
+            a = part(i, True, ctx, ys)
+            loc = _conv(sd, f"local_context.{i}", a)
+            n = part(i, False, [loc] + ctx, ys)
+            yhat.append(n + a)
+            c0 += c
+        return torch.cat(yhat, dim=1)
+
+    @torch.no_grad()
+    def compress(self, x: torch.Tensor):  # elic.py:161-253
+        y = _stack1(self.sd, "g_a.analysis_transform", _GA1, x)
+        t = torch.relu(_conv(self.sd, "h_a.reduction.0", y))
+        t = torch.relu(_conv(self.sd, "h_a.reduction.2", t, stride=2))
+        z = _conv(self.sd, "h_a.reduction.4", t, stride=2)
+        zs = self._z_compress(z)
+        zhat = self._z_decompress(zs, z.shape[-2:])
+        hyper = self._hyper(zhat)
+        enc = ([], [])
+        yhat = self._slices(y, hyper, enc, None)
+        ys = coder.rans_encode(np.concatenate(enc[0]), np.concatenate(enc[1]), self.gc)
+        if self.trace is not None:
+            self.trace.update({"y": y, "z": z, "zhat": zhat, "hyper": hyper, "yhat": yhat})
+        return {"strings": [[ys], zs], "shape": tuple(z.shape[-2:])}
+
+    def _hyper(self, zhat):  # synthesis.py:276-285
+        t = torch.relu(_deconv(self.sd, "h_s.increase.0", zhat, stride=2))
+        t = torch.relu(_deconv(self.sd, "h_s.increase.2", t, stride=2))
+        return _deconv(self.sd, "h_s.increase.4", t, stride=1)
+
+    @torch.no_grad()
+    def decompress(self, strings, shape):  # elic.py:255-325
+        zhat = self._z_decompress(strings[1], shape)
+        hyper = self._hyper(zhat)
+        dec = coder.RansDecoder()
+        dec.set_stream(strings[0][0])
+        yhat = self._slices(None, hyper, None, dec)
+        return {"x_hat": _stack1(self.sd, "g_s.synthesis_transform", _GS1, yhat), "y_hat": yhat}
+
+
+# --------------------------------------------------------------------------------------------------
 # harness arithmetic: dataset/utils.py:58-100, utils/IOutils.py:30-88, utils/metrics.py:8-14
 # --------------------------------------------------------------------------------------------------
 def pad_replicate0(x: torch.Tensor, p: int = 64) -> torch.Tensor:

@@ -78,4 +78,6 @@ def load_reference():
     from config.config import model_config  # noqa: E402
     from models.elic_united import ELIC_united  # noqa: E402
 
-    return ELIC_united, model_config, {"ans": ans, "_CXX": cxx}
+    from models.elic import ELIC  # noqa: E402
+
+    return ELIC_united, model_config, {"ans": ans, "_CXX": cxx, "ELIC": ELIC}

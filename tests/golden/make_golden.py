@@ -8,6 +8,7 @@ Outputs (data only -- inputs are regenerated from rgbd_amd.synth, never stored):
     tests/golden/model_*.npz        ELIC_united streams, latents and reconstructions from the reference's
                                     compress()/decompress() on synthetic weights + inputs
     tests/golden/bicee_*.npz        Bi-CEE stage alone (BASELINE config 4): compress_united / decompress_united outputs
+    tests/golden/elic_*.npz         single-modal ELIC (BASELINE config 1): streams, latents, reconstruction
     tests/golden/harness.json       pad / container / bpp / PSNR tuples (TesterUnited arithmetic)
 
 The reference runs on PyTorch CPU kernels; float tensors are therefore specific to this container's
@@ -177,6 +178,31 @@ def bicee_case(net, synth, name, B, h, w, seed):
     return g
 
 
+def elic_single_case(ext, model_config, synth, name, B, H, W, config_id):
+    """BASELINE config 1: the reference's single-modal ELIC (models/elic.py) compress()/decompress() on one RGB image."""
+    net = ext["ELIC"](config=model_config(), channel=3).eval()
+    net.load_state_dict(synth.synthetic_state_dict(0, model="ELIC"))
+    assert net.update(force=True)
+    r, _ = synth.synthetic_batch(B, H, W, config_id=config_id)
+    x = torch.from_numpy(r)
+    with torch.no_grad():
+        out = net.compress(x)
+        dec = net.decompress(out["strings"], out["shape"])
+        y = net.g_a(x)
+        z = net.h_a(y)
+        hyper = net.h_s(net.entropy_bottleneck.decompress(out["strings"][1], out["shape"]))
+    g = {"B": B, "H": H, "W": W, "config_id": config_id, "shape": np.array(tuple(out["shape"]), np.int32),
+         "y_stream": np.frombuffer(out["strings"][0][0], np.uint8), "y": y.numpy(), "z": z.numpy(), "hyper": hyper.numpy(),
+         "xhat_sub": dec["x_hat"][:, :, ::4, ::4].numpy(),
+         "psnr": np.array([-10 * np.log10(torch.mean((dec["x_hat"].clamp(0, 1) - x) ** 2).item())], np.float64)}
+    for i, zs in enumerate(out["strings"][1]):
+        g[f"z{i}"] = np.frombuffer(zs, np.uint8)
+    g["eb_cdf"] = net.entropy_bottleneck._quantized_cdf.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, f"elic_{name}.npz"), **g)
+    print("elic", name, len(out["strings"][0][0]), len(out["strings"][1][0]), g["psnr"])
+    return g
+
+
 def main():
     ELIC, model_config, ext = rl.load_reference()
     import rgbd_amd  # noqa: F401
@@ -205,6 +231,9 @@ def main():
         g = bicee_case(net, synth, name, B, h, w, seed)
         summary["bicee_" + name] = {"B": B, "h": h, "w": w, "seed": seed,
                                     "y_len": [int(g["r_y"].shape[0]), int(g["d_y"].shape[0])]}
+    g = elic_single_case(ext, model_config, synth, "c1_256x256", 1, 256, 256, 1)
+    summary["elic_c1_256x256"] = {"B": 1, "H": 256, "W": 256, "config_id": 1, "y_len": int(g["y_stream"].shape[0]),
+                                  "psnr": g["psnr"].tolist()}
     with open(os.path.join(HERE, "harness.json"), "w") as f:
         json.dump({"weights_seed": 0, "torch": torch.__version__, "cases": summary}, f, indent=1)
 
