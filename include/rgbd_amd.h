@@ -131,6 +131,19 @@ int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const
                                 float* yhat_depth_dev, void* stream);
 
 /*
+ * Single-modal ELIC (BASELINE config 1): replaces models/elic.py: ELIC.__init__ :15-57, compress :161-253,
+ * decompress :255-325 (x_hat is NOT clamped there).  Same life cycle as above (set_tensor with the reference's key names,
+ * set_tables which = 0 gaussian / 2 bottleneck, set_scale_table, finalize); streams are fetched with
+ * rgbd_elic_stream(modality = 0, kind, index).  x_dev: [B,in_ch,H,W] NCHW fp32, H and W multiples of 64.
+ */
+int rgbd_elic_create_single(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, int32_t in_ch, rgbd_elic** out);
+int rgbd_elic_compress_single(rgbd_elic* m, const float* x_dev, int32_t B, int32_t H, int32_t W, int32_t per_image_streams,
+                              void* stream);
+int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int64_t* y_len, int32_t n_y,
+                                const uint8_t* const* z, const int64_t* z_len, int32_t B, int32_t zh, int32_t zw,
+                                float* x_dev, void* stream);
+
+/*
  * Eval-mode forward(): replaces ELIC_united.forward / entropy_estimate_united / codeOnePart (models/elic_united.py:94-263)
  * and the likelihood halves of EntropyBottleneck.forward / GaussianConditional.forward (entropy_models.py:391-428,
  * 534-558).  x_hat is NOT clamped (as in the reference); likelihoods are lower-bounded at 1e-9.

@@ -7,6 +7,9 @@ from . import arch, synth  # noqa: F401
 from .arch import Config, model_config  # noqa: F401
 from . import _lib, ans, distributed, entropy_models  # noqa: F401,E402
 from .elic_united import ELIC_united, modelZoo  # noqa: F401,E402
+from .elic import ELIC  # noqa: F401,E402
+
+modelZoo["ELIC"] = ELIC
 from .pool import CodecPool  # noqa: F401,E402
 from . import datautils, ioutils, metrics, tester  # noqa: F401,E402
 from .tester import TesterUnited  # noqa: F401,E402

@@ -253,6 +253,8 @@ struct rgbd_tables {
 
 struct rgbd_elic {
     int N = 192, M = 320;
+    int variant = 0;  // 0: ELIC_united (RGB + depth), 1: single-modal ELIC (models/elic.py)
+    int in_ch = 3;    // image channels of the single-modal variant
     std::vector<int> slice_ch;
     std::map<std::string, HostTensor> raw;
     std::map<std::string, PackedConv> convs;
@@ -892,6 +894,101 @@ struct rgbd_elic {
         }
     }
 
+    // ---- single-modal ELIC (models/elic.py:15-57; BASELINE config 1) ------------------------------------------
+    // analysis.py:29-52 / synthesis.py:32-70: the same blocks as above without the cross-modal fusion stages
+    Act stack1(const std::string& prefix, const char* const* kinds, int n, const Act& x_in)
+    {
+        Act x = x_in;
+        for (int i = 0; i < n; ++i) {
+            const std::string k = kinds[i], name = prefix + std::to_string(i);
+            if (k == "conv" || k == "deconv") x = conv(name, x, 2, 2);
+            else if (k == "rb") x = bottleneck(name, x);
+            else x = attention(name, x);
+        }
+        return x;
+    }
+    Act g_a1(const Act& x)
+    {
+        static const char* const kinds[15] = {"conv", "rb", "rb", "rb", "conv", "rb", "rb", "rb",
+                                              "attn", "conv", "rb", "rb", "rb", "conv", "attn"};
+        return stack1("g_a.analysis_transform.", kinds, 15, x);
+    }
+    Act g_s1(const Act& y)
+    {
+        static const char* const kinds[15] = {"attn", "deconv", "rb", "rb", "rb", "deconv", "attn", "rb",
+                                              "rb", "rb", "deconv", "rb", "rb", "rb", "deconv"};
+        return stack1("g_s.synthesis_transform.", kinds, 15, y);
+    }
+    // analysis.py:207-216
+    Act h_a1(const Act& y)
+    {
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act t = conv("h_a.reduction.0", y, 1, 1, relu);
+        t = conv("h_a.reduction.2", t, 2, 2, relu);
+        return conv("h_a.reduction.4", t, 2, 2);
+    }
+    // synthesis.py:276-285
+    Act h_s1(const Act& zhat, const Act* dst = nullptr)
+    {
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act t = conv("h_s.increase.0", zhat, 2, 2, relu);
+        t = conv("h_s.increase.2", t, 2, 2, relu);
+        return conv("h_s.increase.4", t, 1, 1, Epi(), dst);
+    }
+    // entropy.py:7-29: three 1x1 convolutions
+    Act entropy_params1(const std::string& p, const Act& ctx)
+    {
+        Epi relu;
+        relu.act = ACT_RELU;
+        const PackedConv* last = conv_of(p + ".fusion.4.weight");
+        if (!last) return Act();
+        Act out = alloc(ctx.n, ctx.h, ctx.w, last->cout);
+        const size_t mark = arena.top;
+        Act t = conv(p + ".fusion.0", ctx, 1, 0, relu);
+        t = conv(p + ".fusion.2", t, 1, 0, relu);
+        conv(p + ".fusion.4", t, 1, 0, Epi(), &out);
+        arena.top = mark;
+        return out;
+    }
+    // elic.py:180-251 / 268-316.  Context buffer of a slice: [local 2C | channel 2C (i > 0) | hyper 2M]; the anchor
+    // net reads the suffix behind the local-context slot, the non-anchor net the whole buffer.
+    void bicee1(Coding& cd, const Act* y, const Act& hyper, const Act& yhat)
+    {
+        yhat_base[0] = yhat.p;
+        int c0 = 0;
+        int64_t part_off = 0;
+        const int h = hyper.h, w = hyper.w, HC = hyper.c;
+        for (size_t i = 0; i < slice_ch.size(); ++i) {
+            const int C = slice_ch[i];
+            const size_t mark = arena.top;
+            const std::string si = std::to_string(i);
+            const int wide = 2 * C + (i ? 2 * C : 0) + HC;
+            Act ctx = alloc(hyper.n, h, w, wide);
+            copy_ch(hyper, view(ctx, wide - HC, HC));
+            if (i) {
+                const Act cc = view(ctx, 2 * C, 2 * C);
+                channel_context("channel_context." + si, view(yhat, 0, c0), &cc);
+            }
+            const Act ys = y ? view(*y, c0, C) : Act();
+            const Act hs = view(yhat, c0, C);
+            const int64_t part_syms = (int64_t)C * h * (w / 2);
+            Act pa = entropy_params1("entropy_parameters_anchor." + si, view(ctx, 2 * C, wide - 2 * C));
+            code_part(cd, 0, 1, pa, ys, hs, part_off);
+            const Act loc = view(ctx, 0, 2 * C);
+            conv("local_context." + si, hs, 1, 2, Epi(), &loc);
+            Act pn = entropy_params1("entropy_parameters_nonanchor." + si, ctx);
+            code_part(cd, 0, 0, pn, ys, hs, part_off + part_syms);
+            part_off += 2 * part_syms;
+            c0 += C;
+            arena.top = mark;
+        }
+    }
+    int run_compress1(const float* x_dev, int B, int H, int W, int per_image);
+    int run_decompress1(const uint8_t* const* ys, const int64_t* ylen, int n_y, const uint8_t* const* zs, const int64_t* zlen,
+                        int B, int zh, int zw, float* x_out);
+
     // lat != nullptr: the Bi-CEE stage alone (compress_united / decompress_united): latents and hyper parameters come
     // from the caller as NCHW device tensors, the transforms and the z path are skipped
     struct Latents {
@@ -1309,6 +1406,200 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     return r;
 }
 
+// ---- single-modal ELIC: compress (models/elic.py:161-253) and decompress (:255-325) --------------------------------
+int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_image)
+{
+    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
+    const int ny = per_image ? B : 1;
+    named.clear();
+    arena.top = 0;
+    rc = 0;
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(8 * B + 64));
+    int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
+    int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
+    int32_t* zsym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * Tz));
+    int32_t* zidx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * Tz));
+    const int64_t ycount = per_image ? T : T * B;
+    const int64_t ycap = ((5 * ycount + 32 + 704) + 63) & ~(int64_t)63, zcap = ((5 * Tz + 32 + 704) + 63) & ~(int64_t)63;
+    uint32_t* ywords = (uint32_t*)arena.take(sizeof(uint32_t) * (size_t)(ny * ycap));
+    uint32_t* zwords = (uint32_t*)arena.take(sizeof(uint32_t) * (size_t)(B * zcap));
+    int* err = (int*)arena.take(256);
+    dbg_sym = sym;
+    dbg_idx = idx;
+    dbg_per_mod = (int64_t)B * T;
+    // meta64: [0,B) y stream base (checkerboard kernels); [B,2B) z base; [2B,3B) z counts; [3B,4B) z out_words;
+    //         [4B,4B+ny) y encoder bases; [5B,5B+ny) y counts; [6B,6B+ny) y out_words
+    std::vector<int64_t> hmeta((size_t)8 * B + 64, 0);
+    for (int b = 0; b < B; ++b) {
+        hmeta[b] = per_image ? (int64_t)b * T : 0;
+        hmeta[B + b] = (int64_t)b * Tz;
+        hmeta[2 * B + b] = Tz;
+    }
+    for (int i = 0; i < ny; ++i) {
+        hmeta[(size_t)4 * B + i] = per_image ? (int64_t)i * T : 0;
+        hmeta[(size_t)5 * B + i] = ycount;
+    }
+    if (!dry()) {
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(err, 0, 256, s));
+    }
+    Act x = alloc(B, H, W, in_ch);
+    if (!dry()) {
+        const int r = launch_nchw_to_nhwc16(x_dev, B, in_ch, H, W, x.p, x.cs, s);
+        if (r) return r;
+    }
+    Act y = alloc(B, h, w, M);
+    {
+        const size_t mark = arena.top;
+        copy_ch(g_a1(x), y);
+        arena.top = mark;
+    }
+    Act z = h_a1(y);
+    named["y"] = y;
+    named["z"] = z;
+    Act zhat = alloc(B, zh, zw, N);
+    float* md = dense_of("entropy_bottleneck.medians");
+    if (!dry() && !rc && md) {
+        int r = launch_z_quant(z.p, z.cs, B, zh, zw, N, md, zsym, zidx, s);
+        if (!r)
+            r = launch_rans_encode(zsym, zidx, meta64 + B, meta64 + 2 * B, B, B, tables[2].d, tables[2].d, zwords, zcap,
+                                   meta64 + 3 * B, err, s);
+        if (!r) r = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
+        if (r) fail(r);
+    }
+    named["zhat"] = zhat;
+    Act hyper = h_s1(zhat);
+    named["hyper"] = hyper;
+    Act yhat = alloc(B, h, w, M);
+    named["yhat"] = yhat;
+    Coding cd;
+    cd.encode = true;
+    cd.per_image = per_image;
+    cd.per_image_total = T;
+    cd.sym = sym;
+    cd.idx = idx;
+    cd.stream_base = meta64;
+    bicee1(cd, &y, hyper, yhat);
+    if (!dry() && !rc) {
+        const int r = launch_rans_encode(sym, idx, meta64 + 4 * B, meta64 + 5 * B, ny, ny, tables[0].d, tables[0].d, ywords,
+                                         ycap, meta64 + 6 * B, err, s);
+        if (r) fail(r);
+    }
+    if (rc) return rc;
+    if (dry()) return RGBD_OK;
+    std::vector<int64_t> ow((size_t)2 * B, 0);
+    int herr = 0;
+    HIP_TRY(hipMemcpyAsync(ow.data(), meta64 + 6 * B, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ow.data() + B, meta64 + 3 * B, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (herr) return RGBD_ENOSPC;
+    streams[0][0].assign(ny, {});
+    streams[0][1].assign(B, {});
+    streams[1][0].clear();
+    streams[1][1].clear();
+    for (int i = 0; i < ny; ++i) {
+        const int64_t nw = ow[i];
+        streams[0][0][i].resize((size_t)nw * 4);
+        HIP_TRY(hipMemcpyAsync(streams[0][0][i].data(), ywords + (size_t)i * ycap + (ycap - nw), (size_t)nw * 4,
+                               hipMemcpyDeviceToHost, s));
+    }
+    for (int i = 0; i < B; ++i) {
+        const int64_t nw = ow[(size_t)B + i];
+        streams[0][1][i].resize((size_t)nw * 4);
+        HIP_TRY(hipMemcpyAsync(streams[0][1][i].data(), zwords + (size_t)i * zcap + (zcap - nw), (size_t)nw * 4,
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return RGBD_OK;
+}
+
+int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, int n_y, const uint8_t* const* zs,
+                               const int64_t* zlen, int B, int zh, int zw, float* x_out)
+{
+    const int h = zh * 4, w = zw * 4, H = zh * 64, W = zw * 64;
+    const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
+    const int per_image = (n_y == B) ? 1 : 0;
+    named.clear();
+    arena.top = 0;
+    rc = 0;
+    std::vector<uint32_t> hwords;
+    std::vector<int64_t> yoff, ylw, zoff, zlw;
+    auto push = [&](const uint8_t* const* arr, const int64_t* len, int n, std::vector<int64_t>& off,
+                    std::vector<int64_t>& ln) -> int {
+        for (int i = 0; i < n; ++i) {
+            if (len[i] < 8 || (len[i] & 3)) return RGBD_EINVAL;
+            off.push_back((int64_t)hwords.size());
+            ln.push_back(len[i] / 4);
+            const size_t o = hwords.size();
+            hwords.resize(o + (size_t)len[i] / 4);
+            memcpy(hwords.data() + o, arr[i], (size_t)len[i]);
+        }
+        return RGBD_OK;
+    };
+    int r = push(ys, ylen, n_y, yoff, ylw);
+    if (!r) r = push(zs, zlen, B, zoff, zlw);
+    if (r) return r;
+    std::vector<int64_t> hmeta;  // y off[n_y], y len[n_y], z off[B], z len[B], y base[B], z base[B]
+    hmeta.insert(hmeta.end(), yoff.begin(), yoff.end());
+    hmeta.insert(hmeta.end(), ylw.begin(), ylw.end());
+    hmeta.insert(hmeta.end(), zoff.begin(), zoff.end());
+    hmeta.insert(hmeta.end(), zlw.begin(), zlw.end());
+    const size_t o_ybase = hmeta.size();
+    for (int b = 0; b < B; ++b) hmeta.push_back(per_image ? (int64_t)b * T : 0);
+    const size_t o_zbase = hmeta.size();
+    for (int b = 0; b < B; ++b) hmeta.push_back((int64_t)b * Tz);
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * hmeta.size());
+    uint32_t* words = (uint32_t*)arena.take(sizeof(uint32_t) * (hwords.size() + 4));
+    uint64_t* state = (uint64_t*)arena.take(sizeof(uint64_t) * (size_t)(2 * (n_y + B)));
+    int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
+    int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
+    int32_t* zsym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * Tz));
+    int32_t* zidx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * Tz));
+    dbg_sym = sym;
+    dbg_idx = idx;
+    dbg_per_mod = (int64_t)B * T;
+    if (!dry()) {
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(words, hwords.data(), sizeof(uint32_t) * hwords.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    Act zhat = alloc(B, zh, zw, N);
+    float* md = dense_of("entropy_bottleneck.medians");
+    if (!dry() && md) {
+        int q = launch_fill_zero(zhat.p, zhat.elems(), s);
+        if (!q) q = launch_z_quant(zhat.p, zhat.cs, B, zh, zw, N, md, zsym, zidx, s);  // indexes = channel id
+        if (!q)
+            q = launch_rans_decode(words, meta64 + 2 * n_y, meta64 + 2 * n_y + B, B, state + (size_t)2 * n_y, 1, zidx, zsym,
+                                   meta64 + o_zbase, 0, Tz, tables[2].d, s);
+        if (!q) q = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
+        if (q) fail(q);
+    }
+    named["zhat"] = zhat;
+    Act hyper = h_s1(zhat);
+    named["hyper"] = hyper;
+    Act yhat = alloc(B, h, w, M);
+    named["yhat"] = yhat;
+    Coding cd;
+    cd.encode = false;
+    cd.per_image = per_image;
+    cd.per_image_total = T;
+    cd.sym = sym;
+    cd.idx = idx;
+    cd.stream_base = meta64 + o_ybase;
+    cd.words = words;
+    cd.stream_off = meta64;
+    cd.stream_len = meta64 + n_y;
+    cd.state = state;
+    cd.nstreams = n_y;
+    bicee1(cd, nullptr, hyper, yhat);
+    Act xh = g_s1(yhat);
+    if (rc) return rc;
+    if (dry()) return RGBD_OK;
+    return launch_nhwc_to_nchw_clamp(xh.p, B, in_ch, H, W, xh.cs, x_out, 0, s);  // elic.py:318-325: not clamped
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -1692,6 +1983,62 @@ int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_sl
     return RGBD_OK;
 }
 
+static int check_ready(const rgbd_elic* m);
+
+int rgbd_elic_create_single(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, int32_t in_ch, rgbd_elic** out)
+{
+    if (in_ch < 1 || in_ch > 16) return RGBD_EINVAL;
+    const int r = rgbd_elic_create(N, M, slice_ch, n_slices, out);
+    if (r) return r;
+    (*out)->variant = 1;
+    (*out)->in_ch = in_ch;
+    return RGBD_OK;
+}
+
+int rgbd_elic_compress_single(rgbd_elic* m, const float* x_dev, int32_t B, int32_t H, int32_t W, int32_t per_image_streams,
+                              void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (m->variant != 1 || !x_dev || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64) return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    const int per_image = (per_image_streams || B == 1) ? 1 : 0;
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_compress1(x_dev, B, H, W, per_image);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    r = m->run_compress1(x_dev, B, H, W, per_image);
+    if (m->profile) m->profile_collect();
+    return r;
+}
+
+int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int64_t* y_len, int32_t n_y,
+                                const uint8_t* const* z, const int64_t* z_len, int32_t B, int32_t zh, int32_t zw,
+                                float* x_dev, void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (m->variant != 1 || !y || !y_len || !z || !z_len || !x_dev || B <= 0 || zh <= 0 || zw <= 0) return RGBD_EINVAL;
+    if (n_y != 1 && n_y != B) return RGBD_EINVAL;
+    m->s = (hipStream_t)stream;
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    r = m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev);
+    if (m->profile && !r) {
+        if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
+        m->profile_collect();
+    }
+    return r;
+}
+
 int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
 {
     if (!src || !out || !src->finalized) return RGBD_EINVAL;
@@ -1699,6 +2046,8 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
     m->N = src->N;
     m->M = src->M;
     m->slice_ch = src->slice_ch;
+    m->variant = src->variant;
+    m->in_ch = src->in_ch;
     m->convs = src->convs;    // device pointers are shared, read-only
     m->dense = src->dense;
     for (int i = 0; i < 4; ++i) m->tables[i] = src->tables[i];
@@ -1779,10 +2128,14 @@ int rgbd_elic_finalize(rgbd_elic* m)
         const HostTensor& t = kv.second;
         if (ends_with(name, ".weight") && t.shape.size() == 4) {
             // ConvTranspose2d layers of this model: g_s stages 1/6/12/17 and the h_s deconvs
-            const bool transposed = name.find(".deconv.") != std::string::npos ||
-                                    (name.rfind("g_s.", 0) == 0 &&
-                                     (ends_with(name, "_transform.1.weight") || ends_with(name, "_transform.6.weight") ||
-                                      ends_with(name, "_transform.12.weight") || ends_with(name, "_transform.17.weight")));
+            // (single-modal ELIC: g_s stages 1/5/10/14 and h_s.increase.*; stage numbers that are not a bare
+            //  "<stage>.weight" in the other variant belong to blocks with sub-names, so the union is unambiguous)
+            bool transposed = name.find(".deconv.") != std::string::npos || name.rfind("h_s.increase.", 0) == 0;
+            if (name.rfind("g_s.", 0) == 0)
+                for (const char* suf : {"_transform.1.weight", "_transform.6.weight", "_transform.12.weight",
+                                        "_transform.17.weight", "_transform.5.weight", "_transform.10.weight",
+                                        "_transform.14.weight"})
+                    transposed = transposed || ends_with(name, suf);
             const std::string bname = name.substr(0, name.size() - 6) + "bias";
             auto bit = m->raw.find(bname);
             PackedConv pc;
@@ -1801,7 +2154,7 @@ int rgbd_elic_finalize(rgbd_elic* m)
             HIP_TRY(hipMalloc((void**)&d, hv.size() * sizeof(float)));
             HIP_TRY(hipMemcpy(d, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
             m->dense[name] = d;
-        } else if (ends_with(name, "_entropy_bottleneck.quantiles")) {
+        } else if (ends_with(name, "entropy_bottleneck.quantiles")) {
             // medians = quantiles[:, 0, 1]  (entropy_models.py:316-318)
             const int C = (int)t.shape[0];
             std::vector<float> med(C);
@@ -1852,8 +2205,8 @@ int rgbd_elic_finalize(rgbd_elic* m)
 static int check_ready(const rgbd_elic* m)
 {
     if (!m || !m->finalized || !m->scale_table) return RGBD_ESTATE;
-    for (const auto& t : m->tables)
-        if (!t.ready) return RGBD_ESTATE;
+    for (int i = 0; i < 4; ++i)
+        if (!m->tables[i].ready && !(m->variant == 1 && (i & 1))) return RGBD_ESTATE;  // single-modal: slots 0 and 2
     return RGBD_OK;
 }
 

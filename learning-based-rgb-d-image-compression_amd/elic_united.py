@@ -48,10 +48,30 @@ class ELIC_united:
         self._dirty = True
 
     # ---- torch.nn.Module-like surface ------------------------------------------------------------------
+    _MODEL = "ELIC_united"
+
     def _materialize(self):
         if self._params is None:
-            self._params = synth.synthetic_state_dict(self._init_seed, self.config, stress=False)
+            self._params = synth.synthetic_state_dict(self._init_seed, self.config, stress=False, model=self._MODEL)
         return self._params
+
+    def _holders(self):
+        """state_dict prefix -> table holder."""
+        return {"rgb_gaussian_conditional": self.rgb_gaussian_conditional,
+                "depth_gaussian_conditional": self.depth_gaussian_conditional,
+                "rgb_entropy_bottleneck": self.rgb_entropy_bottleneck,
+                "depth_entropy_bottleneck": self.depth_entropy_bottleneck}
+
+    def _table_slots(self):
+        """(engine table slot, holder): 0/1 gaussian rgb/depth, 2/3 bottleneck rgb/depth."""
+        return [(0, self.rgb_gaussian_conditional), (1, self.depth_gaussian_conditional),
+                (2, self.rgb_entropy_bottleneck), (3, self.depth_entropy_bottleneck)]
+
+    def _create_engine(self):
+        h = ctypes.c_void_p()
+        sl = (ctypes.c_int32 * len(self.slice_ch))(*self.slice_ch)
+        check(lib().rgbd_elic_create(self.N, self.M, sl, len(self.slice_ch), ctypes.byref(h)), "elic_create")
+        return h
 
     def eval(self):
         self.training = False
@@ -74,10 +94,7 @@ class ELIC_united:
     def state_dict(self):
         p = self._materialize()
         out = OrderedDict()
-        holders = {"rgb_gaussian_conditional": self.rgb_gaussian_conditional,
-                   "depth_gaussian_conditional": self.depth_gaussian_conditional,
-                   "rgb_entropy_bottleneck": self.rgb_entropy_bottleneck,
-                   "depth_entropy_bottleneck": self.depth_entropy_bottleneck}
+        holders = self._holders()
         for name in self._entries:
             mod, _, leaf = name.rpartition(".")
             if mod in holders and leaf in _TABLE_KEYS:
@@ -95,10 +112,7 @@ class ELIC_united:
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
         params = self._materialize() if missing else OrderedDict()
-        holders = {"rgb_gaussian_conditional": self.rgb_gaussian_conditional,
-                   "depth_gaussian_conditional": self.depth_gaussian_conditional,
-                   "rgb_entropy_bottleneck": self.rgb_entropy_bottleneck,
-                   "depth_entropy_bottleneck": self.depth_entropy_bottleneck}
+        holders = self._holders()
         for name, e in self._entries.items():
             if name not in state_dict:
                 continue
@@ -149,10 +163,7 @@ class ELIC_united:
         L = lib()
         torch.cuda.set_device(self._device)
         if self._h is None:
-            h = ctypes.c_void_p()
-            sl = (ctypes.c_int32 * len(self.slice_ch))(*self.slice_ch)
-            check(L.rgbd_elic_create(self.N, self.M, sl, len(self.slice_ch), ctypes.byref(h)), "elic_create")
-            self._h = h
+            self._h = self._create_engine()
         p = self._materialize()
         for name, e in self._entries.items():
             if not e.is_param:
@@ -162,14 +173,13 @@ class ELIC_united:
             shape = (ctypes.c_int64 * a.ndim)(*a.shape)
             check(L.rgbd_elic_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shape,
                                          a.ndim), f"set_tensor({name})")
-        for which, holder in enumerate((self.rgb_gaussian_conditional, self.depth_gaussian_conditional,
-                                        self.rgb_entropy_bottleneck, self.depth_entropy_bottleneck)):
+        for which, holder in self._table_slots():
             cdf, sizes, offs = holder.numpy_tables()  # raises "Uninitialized CDFs. Run update() first"
             i32p = ctypes.POINTER(ctypes.c_int32)
             check(L.rgbd_elic_set_tables(self._h, which, cdf.ctypes.data_as(i32p), int(cdf.shape[1]),
                                          sizes.ctypes.data_as(i32p), offs.ctypes.data_as(i32p), int(cdf.shape[0])),
                   f"set_tables({which})")
-        st = self.rgb_gaussian_conditional.scale_table.float().contiguous().numpy()
+        st = self._table_slots()[0][1].scale_table.float().contiguous().numpy()
         check(L.rgbd_elic_set_scale_table(self._h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(st.shape[0])),
               "set_scale_table")
         check(L.rgbd_elic_finalize(self._h), "finalize")
@@ -383,4 +393,4 @@ class _LazyStore:
         return self._o._materialize()[k]
 
 
-modelZoo = {"ELIC_united": ELIC_united}
+modelZoo = {"ELIC_united": ELIC_united}  # models/__init__.py:11-20; rgbd_amd/__init__.py adds "ELIC"

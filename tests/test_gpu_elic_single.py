@@ -1,0 +1,105 @@
+"""Single-modal ELIC (BASELINE config 1; reference models/elic.py) on the GPU vs the CPU oracle and the reference golden.
+Same layered contract as tests/test_gpu_model.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_utils import require_gpu
+from oracle import coder
+from oracle import elic_oracle as eo
+from test_gpu_model import _rel, _walk_parts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd1():
+    from rgbd_amd import synth
+
+    return synth.synthetic_state_dict(0, model="ELIC")
+
+
+@pytest.fixture(scope="module")
+def net1(sd1):
+    require_gpu()
+    import rgbd_amd
+
+    m = rgbd_amd.modelZoo["ELIC"](config=rgbd_amd.model_config(), channel=3).eval()
+    m.load_state_dict(sd1, strict=True)
+    assert m.update(force=True)
+    return m.to("cuda")
+
+
+@pytest.fixture(scope="module")
+def orc1(sd1):
+    c = eo.OracleCodecSingle(sd1)
+    c.update()
+    return c
+
+
+def test_config1_256(net1, orc1):
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "elic_c1_256x256.npz"))
+    r, _ = synth.synthetic_batch(1, 256, 256, config_id=1)
+    x = torch.from_numpy(r)
+    out = net1.compress(x.cuda())
+    assert tuple(out["shape"]) == (4, 4) and len(out["strings"][0]) == 1 and len(out["strings"][1]) == 1
+    orc1.trace = {}
+    ref = orc1.compress(x)
+    tr, orc1.trace = orc1.trace, None
+    for name in ("y", "z", "hyper"):  # float stages vs the oracle and vs the reference's own tensors
+        got = net1.debug_tensor(name)
+        assert _rel(got, tr[name].numpy()) < 2e-5, name
+        assert _rel(got, g[name]) < 2e-5, name
+    # integer stages: z stream from the GPU's z floats, y stream from the GPU's symbols / indexes
+    assert orc1._z_compress(torch.from_numpy(net1.debug_tensor("z"))) == out["strings"][1]
+    gsym, gidx = net1.debug_symbols(0)
+    assert gsym.shape[0] == 320 * 16 * 16
+    assert coder.rans_encode(gsym, gidx, orc1.gc) == out["strings"][0][0]
+    clean = _walk_parts(tr, {0: gsym}, {0: gidx}, orc1, {0: tr["y"]})
+    print(f"single-modal ELIC: parts identical before the first boundary flip: {clean} of {len(tr['parts'])};",
+          "streams identical to oracle:", out["strings"] == ref["strings"], "| to the reference golden:",
+          out["strings"][0][0] == g["y_stream"].tobytes() and out["strings"][1][0] == g["z0"].tobytes())
+    assert clean >= 1
+    assert abs(len(out["strings"][0][0]) - g["y_stream"].shape[0]) <= 64
+    # decoder reproduces the encoder's y_hat bit for bit; x_hat vs the oracle's synthesis transform on the same y_hat
+    yhat_enc = net1.debug_tensor("yhat").copy()
+    rec = net1.decompress(out["strings"], out["shape"])
+    assert np.array_equal(net1.debug_tensor("yhat"), yhat_enc)
+    xh = rec["x_hat"].cpu()
+    assert xh.shape == (1, 3, 256, 256)
+    oxh = eo._stack1(orc1.sd, "g_s.synthesis_transform", eo._GS1, torch.from_numpy(yhat_enc))
+    assert (xh - oxh).abs().max() < 1e-4 * max(1.0, float(oxh.abs().max()))
+    assert abs(eo.psnr(xh.clamp(0, 1), x) - eo.psnr(oxh.clamp(0, 1), x)) < 1e-4
+    if out["strings"] == ref["strings"]:
+        assert abs(eo.psnr(xh.clamp(0, 1), x) - g["psnr"][0]) < 1e-4
+
+
+def test_batch_and_errors(net1):
+    from rgbd_amd import synth
+
+    r, _ = synth.synthetic_batch(2, 128, 192, config_id=3)
+    x = torch.from_numpy(r).cuda()
+    net1.per_image_streams = True
+    try:
+        out = net1.compress(x)
+        assert len(out["strings"][0]) == 2 and len(out["strings"][1]) == 2
+        rec = net1.decompress(out["strings"], out["shape"])
+        for i in range(2):
+            one = net1.compress(x[i:i + 1])
+            assert one["strings"][0][0] == out["strings"][0][i] and one["strings"][1][0] == out["strings"][1][i]
+            rec1 = net1.decompress(one["strings"], one["shape"])
+            assert torch.equal(rec1["x_hat"][0], rec["x_hat"][i])
+    finally:
+        net1.per_image_streams = False
+    out = net1.compress(x)  # reference format: one y stream for the batch
+    assert len(out["strings"][0]) == 1
+    rec2 = net1.decompress(out["strings"], out["shape"])
+    assert torch.equal(rec2["x_hat"], rec["x_hat"])
+    with pytest.raises(ValueError):
+        net1.compress(x[:, :, :100])
+    with pytest.raises(ValueError):
+        net1.compress(torch.zeros(1, 1, 64, 64))
