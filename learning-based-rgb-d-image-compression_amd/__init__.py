@@ -12,4 +12,4 @@ from .elic import ELIC  # noqa: F401,E402
 modelZoo["ELIC"] = ELIC
 from .pool import CodecPool  # noqa: F401,E402
 from . import datautils, ioutils, metrics, tester  # noqa: F401,E402
-from .tester import TesterUnited  # noqa: F401,E402
+from .tester import TesterSingle, TesterUnited  # noqa: F401,E402

@@ -93,7 +93,7 @@ class TesterUnited:
                 self.net = model(config=model_config_, channel=self.channel).eval()
                 break
         else:
-            raise ValueError(f"model {model_name} is not provided by rgbd_amd (ELIC_united only)")
+            raise ValueError(f"model {model_name} is not provided by rgbd_amd (ELIC_united and ELIC only)")
         best = os.path.join(self.ckpt_dir_path, "checkpoint_best_loss.pth.tar")
         if ckpt_path is None and os.path.exists(best):
             ckpt_path = best
@@ -184,3 +184,104 @@ class TesterUnited:
             f"Avg rMS-SSIM: {meters['avg_rgb_ms_ssim'].avg:.7f} | Avg dMS-SSIM: {meters['avg_depth_ms_ssim'].avg:.7f} | "
             f"Avg Encoding Latency: {meters['avg_encode_time'].avg:.6f} | Avg Decoding latency: {meters['avg_deocde_time'].avg:.6f}")
         return rows, meters
+
+
+class ImageFolder:
+    """One modality of a dataset root: <root>/rgb/* (channel 3) or <root>/depth/* (channel 1), sorted by file name
+    (dataset/testDataset.py:14-66)."""
+
+    def __init__(self, root, channel=3, debug=False):
+        self.mode = "RGB" if channel == 3 else "L"
+        split = Path(root) / ("rgb" if channel == 3 else "depth")
+        if not split.is_dir():
+            raise RuntimeError(f'Invalid directory "{root}"')
+        self.samples = sorted(f for f in split.iterdir() if f.is_file())
+        if debug:
+            self.samples = self.samples[:20]
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        return load_image(self.samples[i], self.mode)[None], [os.path.splitext(self.samples[i].name)[0]]
+
+
+class TesterSingle(TesterUnited):
+    """testing/tester_single.py:14-170 for the single-modal models (channel 3 or 1; `playground/test.py -m ELIC`)."""
+
+    def __init__(self, args, config=None, net=None):
+        super().__init__(types_namespace_without_dataset(args), config, net)
+        self.test_dataloader = ImageFolder(args.dataset, channel=args.channel, debug=self.debug) if args.dataset else None
+
+    # tester_single.py:121-142
+    def compress_one_image(self, x, stream_path, H, W, img_name):
+        torch.cuda.synchronize()
+        start = time.time()
+        out = self.net.compress(x)
+        torch.cuda.synchronize()
+        enc_time = time.time() - start
+        os.makedirs(stream_path, exist_ok=True)
+        fn = os.path.join(stream_path, img_name)
+        with Path(fn).open("wb") as f:
+            write_uints(f, (H, W))
+            write_body(f, out["shape"], out["strings"])
+        return float(filesize(fn)) * 8 / (H * W), enc_time
+
+    # tester_single.py:144-170
+    def decompress_one_image(self, stream_path, img_name, mode="reflect0"):
+        with Path(os.path.join(stream_path, img_name)).open("rb") as f:
+            original_size = read_uints(f, 2)
+            strings, shape = read_body(f)
+        torch.cuda.synchronize()
+        start = time.time()
+        out = self.net.decompress(strings, shape)
+        torch.cuda.synchronize()
+        dec_time = time.time() - start
+        cropper = crop0 if mode.find("0") != -1 else crop1
+        return cropper(out["x_hat"], original_size), dec_time
+
+    # tester_single.py:45-66
+    @torch.no_grad()
+    def test_model(self, padding_mode="reflect0", padding=True):
+        self.net.eval()
+        names = ("avg_psnr", "avg_ms_ssim", "avg_bpp", "avg_deocde_time", "avg_encode_time")
+        meters = {k: AverageMeter() for k in names}
+        rec_dir = self.get_rec_dir(padding=padding, padding_mode=padding_mode)
+        rows = []
+        for i in range(len(self.test_dataloader)):
+            img, name = self.test_dataloader[i]
+            _, C, H, W = img.shape
+            img = img.to(self.device)
+            stream_path = os.path.join(rec_dir, "depth_bin" if C == 1 else "rgb_bin")
+            bpp, et = self.compress_one_image(pad(img, padding_mode), stream_path, H, W, name[0])
+            x_hat, dt = self.decompress_one_image(stream_path, name[0], mode=padding_mode)
+            p, m = compute_metrics(x_hat, img)
+            if getattr(self, "save_reconstructions", True):  # tester_single.py:68-85
+                tag = f"{name[0]}_{bpp:.4f}_{p:.4f}_"
+                if C == 1:
+                    save_depth16(x_hat, os.path.join(rec_dir, "depth_rec", f"{tag}_rec_16bit.png"),
+                                 100000 if rec_dir.find("sun") != -1 else 10000)
+                    save_image(x_hat, os.path.join(rec_dir, "depth_rec", f"{tag}_rec_8bit.png"))
+                else:
+                    save_image(x_hat, os.path.join(rec_dir, "rgb_rec", f"{tag}_rec.png"))
+            for k, v in zip(names, (p, m, bpp, dt, et)):
+                meters[k].update(v)
+            self.logger_test.info(f"Image[{i}:{name[0]}] | Bpp loss: {bpp:.4f} | PSNR: {p:.4f} | MS-SSIM: {m:.4f} | "
+                                  f"Encoding Latency: {et:.4f} | Decoding latency: {dt:.4f}")
+            rows.append({"name": name[0], "bpp": bpp, "psnr": p, "enc_time": et, "dec_time": dt})
+        self.logger_test.info(
+            f"Epoch:[{self.epoch}] | Avg Bpp: {meters['avg_bpp'].avg:.7f} | Avg PSNR: {meters['avg_psnr'].avg:.7f} | "
+            f"Avg MS-SSIM: {meters['avg_ms_ssim'].avg:.7f} | Avg Encoding Latency: {meters['avg_encode_time'].avg:.6f} | "
+            f"Avg Decoding latency: {meters['avg_deocde_time'].avg:.6f}")
+        return rows, meters
+
+
+def types_namespace_without_dataset(args):
+    """The base constructor opens the RGB-D pair folder; the single-modal tester opens one modality itself."""
+    import copy
+
+    a = copy.copy(args)
+    exp = args.experiment or TesterUnited.get_exp_name(args.dataset, args.channel, args.model, args.quality)
+    a.experiment = exp
+    a.dataset = None
+    return a

@@ -89,3 +89,39 @@ def test_pool_matches_single_instance(net, synth_sd):
     for out, mxr, mxd in many:
         assert out["r_strings"] == ref["r_strings"] and out["d_strings"] == ref["d_strings"]
         assert torch.equal(mxr, ref_rec["x_hat"]["r"])
+
+
+def test_tester_single_on_files(tmp_path, monkeypatch):
+    """testing/tester_single.py counterpart with the single-modal ELIC (`playground/test.py -m ELIC --channel 3`)."""
+    from PIL import Image
+
+    import rgbd_amd
+    from rgbd_amd import synth
+
+    net = rgbd_amd.ELIC(config=rgbd_amd.model_config(), channel=3).eval()
+    net.load_state_dict(synth.synthetic_state_dict(0, model="ELIC"))
+    net.update(force=True)
+    net = net.to("cuda")
+    root = tmp_path / "nyu_test"
+    (root / "rgb").mkdir(parents=True)
+    for i in range(2):
+        r, _ = synth.synthetic_pair(i, 100, 150, config_id=6, smooth=True)
+        Image.fromarray((r.transpose(1, 2, 0) * 255).astype(np.uint8)).save(root / "rgb" / f"{i:04d}.png")
+    monkeypatch.chdir(tmp_path)
+    args = types.SimpleNamespace(channel=3, debug=False, experiment=None, dataset=str(root), model="ELIC", quality="1",
+                                 checkpoint=None)
+    t = rgbd_amd.TesterSingle(args, rgbd_amd.model_config(), net=net)
+    assert t.exp_name == "nyuv2_rgb_ELIC_1"  # tester.py:66-75
+    rows, meters = t.test_model(padding_mode="replicate0", padding=True)
+    rec_dir = t.get_rec_dir(padding=True, padding_mode="replicate0")
+    assert len(rows) == 2 and len(os.listdir(os.path.join(rec_dir, "rgb_rec"))) == 2
+    for row in rows:
+        assert row["bpp"] == os.path.getsize(os.path.join(rec_dir, "rgb_bin", row["name"])) * 8.0 / (100 * 150)
+        assert np.isfinite(row["psnr"]) and row["enc_time"] > 0 and row["dec_time"] > 0
+    img, name = t.test_dataloader[0]
+    xp = rgbd_amd.datautils.pad(img.cuda(), "replicate0")
+    out = net.compress(xp)
+    rec = net.decompress(out["strings"], out["shape"])
+    xh, _ = t.decompress_one_image(os.path.join(rec_dir, "rgb_bin"), name[0], mode="replicate0")
+    assert torch.equal(xh, rec["x_hat"][:, :, :100, :150])
+    assert abs(eo.psnr(xh.cpu(), img) - rows[0]["psnr"]) < 1e-9
