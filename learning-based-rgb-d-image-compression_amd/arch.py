@@ -137,6 +137,27 @@ class _Builder:
         self.buffer(f"{name}.likelihood_lower_bound.bound", (1,))
         self.buffer(f"{name}.lower_bound_scale.bound", (1,))
 
+    # nn.Linear / nn.LayerNorm / Swin pieces of models/stf_united.py
+    def linear(self, name: str, cin: int, cout: int, bias: bool = True):
+        self.entries[f"{name}.weight"] = Entry((cout, cin), "linear_w", fan_in=cin)
+        if bias:
+            self.entries[f"{name}.bias"] = Entry((cout,), "bias", fan_in=cin)
+
+    def layernorm(self, name: str, c: int):
+        self.entries[f"{name}.weight"] = Entry((c,), "ln_w")
+        self.entries[f"{name}.bias"] = Entry((c,), "ln_b")
+
+    # stf_united.py:118-214 (window 4x4: 49 relative offsets; relative_position_index is a registered buffer)
+    def swin_block(self, name: str, dim: int, heads: int, window: int = 4, mlp_ratio: int = 4):
+        self.layernorm(f"{name}.norm1", dim)
+        self.entries[f"{name}.attn.relative_position_bias_table"] = Entry(((2 * window - 1) ** 2, heads), "rpb_table")
+        self.buffer(f"{name}.attn.relative_position_index", (window * window, window * window), "int64")
+        self.linear(f"{name}.attn.qkv", dim, 3 * dim)
+        self.linear(f"{name}.attn.proj", dim, dim)
+        self.layernorm(f"{name}.norm2", dim)
+        self.linear(f"{name}.mlp.fc1", dim, mlp_ratio * dim)
+        self.linear(f"{name}.mlp.fc2", mlp_ratio * dim, dim)
+
     def buffer(self, name: str, shape, dtype: str = "float32"):
         self.entries[name] = Entry(tuple(shape), "buffer", dtype=dtype, is_param=False)
 
@@ -303,6 +324,69 @@ def elic_entries(config=None, channel: int = 3) -> "OrderedDict[str, Entry]":
     b.entropy_bottleneck("entropy_bottleneck", N)
     b.gaussian_conditional("gaussian_conditional")
     return b.entries
+
+
+STF_DEPTHS = (2, 2, 6, 2)
+STF_HEADS = (3, 6, 12, 24)
+STF_EMBED = 48
+
+
+def stf_config() -> Config:
+    """models/stf_united.py:638-640: the Swin variant overrides N, M and the slice widths."""
+    cfg = model_config()
+    cfg["N"], cfg["M"], cfg["slice_ch"] = 192, 384, [24, 24, 48, 96, 192]
+    return cfg
+
+
+def stf_united_entries(config=None) -> "OrderedDict[str, Entry]":
+    """Every state_dict entry of STF_united (reference: models/stf_united.py:403-678; 1440 tensors): the Swin analysis /
+    synthesis transforms plus ELIC_united's hyper and entropy nets at N=192, M=384, slices [24,24,48,96,192]."""
+    cfg = stf_config()
+    base = elic_united_entries(cfg)
+    b = _Builder()
+    E, depths, heads = STF_EMBED, STF_DEPTHS, STF_HEADS
+    # analysis: stf_united.py:403-502
+    for mod, cin in (("rgb", 3), ("depth", 1)):
+        b.conv(f"g_a.{mod}_patch_embed.proj", cin, E, 2)
+        b.layernorm(f"g_a.{mod}_patch_embed.norm", E)
+    for mod in ("rgb", "depth"):
+        dim, li = E, 0
+        for i in range(4):
+            p = f"g_a.{mod}_ana_layers.{li}"
+            for k in range(depths[i]):
+                b.swin_block(f"{p}.blocks.{k}", dim, heads[i])
+            if i < 3:
+                b.linear(f"{p}.downsample.reduction", 4 * dim, 2 * dim, bias=False)
+                b.layernorm(f"{p}.downsample.norm", 4 * dim)
+            dim *= 2
+            li += 1
+            if i < 3:
+                if mod == "rgb":
+                    b.bi_spf(f"g_a.rgb_ana_layers.{li}", dim)
+                li += 1
+    # synthesis: stf_united.py:505-602
+    for mod, cout in (("rgb", 3), ("depth", 1)):
+        dim, li = 8 * E, 0
+        for i in range(4):
+            p = f"g_s.{mod}_syn_layers.{li}"
+            for k in range(depths[3 - i]):
+                b.swin_block(f"{p}.blocks.{k}", dim, heads[3 - i])
+            if i < 3:
+                b.linear(f"{p}.downsample.reduction", dim, 2 * dim, bias=False)
+                b.layernorm(f"{p}.downsample.norm", dim)
+            dim //= 2
+            li += 1
+            if i < 3:
+                if mod == "rgb":
+                    b.bi_spf(f"g_s.rgb_syn_layers.{li}", dim)
+                li += 1
+        b.conv(f"g_s.{mod}_end_conv.0", E, 4 * E, 5)
+        b.conv(f"g_s.{mod}_end_conv.2", E, cout, 3)
+    out = OrderedDict(b.entries)
+    for k, v in base.items():
+        if not k.startswith(("g_a.", "g_s.")):
+            out[k] = v
+    return out
 
 
 def count_parameters(entries) -> int:

@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .arch import Entry, elic_entries, elic_united_entries, model_config
+from .arch import Entry, elic_entries, elic_united_entries, model_config, stf_config, stf_united_entries
 
 _IH_STD = math.sqrt(4.0 * (65536.0**2 - 1.0) / 12.0)  # std of the sum of four uniform 16-bit ints
 _IH_MEAN = 2.0 * 65535.0
@@ -60,6 +60,12 @@ def make_tensor(name: str, e: Entry, seed: int) -> np.ndarray:
     if e.kind == "linear_w":
         b = 1.0 / math.sqrt(e.fan_in)
         return uniform_like(name, seed, e.shape, -b, b)
+    if e.kind == "ln_w":  # nn.LayerNorm starts at (1, 0); perturbed so that the affine part is exercised
+        return (1.0 + uniform_like(name, seed, e.shape, -0.1, 0.1)).astype(np.float32)
+    if e.kind == "ln_b":
+        return uniform_like(name, seed, e.shape, -0.1, 0.1)
+    if e.kind == "rpb_table":  # trunc_normal_(std=0.02) in the reference; wider here so the bias matters
+        return normal_like(name, seed, e.shape, 0.3)
     if e.kind == "eb_matrix":
         idx = int(name[-1])
         return _eb_matrix_init(e.shape, idx) + normal_like(name, seed, e.shape, 0.05)
@@ -77,6 +83,11 @@ def make_tensor(name: str, e: Entry, seed: int) -> np.ndarray:
     if e.kind == "buffer":
         if e.dtype == "int32":
             return np.zeros(e.shape, dtype=np.int32)
+        if e.dtype == "int64":  # relative_position_index of a Swin window (stf_united.py:62-72)
+            ws = int(round(math.sqrt(e.shape[0])))
+            c = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij")).reshape(2, -1)
+            rel = (c[:, :, None] - c[:, None, :]).transpose(1, 2, 0) + (ws - 1)
+            return (rel[:, :, 0] * (2 * ws - 1) + rel[:, :, 1]).astype(np.int64)
         if name.endswith(".target"):
             t = math.log(2.0 / 1e-9 - 1.0)  # entropy_models.py:309-310
             return np.array([-t, 0.0, t], dtype=np.float32)
@@ -92,13 +103,21 @@ def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_tor
                          model: str = "ELIC_united", channel: int = 3):
     """Full state_dict (parameters + buffers) of ELIC_united (default) or the single-modal ELIC with deterministic
     synthetic values."""
-    cfg = model_config() if config is None else config
-    entries = elic_united_entries(cfg) if model == "ELIC_united" else elic_entries(cfg, channel)
+    if model == "STF_united":
+        cfg = stf_config()
+        entries = stf_united_entries()
+    else:
+        cfg = model_config() if config is None else config
+        entries = elic_united_entries(cfg) if model == "ELIC_united" else elic_entries(cfg, channel)
     sd = OrderedDict()
     for name, e in entries.items():
         sd[name] = make_tensor(name, e, seed)
     if stress and model == "ELIC_united":
         _apply_stress(sd, cfg)
+    elif stress and model == "STF_united":
+        _apply_stress(sd, cfg, transforms=False)
+        for mod in ("rgb", "depth"):  # latents of a few units: the last patch-merging projection feeds the final stage
+            sd[f"g_a.{mod}_ana_layers.4.downsample.reduction.weight"] *= np.float32(STF_Y_GAIN)
     elif stress:
         _apply_stress_single(sd, cfg)
     if as_torch:
@@ -108,10 +127,14 @@ def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_tor
     return sd
 
 
-def _apply_stress(sd, cfg):
+STF_Y_GAIN = 12.0
+
+
+def _apply_stress(sd, cfg, transforms=True):
     slice_ch = list(cfg["slice_ch"])
     for mod in ("rgb", "depth"):
-        sd[f"g_a.{mod}_analysis_transform.16.weight"] *= np.float32(48.0)
+        if transforms:
+            sd[f"g_a.{mod}_analysis_transform.16.weight"] *= np.float32(48.0)
     for mod in ("rgb", "depth"):
         sd[f"h_a.{mod}_reduction.4.weight"] *= np.float32(24.0)  # |z| of a few units: exercises the z coder
     for m in ("r", "d"):

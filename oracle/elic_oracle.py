@@ -296,6 +296,7 @@ class OracleCodec:
         self.gc = None
         self.eb = {}
         self.trace = None  # when a dict, per-part intermediates are recorded
+        self.g_a, self.g_s = g_a, g_s  # transform pair (the Swin variant swaps these, models/stf_united.py:641-677)
 
     def update(self):  # elic_united.py:580-586
         self.gc = gaussian_tables(self.table)
@@ -367,7 +368,7 @@ class OracleCodec:
 
     @torch.no_grad()
     def compress(self, rgb: torch.Tensor, depth: torch.Tensor):  # elic_united.py:403-427
-        y_r, y_d = g_a(self.sd, rgb, depth)
+        y_r, y_d = self.g_a(self.sd, rgb, depth)
         z_r, z_d = h_a(self.sd, y_r, y_d)
         zs_r, _ = self._z_compress("rgb", z_r)
         zh_r = self._z_decompress("rgb", zs_r, z_r.shape[-2:])
@@ -475,8 +476,153 @@ class OracleCodec:
         zh_d = self._z_decompress("depth", d_strings[1], shape)
         hyp_r, hyp_d = h_s(self.sd, zh_r, zh_d)
         yhat_r, yhat_d = self.decompress_united(r_strings[0][0], hyp_r, d_strings[0][0], hyp_d)
-        xr, xd = g_s(self.sd, yhat_r, yhat_d)
+        xr, xd = self.g_s(self.sd, yhat_r, yhat_d)
         return {"x_hat": {"r": xr.clamp_(0, 1), "d": xd.clamp_(0, 1)}, "cost_time": time.process_time() - t0}
+
+
+# --------------------------------------------------------------------------------------------------
+# STF_united (models/stf_united.py): Swin analysis / synthesis transforms on top of ELIC_united's entropy model
+# --------------------------------------------------------------------------------------------------
+STF_DEPTHS, STF_HEADS, STF_EMBED, STF_WS = (2, 2, 6, 2), (3, 6, 12, 24), 48, 4
+
+
+def _ln(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def _win_part(x, ws):  # stf_united.py:34-38
+    B, H, W, C = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+
+
+def _win_rev(w, ws, H, W):  # stf_united.py:41-45
+    B = int(w.shape[0] / (H * W / ws / ws))
+    return w.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def _swin_block(sd, p, x, H, W, shift, heads, mask):  # stf_united.py:48-214
+    ws = STF_WS
+    B, L, C = x.shape
+    shortcut = x
+    x = _ln(sd, p + ".norm1", x).view(B, H, W, C)
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = x.shape[1], x.shape[2]
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = _win_part(x, ws).view(-1, ws * ws, C)
+    B_, N = xw.shape[0], ws * ws
+    qkv = F.linear(xw, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
+    qkv = qkv.reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4).contiguous()
+    q, k, v = qkv[0] * ((C // heads) ** -0.5), qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    rpb = sd[p + ".attn.relative_position_bias_table"][sd[p + ".attn.relative_position_index"].view(-1)]
+    attn = attn + rpb.view(N, N, -1).permute(2, 0, 1).contiguous().unsqueeze(0)
+    if shift > 0:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    attn = torch.softmax(attn, dim=-1)
+    xo = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    xo = F.linear(xo, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"])
+    x = _win_rev(xo.view(-1, ws, ws, C), ws, Hp, Wp)
+    if shift > 0:
+        x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
+    if pad_r > 0 or pad_b > 0:
+        x = x[:, :H, :W, :].contiguous()
+    x = shortcut + x.view(B, H * W, C)
+    t = F.linear(_ln(sd, p + ".norm2", x), sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])
+    t = F.linear(F.gelu(t), sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    return x + t
+
+
+def _shift_mask(H, W):  # stf_united.py:329-352
+    ws, sh = STF_WS, STF_WS // 2
+    Hp, Wp = int(np.ceil(H / ws)) * ws, int(np.ceil(W / ws)) * ws
+    img = torch.zeros((1, Hp, Wp, 1))
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -sh), slice(-sh, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -sh), slice(-sh, None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = _win_part(img, ws).view(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return m.masked_fill(m != 0, float(-100.0)).masked_fill(m == 0, float(0.0))
+
+
+def _basic_layer(sd, p, x, H, W, depth, heads, down):  # stf_united.py:270-366
+    mask = _shift_mask(H, W)
+    for k in range(depth):
+        x = _swin_block(sd, f"{p}.blocks.{k}", x, H, W, 0 if k % 2 == 0 else STF_WS // 2, heads, mask)
+    if down == "merge":  # PatchMerging, stf_union.py:217-249
+        B, L, C = x.shape
+        x = x.view(B, H, W, C)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1)
+        x = x.view(B, -1, 4 * C)
+        x = F.linear(_ln(sd, p + ".downsample.norm", x), sd[p + ".downsample.reduction.weight"])
+        return x, (H + 1) // 2, (W + 1) // 2
+    if down == "split":  # PatchSplit, stf_united.py:252-267
+        B, L, C = x.shape
+        x = F.linear(_ln(sd, p + ".downsample.norm", x), sd[p + ".downsample.reduction.weight"])
+        x = F.pixel_shuffle(x.permute(0, 2, 1).contiguous().view(B, 2 * C, H, W), 2)
+        return x.permute(0, 2, 3, 1).contiguous().view(B, 4 * L, -1), 2 * H, 2 * W
+    return x, H, W
+
+
+def _stf_stack(sd, root, rgb, depth, Wh, Ww, depths, heads, down):
+    B = rgb.shape[0]
+    li = 0
+    for i in range(4):
+        dn = down if i < 3 else None
+        rgb, _, _ = _basic_layer(sd, f"{root}.rgb_{root_kind2(root)}_layers.{li}", rgb, Wh, Ww, depths[i], heads[i], dn)
+        depth, Wh, Ww = _basic_layer(sd, f"{root}.depth_{root_kind2(root)}_layers.{li}", depth, Wh, Ww, depths[i], heads[i], dn)
+        li += 1
+        if i < 3:  # Bi-CPT fusion as a residual (stf_united.py:481-489 / 581-589)
+            r = rgb.view(B, Wh, Ww, -1).permute(0, 3, 1, 2).contiguous()
+            d = depth.view(B, Wh, Ww, -1).permute(0, 3, 1, 2).contiguous()
+            rf, df = _bi_spf(sd, f"{root}.rgb_{root_kind2(root)}_layers.{li}", r, d)
+            rgb = (r + rf).flatten(2).transpose(1, 2)
+            depth = (d + df).flatten(2).transpose(1, 2)
+            li += 1
+    return rgb, depth, Wh, Ww
+
+
+def root_kind2(root):
+    return "ana" if root == "g_a" else "syn"
+
+
+def g_a_stf(sd, rgb, depth):  # stf_united.py:462-502
+    outs = []
+    for mod, x in (("rgb", rgb), ("depth", depth)):
+        x = F.conv2d(x, sd[f"g_a.{mod}_patch_embed.proj.weight"], sd[f"g_a.{mod}_patch_embed.proj.bias"], stride=2)
+        Wh, Ww = x.shape[2], x.shape[3]
+        x = _ln(sd, f"g_a.{mod}_patch_embed.norm", x.flatten(2).transpose(1, 2))
+        x = x.transpose(1, 2).view(-1, STF_EMBED, Wh, Ww)
+        outs.append(x.flatten(2).transpose(1, 2))
+    r, d, Wh, Ww = _stf_stack(sd, "g_a", outs[0], outs[1], Wh, Ww, STF_DEPTHS, STF_HEADS, "merge")
+    C = STF_EMBED * 8
+    return (r.view(-1, Wh, Ww, C).permute(0, 3, 1, 2).contiguous(), d.view(-1, Wh, Ww, C).permute(0, 3, 1, 2).contiguous())
+
+
+def g_s_stf(sd, rgb, depth):  # stf_united.py:564-602
+    B, C, Wh, Ww = rgb.shape
+    r = rgb.permute(0, 2, 3, 1).contiguous().view(-1, Wh * Ww, C)
+    d = depth.permute(0, 2, 3, 1).contiguous().view(-1, Wh * Ww, C)
+    r, d, Wh, Ww = _stf_stack(sd, "g_s", r, d, Wh, Ww, STF_DEPTHS[::-1], STF_HEADS[::-1], "split")
+    outs = []
+    for mod, x in (("rgb", r), ("depth", d)):
+        x = x.view(-1, Wh, Ww, STF_EMBED).permute(0, 3, 1, 2).contiguous()
+        x = F.pixel_shuffle(_conv(sd, f"g_s.{mod}_end_conv.0", x), 2)
+        outs.append(_conv(sd, f"g_s.{mod}_end_conv.2", x))
+    return outs[0], outs[1]
+
+
+def oracle_stf(state_dict):
+    """OracleCodec for STF_united: ELIC_united's compress/decompress with the Swin transforms and its own widths."""
+    c = OracleCodec(state_dict, {"N": 192, "M": 384, "slice_ch": [24, 24, 48, 96, 192]})
+    c.g_a, c.g_s = g_a_stf, g_s_stf
+    return c
 
 
 # --------------------------------------------------------------------------------------------------
