@@ -144,6 +144,14 @@ int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int
                                 float* x_dev, void* stream);
 
 /*
+ * STF_united (BASELINE config 5): replaces models/stf_united.py: SymmetricalTransFormerUnited :605-678 with
+ * AnalysisTransformSTFunited :403-502 / SynthesisTransformSTFunited :505-602 (Swin blocks :118-214, PatchMerging :217-249,
+ * PatchSplit :252-267, BasicLayer :270-366, PatchEmbed :369-400).  Everything behind the transforms is ELIC_united's (same
+ * compress / decompress / forward entry points above); nn.Linear weights are passed as (out, in, 1, 1).
+ */
+int rgbd_elic_create_stf(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out);
+
+/*
  * Eval-mode forward(): replaces ELIC_united.forward / entropy_estimate_united / codeOnePart (models/elic_united.py:94-263)
  * and the likelihood halves of EntropyBottleneck.forward / GaussianConditional.forward (entropy_models.py:391-428,
  * 534-558).  x_hat is NOT clamped (as in the reference); likelihoods are lower-bounded at 1e-9.

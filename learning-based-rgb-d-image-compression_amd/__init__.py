@@ -9,7 +9,10 @@ from . import _lib, ans, distributed, entropy_models  # noqa: F401,E402
 from .elic_united import ELIC_united, modelZoo  # noqa: F401,E402
 from .elic import ELIC  # noqa: F401,E402
 
+from .stf_united import STF_united, SymmetricalTransFormerUnited  # noqa: F401,E402
+
 modelZoo["ELIC"] = ELIC
+modelZoo["STF_united"] = SymmetricalTransFormerUnited  # models/__init__.py:11-20
 from .pool import CodecPool  # noqa: F401,E402
 from . import datautils, ioutils, metrics, tester  # noqa: F401,E402
 from .tester import TesterSingle, TesterUnited  # noqa: F401,E402

@@ -38,7 +38,7 @@ struct TapTable {
     int8_t n[4];
 };
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };
 
 struct ConvArgs {
     const float* x;  // input NHWC (already offset to the first input channel)
@@ -49,7 +49,9 @@ struct ConvArgs {
     const float* bias;  // [cout_pad]
     float* y;  // output NHWC (already offset to the first output channel)
     int OH, OW, ycs;
-    int cout_pad;  // channels written (multiple of 16)
+    int cout_pad;  // channels computed (multiple of 16)
+    int cout_store;  // channels written (multiple of 4, <= cout_pad; 0 = cout_pad): narrower when the output is a channel
+                     // slice whose width is not a multiple of 16 (the tail would land in the neighbouring slice)
     int GH, GW;  // tile-grid extent (output positions per phase)
     int IS, OS;  // input step / output step per grid position
     int nphase;  // 1, or 4 for stride-2 transposed conv (phase = py*2+px)
@@ -108,6 +110,13 @@ int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const
                             hipStream_t s);
 int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s);
 int launch_fill_zero(float* p, size_t n, hipStream_t s);
+// swin.hip (STF_united)
+int launch_layernorm(const float* x, size_t ntok, int C, int xcs, const float* w, const float* b, float* y, int ycs,
+                     hipStream_t s);
+int launch_window_attention(const float* qkv, int B, int H, int W, int C, int qcs, int heads, int shift, const float* rpb,
+                            float* out, int ocs, hipStream_t s);
+int launch_patch_merge_gather(const float* x, int B, int H, int W, int C, int xcs, float* y, int ycs, hipStream_t s);
+int launch_pixel_shuffle2(const float* x, int B, int H, int W, int Co, int xcs, float* y, int ycs, hipStream_t s);
 
 // ---- entropy stage (entropy.hip) --------------------------------------------------------------
 struct DevTables {  // packed CDF rows for the device coder

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 const int wmc = c4 / (4 * EMT), ii = (c4 / 4) % EMT;
                 const int cb = co0 + (wmc * MT + ip + ii) * 16 + (c4 & 3) * 4;
                 const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
-                ok[u] = ip + ii < MT && cb < a.cout_pad && gy < a.GH && gx < a.GW;
+                ok[u] = ip + ii < MT && cb < a.cout_store && gy < a.GH && gx < a.GW;
                 cbs[u] = cb;
                 pixs[u] = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
                 v[u] = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 } else if (a.act == ACT_SIGMOID) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w[e] = 1.0f / (1.0f + expf(-w[e]));
+                } else if (a.act == ACT_GELU) {  // nn.GELU (erf form)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = 0.5f * w[e] * (1.0f + erff(w[e] * 0.70710678118654752f));
                 }
                 if (a.mul) w *= ml[u];
                 if (a.res2) w += r2[u];
@@ -485,6 +488,7 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / c4n;
         const int cb = (int)(i - pix * c4n) * 4;
+        if (cb >= a.cout_store) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(a.partial + pix * a.cout_pad + cb);
         for (int s = 1; s < a.splitk; ++s) v += *reinterpret_cast<const f32x4*>(a.partial + s * plane + pix * a.cout_pad + cb);
         v += *reinterpret_cast<const f32x4*>(a.bias + cb);
@@ -498,6 +502,9 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
         } else if (a.act == ACT_SIGMOID) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        } else if (a.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
         }
         if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb);
         if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb);
@@ -562,6 +569,8 @@ long conv_log_read(char* buf, long cap)
 int launch_conv(const ConvArgs& a_in, hipStream_t s)
 {
     ConvArgs a = a_in;
+    if (a.cout_store <= 0 || a.cout_store > a.cout_pad) a.cout_store = a.cout_pad;
+    if (a.cout_store % 4) return RGBD_EINVAL;
     if (a.splitk < 1) a.splitk = 1;
     if (a.splitk > a.cin_pad / 16) a.splitk = a.cin_pad / 16;
     if (a.splitk > 1 && !a.partial) return RGBD_EINVAL;

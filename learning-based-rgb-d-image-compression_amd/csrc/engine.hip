@@ -377,6 +377,9 @@ struct rgbd_elic {
         a.OW = OW;
         a.ycs = y.cs;
         a.cout_pad = pc->cout_pad;
+        // a channel slice narrower than its 16-padded width inside a wider buffer (STF_united: 24 of 48): stop at the
+        // slice end; a buffer of its own gets its pad channels zeroed as usual
+        a.cout_store = (pc->cout % 16 && y.cs != round_up(pc->cout, 16)) ? round_up(pc->cout, 4) : pc->cout_pad;
         make_taps(*pc, stride, pad, &a);
         a.GH = pc->transposed ? x.h : OH;
         a.GW = pc->transposed ? x.w : OW;
@@ -524,7 +527,7 @@ struct rgbd_elic {
     }
 
     // modules/transform/attention.py:84-97; x: [.., n_feats]; writes x * sigmoid(...) into dst
-    void esa(const std::string& p, const Act& x, const Act& dst)
+    void esa(const std::string& p, const Act& x, const Act& dst, const Act* add = nullptr)
     {
         const size_t mark = arena.top;
         Act c1_ = conv(p + ".conv1", x, 1, 0);
@@ -555,13 +558,15 @@ struct rgbd_elic {
         Epi gate;
         gate.act = ACT_SIGMOID;
         gate.mul = &x;
+        gate.res2 = add;  // STF_united adds the gated features to the stream instead of concatenating them
         conv(p + ".conv4", sum, 1, 0, gate, &dst);
         arena.top = mark;
     }
 
     // modules/transform/attention.py:35-48; rgb/depth: views of N channels; writes the gated features into
     // r_dst / d_dst (N channels each)
-    void bi_spf(const std::string& p, const Act& rgb, const Act& depth, const Act& r_dst, const Act& d_dst)
+    void bi_spf(const std::string& p, const Act& rgb, const Act& depth, const Act& r_dst, const Act& d_dst,
+                bool residual = false)
     {
         const size_t mark = arena.top;
         const int half = rgb.c / 2;
@@ -574,8 +579,8 @@ struct rgbd_elic {
         conv(p + ".d_ext", depth, 1, 1, relu, &df);
         copy_ch(df, view(dr, 0, half));
         copy_ch(rf, view(dr, half, half));
-        esa(p + ".r_esa", rd, r_dst);
-        esa(p + ".d_esa", dr, d_dst);
+        esa(p + ".r_esa", rd, r_dst, residual ? &rgb : nullptr);
+        esa(p + ".d_esa", dr, d_dst, residual ? &depth : nullptr);
         arena.top = mark;
     }
 
@@ -894,6 +899,119 @@ struct rgbd_elic {
         }
     }
 
+    // ---- STF_united (models/stf_united.py; BASELINE config 5): Swin transforms on [B,H,W,C] token maps -------------
+    Act layernorm(const std::string& p, const Act& x)
+    {
+        Act y = alloc(x.n, x.h, x.w, x.c);
+        float* w = dense_of(p + ".weight");
+        float* b = dense_of(p + ".bias");
+        if (dry() || rc || !w || !b) return y;
+        const int r = launch_layernorm(x.p, (size_t)x.n * x.h * x.w, x.c, x.cs, w, b, y.p, y.cs, s);
+        if (r) fail(r);
+        return y;
+    }
+    // stf_united.py:118-214: x + proj(attn(norm1(x))), then + mlp(norm2(.)); GELU and both adds are conv epilogues
+    Act swin_block(const std::string& p, const Act& x, int shift, int heads)
+    {
+        Act out = alloc(x.n, x.h, x.w, x.c);
+        const size_t mark = arena.top;
+        Act t = layernorm(p + ".norm1", x);
+        Act qkv = conv(p + ".attn.qkv", t, 1, 0);
+        Act a = alloc(x.n, x.h, x.w, x.c);
+        float* rpb = dense_of(p + ".attn.relative_position_bias_table");
+        if (!dry() && !rc && rpb) {
+            const int r = launch_window_attention(qkv.p, x.n, x.h, x.w, x.c, qkv.cs, heads, shift, rpb, a.p, a.cs, s);
+            if (r) fail(r);
+        }
+        Epi e1;
+        e1.res1 = &x;
+        Act x1 = conv(p + ".attn.proj", a, 1, 0, e1);
+        Act t2 = layernorm(p + ".norm2", x1);
+        Epi g;
+        g.act = ACT_GELU;
+        Act hdn = conv(p + ".mlp.fc1", t2, 1, 0, g);
+        Epi e2;
+        e2.res1 = &x1;
+        conv(p + ".mlp.fc2", hdn, 1, 0, e2, &out);
+        arena.top = mark;
+        return out;
+    }
+    // stf_united.py:270-366; down: 0 none, 1 PatchMerging (:217-249), 2 PatchSplit (:252-267)
+    Act basic_layer(const std::string& p, const Act& x_in, int depth, int heads, int down)
+    {
+        Act x = x_in;
+        for (int k = 0; k < depth; ++k) x = swin_block(p + ".blocks." + std::to_string(k), x, (k & 1) ? 2 : 0, heads);
+        if (down == 1) {
+            Act g4 = alloc(x.n, x.h / 2, x.w / 2, 4 * x.c);
+            if (!dry() && !rc) {
+                const int r = launch_patch_merge_gather(x.p, x.n, x.h, x.w, x.c, x.cs, g4.p, g4.cs, s);
+                if (r) fail(r);
+            }
+            Act t = layernorm(p + ".downsample.norm", g4);
+            return conv(p + ".downsample.reduction", t, 1, 0);
+        }
+        if (down == 2) {
+            Act t = layernorm(p + ".downsample.norm", x);
+            Act r2 = conv(p + ".downsample.reduction", t, 1, 0);
+            Act y = alloc(x.n, 2 * x.h, 2 * x.w, x.c / 2);
+            if (!dry() && !rc) {
+                const int r = launch_pixel_shuffle2(r2.p, x.n, x.h, x.w, x.c / 2, r2.cs, y.p, y.cs, s);
+                if (r) fail(r);
+            }
+            return y;
+        }
+        return x;
+    }
+    void stf_stack(const std::string& root, const char* kind, const Act& r_in, const Act& d_in, const int* depths,
+                   const int* heads, int down, Act* r_out, Act* d_out)
+    {
+        Act r = r_in, d = d_in;
+        int li = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int dn = i < 3 ? down : 0;
+            const std::string pr = root + ".rgb_" + kind + "_layers." + std::to_string(li);
+            const std::string pd = root + ".depth_" + kind + "_layers." + std::to_string(li);
+            r = basic_layer(pr, r, depths[i], heads[i], dn);
+            d = basic_layer(pd, d, depths[i], heads[i], dn);
+            ++li;
+            if (i < 3) {  // Bi-CPT fusion added to the streams (stf_united.py:481-489 / 581-589)
+                Act r2 = alloc(r.n, r.h, r.w, r.c), d2 = alloc(d.n, d.h, d.w, d.c);
+                bi_spf(root + ".rgb_" + kind + "_layers." + std::to_string(li), r, d, r2, d2, true);
+                r = r2;
+                d = d2;
+                ++li;
+            }
+        }
+        *r_out = r;
+        *d_out = d;
+    }
+    void g_a_stf(const Act& rgb, const Act& depth, Act* y_r, Act* y_d)
+    {
+        static const int depths[4] = {2, 2, 6, 2}, heads[4] = {3, 6, 12, 24};
+        Act r = layernorm("g_a.rgb_patch_embed.norm", conv("g_a.rgb_patch_embed.proj", rgb, 2, 0));
+        Act d = layernorm("g_a.depth_patch_embed.norm", conv("g_a.depth_patch_embed.proj", depth, 2, 0));
+        stf_stack("g_a", "ana", r, d, depths, heads, 1, y_r, y_d);
+    }
+    void g_s_stf(const Act& yr, const Act& yd, Act* xr, Act* xd)
+    {
+        static const int depths[4] = {2, 6, 2, 2}, heads[4] = {24, 12, 6, 3};
+        Act r, d;
+        stf_stack("g_s", "syn", yr, yd, depths, heads, 2, &r, &d);
+        const char* mods[2] = {"rgb", "depth"};
+        const Act* in[2] = {&r, &d};
+        Act* out[2] = {xr, xd};
+        for (int m = 0; m < 2; ++m) {  // stf_united.py:550-559
+            const std::string p = std::string("g_s.") + mods[m] + "_end_conv.";
+            Act t = conv(p + "0", *in[m], 1, 2);
+            Act u = alloc(t.n, 2 * t.h, 2 * t.w, t.c / 4);
+            if (!dry() && !rc) {
+                const int q = launch_pixel_shuffle2(t.p, t.n, t.h, t.w, t.c / 4, t.cs, u.p, u.cs, s);
+                if (q) fail(q);
+            }
+            *out[m] = conv(p + "2", u, 1, 1);
+        }
+    }
+
     // ---- single-modal ELIC (models/elic.py:15-57; BASELINE config 1) ------------------------------------------
     // analysis.py:29-52 / synthesis.py:32-70: the same blocks as above without the cross-modal fusion stages
     Act stack1(const std::string& prefix, const char* const* kinds, int n, const Act& x_in)
@@ -1095,7 +1213,8 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
             if (exclusive_transforms && !dry()) phase.lock();
             const size_t mark = arena.top;
             Act yr_t, yd_t;
-            g_a(rgb, depth, &yr_t, &yd_t);
+            if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
+            else g_a(rgb, depth, &yr_t, &yd_t);
             copy_ch(yr_t, y_r);
             copy_ch(yd_t, y_d);
             arena.top = mark;
@@ -1137,6 +1256,11 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     named["hyper_r"] = hyp_r;
     named["hyper_d"] = hyp_d;
     Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+    if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
+        int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
+        if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
+        if (zr) fail(zr);
+    }
     named["yhat_r"] = yhat_r;
     named["yhat_d"] = yhat_d;
     Coding cd;
@@ -1206,7 +1330,8 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     {
         const size_t mark = arena.top;
         Act yr_t, yd_t;
-        g_a(rgb, depth, &yr_t, &yd_t);
+        if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
+        else g_a(rgb, depth, &yr_t, &yd_t);
         copy_ch(yr_t, y_r);
         copy_ch(yd_t, y_d);
         arena.top = mark;
@@ -1230,6 +1355,11 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     Act hyp_r, hyp_d;
     h_s(zh_r, zh_d, &hyp_r, &hyp_d);
     Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+    if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
+        int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
+        if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
+        if (zr) fail(zr);
+    }
     Coding cd;
     cd.estimate = true;
     cd.lik[0] = alloc(B, h, w, M);
@@ -1240,7 +1370,8 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     named["yhat_r"] = yhat_r;
     named["yhat_d"] = yhat_d;
     Act xr, xd;
-    g_s(yhat_r, yhat_d, &xr, &xd);
+    if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
+    else g_s(yhat_r, yhat_d, &xr, &xd);
     if (rc) return rc;
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 0, s);
@@ -1368,6 +1499,11 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
         named["hyper_d"] = hyp_d;
     }
     Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+    if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
+        int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
+        if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
+        if (zr) fail(zr);
+    }
     named["yhat_r"] = yhat_r;
     named["yhat_d"] = yhat_d;
     Coding cd;
@@ -1397,7 +1533,8 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
         HIP_TRY(hipStreamSynchronize(s));  // wait for our own serial phase outside the lock
         phase.lock();
     }
-    g_s(yhat_r, yhat_d, &xr, &xd);
+    if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
+    else g_s(yhat_r, yhat_d, &xr, &xd);
     if (rc) return rc;
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 1, s);
@@ -1971,7 +2108,7 @@ int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_sl
     if (!out || !slice_ch || n_slices <= 0 || N % 16 || M % 16) return RGBD_EINVAL;
     int sum = 0;
     for (int i = 0; i < n_slices; ++i) {
-        if (slice_ch[i] <= 0 || slice_ch[i] % 16) return RGBD_EINVAL;
+        if (slice_ch[i] <= 0 || slice_ch[i] % 8) return RGBD_EINVAL;  // 16-byte channel views; STF_united has 24-wide slices
         sum += slice_ch[i];
     }
     if (sum != M) return RGBD_EINVAL;
@@ -1984,6 +2121,15 @@ int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_sl
 }
 
 static int check_ready(const rgbd_elic* m);
+
+int rgbd_elic_create_stf(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out)
+{
+    if (M != 384) return RGBD_EINVAL;  // embed_dim 48 * 8 (models/stf_united.py:640)
+    const int r = rgbd_elic_create(N, M, slice_ch, n_slices, out);
+    if (r) return r;
+    (*out)->variant = 2;
+    return RGBD_OK;
+}
 
 int rgbd_elic_create_single(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, int32_t in_ch, rgbd_elic** out)
 {
@@ -2153,6 +2299,13 @@ int rgbd_elic_finalize(rgbd_elic* m)
             float* d = nullptr;
             HIP_TRY(hipMalloc((void**)&d, hv.size() * sizeof(float)));
             HIP_TRY(hipMemcpy(d, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+            m->dense[name] = d;
+        } else if ((t.shape.size() == 1 && (name.find(".norm") != std::string::npos)) ||
+                   ends_with(name, "relative_position_bias_table")) {
+            // Swin LayerNorm affine parameters and relative position bias tables: plain device arrays
+            float* d = nullptr;
+            HIP_TRY(hipMalloc((void**)&d, t.v.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(d, t.v.data(), t.v.size() * sizeof(float), hipMemcpyHostToDevice));
             m->dense[name] = d;
         } else if (ends_with(name, "entropy_bottleneck.quantiles")) {
             // medians = quantiles[:, 0, 1]  (entropy_models.py:316-318)

@@ -170,6 +170,8 @@ class ELIC_united:
                 continue
             t = p[name].detach().float().contiguous()
             a = t.numpy()
+            if e.kind == "linear_w" and ".fc." not in name:  # nn.Linear of the Swin blocks -> 1x1 convolution
+                a = a.reshape(a.shape[0], a.shape[1], 1, 1)
             shape = (ctypes.c_int64 * a.ndim)(*a.shape)
             check(L.rgbd_elic_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shape,
                                          a.ndim), f"set_tensor({name})")

@@ -1,0 +1,132 @@
+"""STF_united (BASELINE config 5; reference models/stf_united.py) on the GPU vs the CPU oracle and the reference golden.
+Same layered contract as tests/test_gpu_model.py; the Swin transforms add LayerNorm / softmax / erf, so the float stage is
+checked to 5e-5 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_utils import require_gpu
+from oracle import coder
+from oracle import elic_oracle as eo
+from test_gpu_model import _rel, _walk_parts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd5():
+    from rgbd_amd import synth
+
+    return synth.synthetic_state_dict(0, model="STF_united")
+
+
+@pytest.fixture(scope="module")
+def net5(sd5):
+    require_gpu()
+    import rgbd_amd
+
+    m = rgbd_amd.modelZoo["STF_united"](config=rgbd_amd.model_config(), channel=4).eval()
+    m.load_state_dict(sd5, strict=True)
+    assert m.update(force=True)
+    assert m.count_parameters() == 170296044
+    return m.to("cuda")
+
+
+@pytest.fixture(scope="module")
+def orc5(sd5):
+    c = eo.oracle_stf(sd5)
+    c.update()
+    return c
+
+
+def test_config5_256(net5, orc5):
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stf_c5_256x256.npz"))
+    r, d = synth.synthetic_batch(1, 256, 256, config_id=5)
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    out = net5.compress(r.cuda(), d.cuda())
+    assert tuple(out["shape"]) == (4, 4)
+    orc5.trace = {}
+    orc5.compress(r, d)
+    tr, orc5.trace = orc5.trace, None
+    # float stage: the Swin analysis transform + hyper analysis against the oracle and the reference's own latents
+    for name in ("y_r", "y_d", "z_r", "z_d"):
+        got = net5.debug_tensor(name)
+        assert _rel(got, tr[name].numpy()) < 5e-5, (name, _rel(got, tr[name].numpy()))
+    assert _rel(net5.debug_tensor("y_r"), g["y_r"]) < 5e-5 and _rel(net5.debug_tensor("y_d"), g["y_d"]) < 5e-5
+    # integer stage 1: z streams from the GPU's own z floats; hyper synthesis on the GPU's own z_hat
+    for mod, key, zname in (("rgb", "r_strings", "z_r"), ("depth", "d_strings", "z_d")):
+        strings, _ = orc5._z_compress(mod, torch.from_numpy(net5.debug_tensor(zname)))
+        assert strings == out[key][1]
+    zh = [torch.from_numpy(net5.debug_tensor(n)) for n in ("zhat_r", "zhat_d")]
+    ohr, ohd = eo.h_s(orc5.sd, zh[0], zh[1])
+    assert _rel(net5.debug_tensor("hyper_r"), ohr.numpy()) < 2e-5 and _rel(net5.debug_tensor("hyper_d"), ohd.numpy()) < 2e-5
+    # integer stage 2: y streams from the GPU's own symbols / indexes
+    gsym, gidx = {}, {}
+    for mod, key in ((0, "r_strings"), (1, "d_strings")):
+        gsym[mod], gidx[mod] = net5.debug_symbols(mod)
+        assert gsym[mod].shape[0] == 384 * 16 * 16
+        assert coder.rans_encode(gsym[mod], gidx[mod], orc5.gc) == out[key][0][0]
+    # Bi-CEE against the oracle run on the GPU's own latents and hyper parameters (a z symbol on a rounding boundary would
+    # otherwise change every context): flips must be decision-boundary cases
+    gy = [torch.from_numpy(net5.debug_tensor(n)) for n in ("y_r", "y_d")]
+    gh = [torch.from_numpy(net5.debug_tensor(n)) for n in ("hyper_r", "hyper_d")]
+    orc5.trace = {}
+    osr, osd = orc5.compress_united(gy[0], gh[0], gy[1], gh[1])
+    tr2, orc5.trace = orc5.trace, None
+    clean = _walk_parts(tr2, gsym, gidx, orc5, {0: gy[0], 1: gy[1]})
+    print(f"STF_united: parts identical before the first boundary flip: {clean} of {len(tr2['parts'])};",
+          "y streams identical to the oracle on the same latents:", out["r_strings"][0] == osr and out["d_strings"][0] == osd,
+          "| to the reference golden:", out["r_strings"][0][0] == g["r_y"].tobytes())
+    assert clean >= 1
+    assert abs(len(out["r_strings"][0][0]) - g["r_y"].shape[0]) <= 256
+    yhat_enc = [net5.debug_tensor("yhat_r").copy(), net5.debug_tensor("yhat_d").copy()]
+    rec = net5.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert np.array_equal(net5.debug_tensor("yhat_r"), yhat_enc[0]) and np.array_equal(net5.debug_tensor("yhat_d"), yhat_enc[1])
+    xr, xd = rec["x_hat"]["r"].cpu(), rec["x_hat"]["d"].cpu()
+    assert xr.shape == (1, 3, 256, 256) and xd.shape == (1, 1, 256, 256)
+    oxr, oxd = eo.g_s_stf(orc5.sd, torch.from_numpy(yhat_enc[0]), torch.from_numpy(yhat_enc[1]))
+    oxr, oxd = oxr.clamp(0, 1), oxd.clamp(0, 1)
+    assert (xr - oxr).abs().max() < 2e-4 and (xd - oxd).abs().max() < 2e-4
+    assert abs(eo.psnr(xr, r) - eo.psnr(oxr, r)) < 1e-4 and abs(eo.psnr(xd, d) - eo.psnr(oxd, d)) < 1e-4
+
+
+def test_batch_invariance_and_forward(net5):
+    from rgbd_amd import synth
+
+    r, d = synth.synthetic_batch(2, 256, 320, config_id=6)  # the ESA pooling needs H/16, W/16 >= 15 (as in the reference)
+    r, d = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+    net5.per_image_streams = True
+    try:
+        out = net5.compress(r, d)
+        rec = net5.decompress(out["r_strings"], out["d_strings"], out["shape"])
+        for i in range(2):
+            one = net5.compress(r[i:i + 1], d[i:i + 1])
+            assert one["r_strings"][0][0] == out["r_strings"][0][i] and one["d_strings"][0][0] == out["d_strings"][0][i]
+    finally:
+        net5.per_image_streams = False
+    fw = net5.forward(r, d)  # eval forward: same x_hat (before the clamp) as decompress(compress())
+    assert torch.equal(fw["x_hat"]["r"].clamp(0, 1), rec["x_hat"]["r"]) and torch.equal(fw["x_hat"]["d"].clamp(0, 1), rec["x_hat"]["d"])
+
+
+def test_config5_full_size_512(net5, orc5):
+    """BASELINE config 5 at its full size (one 512x512 RGB-D pair): decoder == encoder on the latents, x_hat == eval
+    forward(), analysis transform against the oracle."""
+    from rgbd_amd import synth
+
+    r, d = synth.synthetic_batch(1, 512, 512, config_id=5)
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    out = net5.compress(r.cuda(), d.cuda())
+    assert tuple(out["shape"]) == (8, 8)
+    oy_r, oy_d = eo.g_a_stf(orc5.sd, r, d)
+    assert _rel(net5.debug_tensor("y_r"), oy_r.numpy()) < 5e-5 and _rel(net5.debug_tensor("y_d"), oy_d.numpy()) < 5e-5
+    yhat_enc = [net5.debug_tensor("yhat_r").copy(), net5.debug_tensor("yhat_d").copy()]
+    rec = net5.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert np.array_equal(net5.debug_tensor("yhat_r"), yhat_enc[0]) and np.array_equal(net5.debug_tensor("yhat_d"), yhat_enc[1])
+    fw = net5.forward(r.cuda(), d.cuda())
+    assert torch.equal(fw["x_hat"]["r"].clamp(0, 1), rec["x_hat"]["r"]) and torch.equal(fw["x_hat"]["d"].clamp(0, 1), rec["x_hat"]["d"])
+    bpp = sum(len(s) for k in ("r_strings", "d_strings") for lst in out[k] for s in lst) * 8.0 / (512 * 512)
+    assert np.isfinite(bpp) and bpp > 0
