@@ -22,14 +22,15 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WORKLOADS = {
-    # name: (batch per GPU, H, W, synthetic config id)
-    "c2_8x256x256": (8, 256, 256, 2),
-    "c3_4x480x640": (4, 480, 640, 3),
+    # name: (batch per GPU, H, W, synthetic config id, model)
+    "c2_8x256x256": (8, 256, 256, 2, "ELIC_united"),
+    "c3_4x480x640": (4, 480, 640, 3, "ELIC_united"),
+    "c5_stf_1x512x512": (1, 512, 512, 5, "STF_united"),  # BASELINE config 5 (Swin transforms)
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (dense f32 matrix)
 
 
-def cpu_baseline(sd, H, W, cid, seconds_budget=25.0):
+def cpu_baseline(sd, H, W, cid, model="ELIC_united", seconds_budget=25.0):
     """The oracle (CPU restatement of the reference path: PyTorch-CPU eager + C coder) timed on this host, B=1, on single
     pairs of the workload's image size (replicate-padded to multiples of 64 like the harness does)."""
     import torch
@@ -39,7 +40,7 @@ def cpu_baseline(sd, H, W, cid, seconds_budget=25.0):
 
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    orc = eo.OracleCodec(sd)
+    orc = eo.OracleCodec(sd) if model == "ELIC_united" else eo.oracle_stf(sd)
     orc.update()
     done, spent, best = 0, 0.0, None
     while spent < seconds_budget and done < 6:
@@ -79,11 +80,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    B, H, W, cid = WORKLOADS[args.workload]
-    sd = synth.synthetic_state_dict(0)
+    B, H, W, cid, model = WORKLOADS[args.workload]
+    sd = synth.synthetic_state_dict(0, model=model)
     # per-image stream sets (the unit that shards across GPUs); W engine instances overlap one group's serial coder
     # phases with another group's convolutions
-    net = CodecPool(sd, config=rgbd_amd.model_config(), workers=args.workers, device=dev, per_image_streams=True)
+    net = CodecPool(sd, config=rgbd_amd.model_config(), workers=args.workers, device=dev, per_image_streams=True,
+                    model_cls=rgbd_amd.modelZoo[model])
 
     r, d = synth.synthetic_batch(B, H, W, config_id=cid, start=rank * B)
     rgb, depth = torch.from_numpy(r).to(dev), torch.from_numpy(d).to(dev)
@@ -149,7 +151,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)", "images_per_gpu": B,
+            "config": {"workload": args.workload, "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)" if model == "ELIC_united" else "STF_united ch4 (N=192,M=384)", "images_per_gpu": B,
                        "image": [H, W], "padded": [H + ph, W + pw], "weights": "synthetic seed 0 (stress recipe)",
                        "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers},
             # `achieved`: conv FLOPs of the timed steps / wall time of the timed region -- with several engine instances
@@ -186,7 +188,7 @@ def main():
                                       "note": "same launches, single engine instance, no concurrent kernels"}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, H, W, cid)
+            res["cpu_baseline"] = cpu_baseline(sd, H, W, cid, model)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -356,7 +356,7 @@ class ELIC_united:
         """Another engine instance on the same GPU that borrows this one's device weights and tables (own workspace and
         stream).  The clone keeps a reference to its parent so the weights outlive it."""
         self._ready()
-        other = ELIC_united.__new__(ELIC_united)
+        other = type(self).__new__(type(self))
         other.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_h"})
         h = ctypes.c_void_p()
         check(lib().rgbd_elic_clone_shared(self._h, ctypes.byref(h)), "clone_shared")

@@ -16,7 +16,8 @@ from .elic_united import ELIC_united
 
 
 class CodecPool:
-    def __init__(self, state_dict, config=None, workers: int = 2, device="cuda", per_image_streams: bool = True):
+    def __init__(self, state_dict, config=None, workers: int = 2, device="cuda", per_image_streams: bool = True,
+                 model_cls=ELIC_united):
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -24,7 +25,7 @@ class CodecPool:
         self.streams = []
         for i in range(workers):
             if i == 0:
-                net = ELIC_united(config=config, channel=4).eval()
+                net = model_cls(config=config, channel=4).eval()  # ELIC_united or its Swin variant STF_united
                 net.load_state_dict(state_dict)
                 net.update(force=True)
                 net = net.to(self.device)

@@ -21,8 +21,5 @@ class SymmetricalTransFormerUnited(ELIC_united):
         check(lib().rgbd_elic_create_stf(self.N, self.M, sl, len(self.slice_ch), ctypes.byref(h)), "elic_create_stf")
         return h
 
-    def clone_shared(self):
-        raise NotImplementedError("CodecPool drives ELIC_united")
-
 
 STF_united = SymmetricalTransFormerUnited
