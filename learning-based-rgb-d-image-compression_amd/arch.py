@@ -326,6 +326,88 @@ def elic_entries(config=None, channel: int = 3) -> "OrderedDict[str, Entry]":
     return b.entries
 
 
+def r2d_entropy_param_in_dims(M: int, slice_ch: List[int], i: int) -> Dict[str, int]:
+    """models/elic_united_R2D.py:47-71: the RGB nets see RGB context only, the depth nets see both."""
+    c = slice_ch[i]
+    if i == 0:
+        return {"rgb_anchor": 2 * M, "depth_anchor": 4 * M + 2 * c, "rgb_nonanchor": 2 * M + 2 * c,
+                "depth_nonanchor": 4 * M + 4 * c}
+    return {"rgb_anchor": 2 * M + 2 * c, "depth_anchor": 4 * M + 6 * c, "rgb_nonanchor": 2 * M + 4 * c,
+            "depth_nonanchor": 4 * M + 8 * c}
+
+
+def elic_united_r2d_entries(config=None) -> "OrderedDict[str, Entry]":
+    """Every state_dict entry of ELIC_united_R2D (reference: models/elic_united_R2D.py:9-71): the one-directional variant
+    (RGB is coded on its own, depth is conditioned on RGB) -- SURVEY 8f rank 4."""
+    cfg = model_config() if config is None else config
+    N, M = int(cfg["N"]), int(cfg["M"])
+    slice_ch = list(cfg["slice_ch"])
+    b = _Builder()
+
+    def spf_single(name, n):  # modules/transform/attention.py:14-32
+        b.conv(f"{name}.r_ext", n, n // 2, 3)
+        b.conv(f"{name}.d_ext", n, n // 2, 3)
+        b.esa(f"{name}.d_esa", n)
+
+    # analysis.py:56-112: the RGB stream never takes depth features; the depth stream concatenates the fused ones
+    for mod, cin, k in (("rgb", 3, 1), ("depth", 1, 2)):
+        p = f"g_a.{mod}_analysis_transform"
+        b.conv(f"{p}.0", cin, N, 5)
+        for j in (1, 2, 3, 6, 7, 8, 12, 13, 14):
+            b.bottleneck(f"{p}.{j}", N)
+        for j in (4, 10, 15):
+            if mod == "rgb":
+                spf_single(f"{p}.{j}", N)
+        b.conv(f"{p}.5", k * N, N, 5)
+        b.attention(f"{p}.9", N)
+        b.conv(f"{p}.11", k * N, N, 5)
+        b.conv(f"{p}.16", k * N, M, 5)
+        b.attention(f"{p}.17", M)
+    # synthesis.py:186-242
+    for mod, cout, k in (("rgb", 3, 1), ("depth", 1, 2)):
+        p = f"g_s.{mod}_synthesis_transform"
+        b.attention(f"{p}.0", M)
+        b.deconv(f"{p}.1", M, N, 5)
+        for j in (2, 8, 13):
+            if mod == "rgb":
+                spf_single(f"{p}.{j}", N)
+        for j in (3, 9, 14):
+            b.bottleneck(f"{p}.{j}", k * N, N)
+        for j in (4, 5, 10, 11, 15, 16):
+            b.bottleneck(f"{p}.{j}", N)
+        b.deconv(f"{p}.6", N, N, 5)
+        b.attention(f"{p}.7", N)
+        b.deconv(f"{p}.12", N, N, 5)
+        b.deconv(f"{p}.17", N, cout, 5)
+    for mod in ("rgb", "depth"):  # analysis.py:231-237 (HyperAnalysisEXcross, as in ELIC_united)
+        p = f"h_a.{mod}_reduction"
+        b.conv(f"{p}.0", M, N, 3)
+        b.conv(f"{p}.2", N, N, 5)
+        b.conv(f"{p}.4", N, N, 5)
+    # synthesis.py:325-380: RGB hyper synthesis on its own, depth on (depth, rgb)
+    for m, mult in (("r", 1), ("d", 2)):
+        for idx, (cin, cout, k) in enumerate(((N, M, 5), (M, M * 3 // 2, 5), (M * 3 // 2, 2 * M, 3)), 1):
+            p = f"h_s.{m}_h_s{idx}"
+            b.se(f"{p}.se", mult * cin)
+            b.deconv(f"{p}.deconv", mult * cin, cout, k)
+    for fam in ("rgb_local_context", "rgb_local_context_anchor_with_nonanchor", "depth_local_context"):
+        for i, c in enumerate(slice_ch):
+            b.conv(f"{fam}.{i}", c, 2 * c, 5)
+    for fam in ("rgb_channel_context", "depth_channel_context"):
+        for i in range(1, len(slice_ch)):
+            b.channel_context(f"{fam}.{i}", sum(slice_ch[:i]), 2 * slice_ch[i])
+    for fam, key in (("rgb_entropy_parameters_anchor", "rgb_anchor"), ("depth_entropy_parameters_anchor", "depth_anchor"),
+                     ("rgb_entropy_parameters_nonanchor", "rgb_nonanchor"),
+                     ("depth_entropy_parameters_nonanchor", "depth_nonanchor")):
+        for i, c in enumerate(slice_ch):
+            b.entropy_params(f"{fam}.{i}", r2d_entropy_param_in_dims(M, slice_ch, i)[key], 2 * c)
+    b.entropy_bottleneck("rgb_entropy_bottleneck", N)
+    b.entropy_bottleneck("depth_entropy_bottleneck", N)
+    b.gaussian_conditional("rgb_gaussian_conditional")
+    b.gaussian_conditional("depth_gaussian_conditional")
+    return b.entries
+
+
 STF_DEPTHS = (2, 2, 6, 2)
 STF_HEADS = (3, 6, 12, 24)
 STF_EMBED = 48

@@ -13,7 +13,8 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .arch import Entry, elic_entries, elic_united_entries, model_config, stf_config, stf_united_entries
+from .arch import (Entry, elic_entries, elic_united_entries, elic_united_r2d_entries, model_config, stf_config,
+                   stf_united_entries)
 
 _IH_STD = math.sqrt(4.0 * (65536.0**2 - 1.0) / 12.0)  # std of the sum of four uniform 16-bit ints
 _IH_MEAN = 2.0 * 65535.0
@@ -108,11 +109,12 @@ def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_tor
         entries = stf_united_entries()
     else:
         cfg = model_config() if config is None else config
-        entries = elic_united_entries(cfg) if model == "ELIC_united" else elic_entries(cfg, channel)
+        entries = {"ELIC_united": elic_united_entries, "ELIC_united_R2D": elic_united_r2d_entries}.get(model)
+        entries = entries(cfg) if entries else elic_entries(cfg, channel)
     sd = OrderedDict()
     for name, e in entries.items():
         sd[name] = make_tensor(name, e, seed)
-    if stress and model == "ELIC_united":
+    if stress and model in ("ELIC_united", "ELIC_united_R2D"):
         _apply_stress(sd, cfg)
     elif stress and model == "STF_united":
         _apply_stress(sd, cfg, transforms=False)

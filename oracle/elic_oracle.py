@@ -297,6 +297,8 @@ class OracleCodec:
         self.eb = {}
         self.trace = None  # when a dict, per-part intermediates are recorded
         self.g_a, self.g_s = g_a, g_s  # transform pair (the Swin variant swaps these, models/stf_united.py:641-677)
+        self.h_s = h_s
+        self.r2d = False  # ELIC_united_R2D context wiring
 
     def update(self):  # elic_united.py:580-586
         self.gc = gaussian_tables(self.table)
@@ -354,11 +356,13 @@ class OracleCodec:
         c1 = c0 + self.slice_ch[i]
         yr = y_r[:, c0:c1] if y_r is not None else None
         yd = y_d[:, c0:c1] if y_d is not None else None
-        ra = part("rgb", True, ctx0, yr)
+        # R2D: the RGB nets only see RGB context (hyper_r [, ch_r]); the depth nets see everything
+        ctx_r = ([hyp_r] + ctx0[2:3]) if self.r2d else ctx0
+        ra = part("rgb", True, ctx_r, yr)
         r_loc = _conv(sd, f"rgb_local_context.{i}", ra)
         da = part("depth", True, [r_loc] + ctx0, yd)
         d_loc = _conv(sd, f"depth_local_context.{i}", da)
-        rn = part("rgb", False, [r_loc, d_loc] + ctx0, yr)
+        rn = part("rgb", False, ([r_loc] + ctx_r) if self.r2d else ([r_loc, d_loc] + ctx0), yr)
         r_hat = rn + ra
         r_loc2 = _conv(sd, f"rgb_local_context_anchor_with_nonanchor.{i}", r_hat)
         dn = part("depth", False, [r_loc2, d_loc] + ctx0, yd)
@@ -374,7 +378,7 @@ class OracleCodec:
         zh_r = self._z_decompress("rgb", zs_r, z_r.shape[-2:])
         zs_d, _ = self._z_compress("depth", z_d)
         zh_d = self._z_decompress("depth", zs_d, z_d.shape[-2:])
-        hyp_r, hyp_d = h_s(self.sd, zh_r, zh_d)
+        hyp_r, hyp_d = self.h_s(self.sd, zh_r, zh_d)
         ys_r, ys_d = self.compress_united(y_r, hyp_r, y_d, hyp_d)
         if self.trace is not None:
             self.trace.update({"y_r": y_r, "y_d": y_d, "z_r": z_r, "z_d": z_d, "zhat_r": zh_r, "zhat_d": zh_d,
@@ -436,7 +440,7 @@ class OracleCodec:
         z_r, z_d = h_a(sd, y_r, y_d)
         zh_r, zl_r = self._eb_forward("rgb", z_r)
         zh_d, zl_d = self._eb_forward("depth", z_d)
-        hyp_r, hyp_d = h_s(sd, zh_r, zh_d)
+        hyp_r, hyp_d = self.h_s(sd, zh_r, zh_d)
         yhat_r, yhat_d, lik_r, lik_d = [], [], [], []
         for i, C in enumerate(self.slice_ch):
             c0 = sum(self.slice_ch[:i])
@@ -474,7 +478,7 @@ class OracleCodec:
         t0 = time.process_time()
         zh_r = self._z_decompress("rgb", r_strings[1], shape)
         zh_d = self._z_decompress("depth", d_strings[1], shape)
-        hyp_r, hyp_d = h_s(self.sd, zh_r, zh_d)
+        hyp_r, hyp_d = self.h_s(self.sd, zh_r, zh_d)
         yhat_r, yhat_d = self.decompress_united(r_strings[0][0], hyp_r, d_strings[0][0], hyp_d)
         xr, xd = self.g_s(self.sd, yhat_r, yhat_d)
         return {"x_hat": {"r": xr.clamp_(0, 1), "d": xd.clamp_(0, 1)}, "cost_time": time.process_time() - t0}
@@ -622,6 +626,65 @@ def oracle_stf(state_dict):
     """OracleCodec for STF_united: ELIC_united's compress/decompress with the Swin transforms and its own widths."""
     c = OracleCodec(state_dict, {"N": 192, "M": 384, "slice_ch": [24, 24, 48, 96, 192]})
     c.g_a, c.g_s = g_a_stf, g_s_stf
+    return c
+
+
+# --------------------------------------------------------------------------------------------------
+# ELIC_united_R2D (models/elic_united_R2D.py): RGB is coded on its own, depth is conditioned on RGB
+# --------------------------------------------------------------------------------------------------
+def _bi_spf_single(sd, p, rgb, depth):  # attention.py:14-32
+    rf = torch.relu(_conv(sd, p + ".r_ext", rgb))
+    df = torch.relu(_conv(sd, p + ".d_ext", depth))
+    return _esa(sd, p + ".d_esa", torch.cat((df, rf), dim=-3))
+
+
+def _stack_r2d(sd, root, kinds, rgb, depth):  # analysis.py:102-112 / synthesis.py:231-242
+    pr, pd = f"{root}.rgb_{root_kind(root)}_transform", f"{root}.depth_{root_kind(root)}_transform"
+    for i, k in enumerate(kinds):
+        if k == "spf":
+            depth = torch.cat((depth, _bi_spf_single(sd, f"{pr}.{i}", rgb, depth)), dim=-3)
+            continue
+        outs = []
+        for p, x in ((pr, rgb), (pd, depth)):
+            n = f"{p}.{i}"
+            if k == "conv":
+                outs.append(_conv(sd, n, x, stride=2))
+            elif k == "deconv":
+                outs.append(_deconv(sd, n, x, stride=2))
+            elif k == "rb":
+                outs.append(_bottleneck(sd, n, x))
+            else:
+                outs.append(_attention(sd, n, x))
+        rgb, depth = outs
+    return rgb, depth
+
+
+def g_a_r2d(sd, rgb, depth):
+    return _stack_r2d(sd, "g_a", _GA, rgb, depth)
+
+
+def g_s_r2d(sd, rgb, depth):
+    return _stack_r2d(sd, "g_s", _GS, rgb, depth)
+
+
+def _hs_block_single(sd, p, f, last):  # synthesis.py:364-380
+    f = _deconv(sd, p + ".deconv", _se(sd, p + ".se", f), stride=1 if last else 2)
+    return f if last else F.leaky_relu(f, 0.01)
+
+
+def h_s_r2d(sd, rgb_z, depth_z):  # synthesis.py:336-343
+    r1 = _hs_block_single(sd, "h_s.r_h_s1", rgb_z, False)
+    d1 = _hs_block(sd, "h_s.d_h_s1", depth_z, rgb_z, False)
+    r2 = _hs_block_single(sd, "h_s.r_h_s2", r1, False)
+    d2 = _hs_block(sd, "h_s.d_h_s2", d1, r1, False)
+    return _hs_block_single(sd, "h_s.r_h_s3", r2, True), _hs_block(sd, "h_s.d_h_s3", d2, r2, True)
+
+
+def oracle_r2d(state_dict, config=None):
+    """OracleCodec for ELIC_united_R2D: other transforms, hyper synthesis and context wiring
+    (elic_united_R2D.py:149-232 compress_one_slice / :234-326 decompress_one_slice)."""
+    c = OracleCodec(state_dict, config)
+    c.g_a, c.g_s, c.h_s, c.r2d = g_a_r2d, g_s_r2d, h_s_r2d, True
     return c
 
 

@@ -10,6 +10,7 @@ Outputs (data only -- inputs are regenerated from rgbd_amd.synth, never stored):
     tests/golden/bicee_*.npz        Bi-CEE stage alone (BASELINE config 4): compress_united / decompress_united outputs
     tests/golden/elic_*.npz         single-modal ELIC (BASELINE config 1): streams, latents, reconstruction
     tests/golden/stf_*.npz          STF_united (Swin transforms; BASELINE config 5 at reduced size)
+    tests/golden/r2d_*.npz          ELIC_united_R2D (one-directional variant)
     tests/golden/harness.json       pad / container / bpp / PSNR tuples (TesterUnited arithmetic)
 
 The reference runs on PyTorch CPU kernels; float tensors are therefore specific to this container's
@@ -229,6 +230,31 @@ def stf_case(model_config, synth, name, B, H, W, config_id):
     return g
 
 
+def r2d_case(model_config, synth, name, B, H, W, config_id):
+    """the reference's ELIC_united_R2D (models/elic_united_R2D.py) compress()/decompress()."""
+    from models.elic_united_R2D import ELIC_united_R2D
+
+    net = ELIC_united_R2D(config=model_config(), channel=4).eval()
+    net.load_state_dict(synth.synthetic_state_dict(0, model="ELIC_united_R2D"))
+    assert net.update(force=True)
+    r, d = synth.synthetic_batch(B, H, W, config_id=config_id)
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    with torch.no_grad():
+        y_r, y_d = net.g_a(r, d)
+        out = net.compress(r, d)
+        dec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    g = {"B": B, "H": H, "W": W, "config_id": config_id, "shape": np.array(tuple(out["shape"]), np.int32),
+         "r_y": np.frombuffer(out["r_strings"][0][0], np.uint8), "d_y": np.frombuffer(out["d_strings"][0][0], np.uint8),
+         "r_z0": np.frombuffer(out["r_strings"][1][0], np.uint8), "d_z0": np.frombuffer(out["d_strings"][1][0], np.uint8),
+         "y_r": y_r.numpy(), "y_d": y_d.numpy(),
+         "xhat_r_sub": dec["x_hat"]["r"][:, :, ::4, ::4].numpy(), "xhat_d_sub": dec["x_hat"]["d"][:, :, ::4, ::4].numpy(),
+         "psnr": np.array([-10 * np.log10(torch.mean((dec["x_hat"]["r"] - r) ** 2).item()),
+                           -10 * np.log10(torch.mean((dec["x_hat"]["d"] - d) ** 2).item())], np.float64)}
+    np.savez_compressed(os.path.join(HERE, f"r2d_{name}.npz"), **g)
+    print("r2d", name, len(out["r_strings"][0][0]), len(out["d_strings"][0][0]), g["psnr"])
+    return g
+
+
 def main():
     ELIC, model_config, ext = rl.load_reference()
     import rgbd_amd  # noqa: F401
@@ -263,6 +289,9 @@ def main():
     g = stf_case(model_config, synth, "c5_256x256", 1, 256, 256, 5)
     summary["stf_c5_256x256"] = {"B": 1, "H": 256, "W": 256, "config_id": 5, "psnr": g["psnr"].tolist(),
                                  "y_len": [int(g["r_y"].shape[0]), int(g["d_y"].shape[0])]}
+    g = r2d_case(model_config, synth, "128x192", 1, 128, 192, 4)
+    summary["r2d_128x192"] = {"B": 1, "H": 128, "W": 192, "config_id": 4, "psnr": g["psnr"].tolist(),
+                              "y_len": [int(g["r_y"].shape[0]), int(g["d_y"].shape[0])]}
     with open(os.path.join(HERE, "harness.json"), "w") as f:
         json.dump({"weights_seed": 0, "torch": torch.__version__, "cases": summary}, f, indent=1)
 

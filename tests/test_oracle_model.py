@@ -183,3 +183,30 @@ def test_stf_united_config5():
     dec = orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
     assert np.array_equal(dec["x_hat"]["r"][:, :, ::4, ::4].numpy(), g["xhat_r_sub"])
     assert abs(eo.psnr(dec["x_hat"]["r"], r) - g["psnr"][0]) < 1e-9
+
+
+def test_elic_united_r2d():
+    """ELIC_united_R2D (models/elic_united_R2D.py) vs the reference's golden."""
+    import os
+
+    from rgbd_amd import arch, synth
+
+    entries = arch.elic_united_r2d_entries()
+    assert len(entries) == 994 and arch.count_parameters(entries) == 127005454  # measured on the reference
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "r2d_128x192.npz"))
+    sd = synth.synthetic_state_dict(0, model="ELIC_united_R2D")
+    orc = eo.oracle_r2d(sd)
+    orc.update()
+    r, d = synth.synthetic_batch(1, 128, 192, config_id=4)
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    y_r, y_d = eo.g_a_r2d(orc.sd, r, d)
+    np.testing.assert_allclose(y_r.numpy(), g["y_r"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(y_d.numpy(), g["y_d"], rtol=1e-5, atol=1e-4)
+    if not np.array_equal(y_r.numpy(), g["y_r"]):
+        pytest.skip("this CPU's kernels differ in the last bits from the golden machine; floats within tolerance")
+    out = orc.compress(r, d)
+    assert out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes()
+    assert out["r_strings"][1][0] == g["r_z0"].tobytes() and out["d_strings"][1][0] == g["d_z0"].tobytes()
+    dec = orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    assert np.array_equal(dec["x_hat"]["r"][:, :, ::4, ::4].numpy(), g["xhat_r_sub"])
+    assert np.array_equal(dec["x_hat"]["d"][:, :, ::4, ::4].numpy(), g["xhat_d_sub"])
