@@ -150,6 +150,10 @@ int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int
  * compress / decompress / forward entry points above); nn.Linear weights are passed as (out, in, 1, 1).
  */
 int rgbd_elic_create_stf(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out);
+/* ELIC_united_R2D: replaces models/elic_united_R2D.py:9-326 (AnalysisTransformEXSingle analysis.py:56-112,
+ * SynthesisTransformEXSingle synthesis.py:186-242, HyperSynthesisEXSingle synthesis.py:325-343, the one-directional context
+ * wiring of compress_one_slice / decompress_one_slice).  Same entry points as ELIC_united otherwise. */
+int rgbd_elic_create_r2d(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out);
 
 /*
  * Eval-mode forward(): replaces ELIC_united.forward / entropy_estimate_united / codeOnePart (models/elic_united.py:94-263)

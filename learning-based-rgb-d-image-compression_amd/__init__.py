@@ -11,6 +11,11 @@ from .elic import ELIC  # noqa: F401,E402
 
 from .stf_united import STF_united, SymmetricalTransFormerUnited  # noqa: F401,E402
 
+from .elic_united_r2d import ELIC_united_R2D  # noqa: F401,E402
+
+# models/__init__.py:11-20 ("the complex ones first": the harness matches model names by substring)
+modelZoo.clear()
+modelZoo.update({"ELIC_united_R2D": ELIC_united_R2D, "ELIC_united": ELIC_united})
 modelZoo["ELIC"] = ELIC
 modelZoo["STF_united"] = SymmetricalTransFormerUnited  # models/__init__.py:11-20
 from .pool import CodecPool  # noqa: F401,E402

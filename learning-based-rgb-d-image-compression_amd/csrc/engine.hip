@@ -1012,6 +1012,150 @@ struct rgbd_elic {
         }
     }
 
+    // ---- ELIC_united_R2D (models/elic_united_R2D.py): RGB on its own, depth conditioned on RGB ------
+    // attention.py:14-32: only the depth-side gated features exist
+    void bi_spf_single(const std::string& p, const Act& rgb, const Act& depth, const Act& d_dst)
+    {
+        const size_t mark = arena.top;
+        const int half = rgb.c / 2;
+        Act dr = alloc(rgb.n, rgb.h, rgb.w, rgb.c);  // cat(df, rf)
+        Epi relu;
+        relu.act = ACT_RELU;
+        Act df = view(dr, 0, half), rf = view(dr, half, half);
+        conv(p + ".d_ext", depth, 1, 1, relu, &df);
+        conv(p + ".r_ext", rgb, 1, 1, relu, &rf);
+        esa(p + ".d_esa", dr, d_dst);
+        arena.top = mark;
+    }
+    // analysis.py:56-112 / synthesis.py:186-242: the same 18 stages as ELIC_united; the fusion stage only widens depth
+    void stack_r2d(const std::string& root, const char* kind, const char* const* kinds, const Act& r_in, const Act& d_in,
+                   Act* r_out, Act* d_out)
+    {
+        const std::string pr = root + ".rgb_" + kind + "_transform.", pd = root + ".depth_" + kind + "_transform.";
+        Act r = r_in, d = d_in;
+        for (int i = 0; i < 18; ++i) {
+            const std::string k = kinds[i], si = std::to_string(i);
+            const bool next_spf = (i + 1 < 18) && std::string(kinds[i + 1]) == "spf";
+            if (k == "spf") {  // d is the 2N-channel concat buffer whose first half is filled
+                bi_spf_single(pr + si, r, view(d, 0, N), view(d, N, N));
+                continue;
+            }
+            Act dcat, ddst;
+            const Act* pd_dst = nullptr;
+            if (next_spf) {
+                const int oh = (k == "deconv") ? d.h * 2 : (k == "conv" ? d.h / 2 : d.h);
+                const int ow = (k == "deconv") ? d.w * 2 : (k == "conv" ? d.w / 2 : d.w);
+                dcat = alloc(d.n, oh, ow, 2 * N);
+                ddst = view(dcat, 0, N);
+                pd_dst = &ddst;
+            }
+            if (k == "conv" || k == "deconv") {
+                r = conv(pr + si, r, 2, 2);
+                d = conv(pd + si, d, 2, 2, Epi(), pd_dst);
+            } else if (k == "rb") {
+                r = bottleneck(pr + si, r);
+                d = bottleneck(pd + si, d, pd_dst);
+            } else {
+                r = attention(pr + si, r);
+                d = attention(pd + si, d, pd_dst);
+            }
+            if (next_spf) d = dcat;
+        }
+        *r_out = r;
+        *d_out = d;
+    }
+    void g_a_r2d(const Act& rgb, const Act& depth, Act* y_r, Act* y_d)
+    {
+        static const char* const kinds[18] = {"conv", "rb", "rb", "rb", "spf", "conv", "rb", "rb", "rb",
+                                              "attn", "spf", "conv", "rb", "rb", "rb", "spf", "conv", "attn"};
+        stack_r2d("g_a", "analysis", kinds, rgb, depth, y_r, y_d);
+    }
+    void g_s_r2d(const Act& yr, const Act& yd, Act* xr, Act* xd)
+    {
+        static const char* const kinds[18] = {"attn", "deconv", "spf", "rb", "rb", "rb", "deconv", "attn", "spf",
+                                              "rb", "rb", "rb", "deconv", "spf", "rb", "rb", "rb", "deconv"};
+        stack_r2d("g_s", "synthesis", kinds, yr, yd, xr, xd);
+    }
+    // synthesis.py:364-380
+    Act hs_block_single(const std::string& p, const Act& x, bool last)
+    {
+        Act f = alloc(x.n, x.h, x.w, x.c);
+        float* sc = se_weights(p + ".se", x);
+        scale_to(x, sc, 0, f);
+        Epi e;
+        e.act = last ? ACT_NONE : ACT_LEAKY;
+        return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
+    }
+    // synthesis.py:336-343
+    void h_s_r2d(const Act& zr, const Act& zd, Act* hr, Act* hd)
+    {
+        Act r1 = hs_block_single("h_s.r_h_s1", zr, false);
+        Act d1 = hs_block("h_s.d_h_s1", zd, zr, false);
+        Act r2 = hs_block_single("h_s.r_h_s2", r1, false);
+        Act d2 = hs_block("h_s.d_h_s2", d1, r1, false);
+        *hr = hs_block_single("h_s.r_h_s3", r2, true);
+        *hd = hs_block("h_s.d_h_s3", d2, r2, true);
+    }
+    // elic_united_R2D.py:149-326.  RGB context buffer [r_loc 2C | hyper_r 2M | ch_r 2C]: anchor reads the suffix, non-anchor
+    // the whole.  Depth context buffer as in ELIC_united: [r_loc 2C | d_loc 2C | hyper_r | hyper_d | ch_r | ch_d].
+    void bicee_r2d(Coding& cd, const Act* y_r, const Act* y_d, const Act& hyp_r, const Act& hyp_d, const Act& yhat_r,
+                   const Act& yhat_d)
+    {
+        yhat_base[0] = yhat_r.p;
+        yhat_base[1] = yhat_d.p;
+        int c0 = 0;
+        int64_t part_off = 0;
+        const int h = hyp_r.h, w = hyp_r.w, HC = hyp_r.c;
+        for (size_t i = 0; i < slice_ch.size(); ++i) {
+            const int C = slice_ch[i];
+            const size_t mark = arena.top;
+            const std::string si = std::to_string(i);
+            const int wide_r = 2 * C + HC + (i ? 2 * C : 0);
+            const int wide_d = 4 * C + 2 * HC + (i ? 4 * C : 0);
+            Act cr = alloc(hyp_r.n, h, w, wide_r), cdx = alloc(hyp_r.n, h, w, wide_d);
+            copy_ch(hyp_r, view(cr, 2 * C, HC));
+            copy_ch(hyp_r, view(cdx, 4 * C, HC));
+            copy_ch(hyp_d, view(cdx, 4 * C + HC, HC));
+            if (i) {
+                const Act chr_ = view(cdx, 4 * C + 2 * HC, 2 * C), chd = view(cdx, 6 * C + 2 * HC, 2 * C);
+                channel_context("rgb_channel_context." + si, view(yhat_r, 0, c0), &chr_);
+                channel_context("depth_channel_context." + si, view(yhat_d, 0, c0), &chd);
+                copy_ch(chr_, view(cr, 2 * C + HC, 2 * C));
+            }
+            const Act yr = y_r ? view(*y_r, c0, C) : Act();
+            const Act yd = y_d ? view(*y_d, c0, C) : Act();
+            const Act hr = view(yhat_r, c0, C), hd = view(yhat_d, c0, C);
+            const int64_t part_syms = (int64_t)C * h * (w / 2);
+            const Act r_loc = view(cr, 0, 2 * C), r_loc_d = view(cdx, 0, 2 * C), d_loc = view(cdx, 2 * C, 2 * C);
+            // rgb anchor: [hyper_r, ch_r]
+            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(cr, 2 * C, wide_r - 2 * C));
+            code_part(cd, 0, 1, p_ra, yr, hr, part_off);
+            conv("rgb_local_context." + si, hr, 1, 2, Epi(), &r_loc);
+            // depth anchor: [r_loc, hyper_r, hyper_d, ch_r, ch_d] (gathered: d_loc's slot sits in between)
+            Act p_da = alloc(hyp_r.n, h, w, 2 * C);
+            {
+                const size_t m2 = arena.top;
+                Act in = alloc(hyp_r.n, h, w, wide_d - 2 * C);
+                copy_ch(r_loc, view(in, 0, 2 * C));
+                copy_ch(view(cdx, 4 * C, wide_d - 4 * C), view(in, 2 * C, wide_d - 4 * C));
+                entropy_params("depth_entropy_parameters_anchor." + si, in, &p_da);
+                arena.top = m2;
+            }
+            code_part(cd, 1, 1, p_da, yd, hd, part_off);
+            conv("depth_local_context." + si, hd, 1, 2, Epi(), &d_loc);
+            // rgb non-anchor: [r_loc, hyper_r, ch_r]
+            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, cr);
+            code_part(cd, 0, 0, p_rn, yr, hr, part_off + part_syms);
+            conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2, Epi(), &r_loc_d);
+            // depth non-anchor: the whole depth buffer
+            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, cdx);
+            code_part(cd, 1, 0, p_dn, yd, hd, part_off + part_syms);
+            part_off += 2 * part_syms;
+            c0 += C;
+            arena.top = mark;
+        }
+    }
+
     // ---- single-modal ELIC (models/elic.py:15-57; BASELINE config 1) ------------------------------------------
     // analysis.py:29-52 / synthesis.py:32-70: the same blocks as above without the cross-modal fusion stages
     Act stack1(const std::string& prefix, const char* const* kinds, int n, const Act& x_in)
@@ -1214,6 +1358,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
             const size_t mark = arena.top;
             Act yr_t, yd_t;
             if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
+            else if (variant == 3) g_a_r2d(rgb, depth, &yr_t, &yd_t);
             else g_a(rgb, depth, &yr_t, &yd_t);
             copy_ch(yr_t, y_r);
             copy_ch(yd_t, y_d);
@@ -1249,7 +1394,8 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
         named["zhat_d"] = zh_d;
 
         // ---- hyper synthesis + Bi-CEE
-        h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
+        else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
         named["hyper_r"] = hyp_r;
         named["hyper_d"] = hyp_d;
     }
@@ -1270,7 +1416,8 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     cd.sym = sym;
     cd.idx = idx;
     cd.stream_base = meta64;
-    bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+    if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+    else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
 
     if (!dry() && !rc) {
         // both modalities in one launch: streams [0, ny) are rgb, [ny, 2ny) depth; bases are relative to `sym`
@@ -1331,6 +1478,7 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
         const size_t mark = arena.top;
         Act yr_t, yd_t;
         if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
+        else if (variant == 3) g_a_r2d(rgb, depth, &yr_t, &yd_t);
         else g_a(rgb, depth, &yr_t, &yd_t);
         copy_ch(yr_t, y_r);
         copy_ch(yd_t, y_d);
@@ -1353,7 +1501,8 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
         }
     }
     Act hyp_r, hyp_d;
-    h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+    if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
+    else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
     Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
     if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
         int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
@@ -1364,13 +1513,15 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     cd.estimate = true;
     cd.lik[0] = alloc(B, h, w, M);
     cd.lik[1] = alloc(B, h, w, M);
-    bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+    if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+    else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
     named["y_r"] = y_r;
     named["y_d"] = y_d;
     named["yhat_r"] = yhat_r;
     named["yhat_d"] = yhat_d;
     Act xr, xd;
     if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
+    else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &xr, &xd);
     else g_s(yhat_r, yhat_d, &xr, &xd);
     if (rc) return rc;
     if (dry()) return RGBD_OK;
@@ -1494,7 +1645,8 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
         named["zhat_r"] = zh_r;
         named["zhat_d"] = zh_d;
 
-        h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
+        else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
         named["hyper_r"] = hyp_r;
         named["hyper_d"] = hyp_d;
     }
@@ -1518,7 +1670,8 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     cd.stream_len = d_ylen;
     cd.state = state;
     cd.nstreams = ns_y;
-    bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
+    if (variant == 3) bicee_r2d(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
+    else bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
     if (lat) {  // decompress_united ends here: y_hat back to the caller (NCHW)
         if (rc) return rc;
         if (dry()) return RGBD_OK;
@@ -1534,6 +1687,7 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
         phase.lock();
     }
     if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
+    else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &xr, &xd);
     else g_s(yhat_r, yhat_d, &xr, &xd);
     if (rc) return rc;
     if (dry()) return RGBD_OK;
@@ -2121,6 +2275,14 @@ int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_sl
 }
 
 static int check_ready(const rgbd_elic* m);
+
+int rgbd_elic_create_r2d(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out)
+{
+    const int r = rgbd_elic_create(N, M, slice_ch, n_slices, out);
+    if (r) return r;
+    (*out)->variant = 3;
+    return RGBD_OK;
+}
 
 int rgbd_elic_create_stf(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_slices, rgbd_elic** out)
 {

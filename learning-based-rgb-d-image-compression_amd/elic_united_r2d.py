@@ -1,0 +1,31 @@
+"""`ELIC_united_R2D` on MI355X: the reference's one-directional variant (models/elic_united_R2D.py) over the HIP engine --
+RGB is coded without looking at depth, depth is conditioned on RGB.  Same API and return values as ELIC_united."""
+import ctypes
+
+from ._lib import check, lib
+from .arch import elic_united_r2d_entries
+from .elic_united import ELIC_united
+
+
+class ELIC_united_R2D(ELIC_united):
+    _MODEL = "ELIC_united_R2D"
+
+    def __init__(self, config=None, channel=4, init_seed=0, **kwargs):
+        super().__init__(config=config, channel=channel, init_seed=init_seed)
+        self._entries = elic_united_r2d_entries(self.config)
+
+    def _create_engine(self):
+        h = ctypes.c_void_p()
+        sl = (ctypes.c_int32 * len(self.slice_ch))(*self.slice_ch)
+        check(lib().rgbd_elic_create_r2d(self.N, self.M, sl, len(self.slice_ch), ctypes.byref(h)), "elic_create_r2d")
+        return h
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("eval-mode forward() is built for ELIC_united and STF_united")
+
+    __call__ = forward
+
+    def compress_united(self, *a, **k):
+        raise NotImplementedError("the stage-level entry points are built for ELIC_united")
+
+    decompress_united = compress_united
