@@ -171,10 +171,6 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
 /* Symbols / indexes of the last compress() in stream order (modality 0/1), total count in *n. */
 int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n);
 
-/* When several codec instances share one GPU (one per HIP stream), their chip-filling transform phases (g_a, g_s) can be
- * made mutually exclusive so that they overlap the other instances' serial entropy-coding phases instead of each other. */
-int rgbd_elic_set_exclusive_transforms(rgbd_elic* m, int32_t on);
-
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
 int rgbd_debug_force_splitk(int32_t s);

@@ -414,13 +414,9 @@ Choice choose(const ConvArgs& a)
     Choice best{2, 4, 4, 16, 4, false};
     double best_cost = -1.0;
     long best_blocks = 0;
-    // short reductions (1x1 convs): the workgroup is a handful of memory round trips around very little matrix work, so
-    // use the fully prefetched variant, whose register budget needs the 64-pixel tiles
-    const bool short_k = K <= 512 && a.splitk == 1;
     for (const auto& c : cand) {
         const int wm = c[0], mt = c[1], nt = c[2];
         const int tm = 16 * mt * wm, tp = 16 * nt * (wm == 2 ? 2 : 4);
-        (void)short_k;
         const int twl = pick_tw_log2(a.GW, a.GH, tp);
         const int TW = 1 << twl, TH = tp / TW;
         const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
@@ -433,9 +429,7 @@ Choice choose(const ConvArgs& a)
         const double mfma = (double)mt * nt * (K / 4.0) * 32.0 / ilp + 3000.0;      // cycles per workgroup (+ prologue)
         const double load = (K * tm * 4.0 + (double)PH * PW * a.cin_pad * 4.0) / 12.0;  // ~12 B/clk/CU from L2
         const long nb = (blocks + 255) / 256;
-        static const bool cu_time = getenv("RGBD_CONV_OBJ_CUTIME") != nullptr;  // experiment: minimise CU-time, not latency
-        const double cost = cu_time ? (double)blocks * (mfma + 0.5 * load)
-                                    : (nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load));
+        const double cost = nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load);
         if (best_cost < 0 || cost < best_cost * 0.999) {
             best_cost = cost;
             best = Choice{wm, mt, nt, 16, twl, false};
@@ -465,8 +459,6 @@ Choice choose(const ConvArgs& a)
         const long tap = (long)16 * best.mt * best.wm * 64;
         const int need = max_taps < 2 ? max_taps : 2;
         best.dma = best.kc == 16 && 2 * patch + 2 * need * tap <= (long)LDS_BUDGET;
-        static const char* nodma = getenv("RGBD_CONV_NODMA");
-        if (nodma) best.dma = false;
     }
     (void)best_blocks;
     return best;

@@ -40,7 +40,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     std::vector<uint16_t> packed(total);
     // bucket-table resolution: as fine as fits next to the packed rows in one CU's LDS (160 KiB)
     int bits = 8;
-    while (bits > 4 && (size_t)nrows * ((1u << bits) + 1) * 8 + (size_t)total * 2 > 124 * 1024) --bits;
+    while (bits > 4 && (size_t)nrows * ((1u << bits) + 1) * 8 + ((size_t)total + 64 * (size_t)nrows) * 2 > 132 * 1024) --bits;
     const int LN = (1 << bits) + 1;
     std::vector<uint32_t> lut((size_t)nrows * LN * 2);  // {j | row[j] << 16, freq_j}
     for (int r = 0; r < nrows; ++r) {
@@ -215,10 +215,6 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
     a->span_y = a->span_x = mx - mn + 1;
 }
 
-// Several engine instances may share one GPU (CodecPool): their chip-filling transform phases (g_a, g_s) take this
-// lock in turn, so one instance's transforms overlap the OTHER instances' serial entropy-coding phases instead of
-// each other.
-std::mutex g_transform_phase;
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 
 // ------------------------------------------------------------------------------------------------
@@ -276,7 +272,6 @@ struct rgbd_elic {
     int64_t dbg_per_mod = 0;
 
     bool owns_weights = true;  // false for instances created by rgbd_elic_clone_shared (they borrow device weights)
-    bool exclusive_transforms = false;  // serialise g_a / g_s against other instances (see g_transform_phase)
 
     // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
     bool profile = false;
@@ -405,9 +400,7 @@ struct rgbd_elic {
             if (name.rfind(pre, 0) == 0) {
                 int mt = 1;
                 for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
-                static const bool nosplit = getenv("RGBD_NO_SPLITK") != nullptr;  // experiment only
-                a.splitk = g_force_splitk > 0 ? g_force_splitk
-                                              : (nosplit ? 1 : conv_splitk_for(a.cin_pad, mt, (long)OH * OW, a.nphase));
+                a.splitk = g_force_splitk > 0 ? g_force_splitk : conv_splitk_for(a.cin_pad, mt, (long)OH * OW, a.nphase);
                 break;
             }
         const size_t pmark = arena.top;
@@ -1353,8 +1346,6 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
         }
         Act z_r, z_d;
         {
-            std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
-            if (exclusive_transforms && !dry()) phase.lock();
             const size_t mark = arena.top;
             Act yr_t, yd_t;
             if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
@@ -1363,7 +1354,6 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
             copy_ch(yr_t, y_r);
             copy_ch(yd_t, y_d);
             arena.top = mark;
-            if (phase.owns_lock()) HIP_TRY(hipStreamSynchronize(s));  // the phase ends when the GPU has finished it
         }
         h_a(y_r, y_d, &z_r, &z_d);
         named["y_r"] = y_r;
@@ -1681,11 +1671,6 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     }
 
     Act xr, xd;
-    std::unique_lock<std::mutex> phase(g_transform_phase, std::defer_lock);
-    if (exclusive_transforms && !dry()) {
-        HIP_TRY(hipStreamSynchronize(s));  // wait for our own serial phase outside the lock
-        phase.lock();
-    }
     if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
     else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &xr, &xd);
     else g_s(yhat_r, yhat_d, &xr, &xd);
@@ -1693,7 +1678,6 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 1, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 1, s);
-    if (phase.owns_lock()) HIP_TRY(hipStreamSynchronize(s));
     return r;
 }
 
@@ -2664,13 +2648,6 @@ int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const
         m->profile_collect();
     }
     return r;
-}
-
-int rgbd_elic_set_exclusive_transforms(rgbd_elic* m, int32_t on)
-{
-    if (!m) return RGBD_EINVAL;
-    m->exclusive_transforms = on != 0;
-    return RGBD_OK;
 }
 
 int rgbd_elic_set_profile(rgbd_elic* m, int32_t on)

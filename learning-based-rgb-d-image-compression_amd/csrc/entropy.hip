@@ -540,11 +540,18 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     const int lut_n = (1 << t.lut_bits) + 1;
     uint2* sl = reinterpret_cast<uint2*>(dsm);                                          // [nrows][lut_n] bucket table
     uint2* rowinfo = sl + ((t.nrows * lut_n + 1) & ~1);                                  // [nrows] packed row info
-    uint16_t* cdf = reinterpret_cast<uint16_t*>(rowinfo + ((t.nrows + 1) & ~1));        // [t.total]
+    // cm: the packed rows again, each followed by 64 pad entries, holding cdf - 1 (entry 0: 0; pads: 0xFFFF = 65536 - 1).
+    // "entry < cum" is then "cdf <= cum" for every lane of a 64-wide probe, pads included, and a probe that runs into
+    // the pad has found the row's last (= escape) slot.  Row r starts at row_off[r] + 64 * r.
+    uint16_t* cm = reinterpret_cast<uint16_t*>(rowinfo + ((t.nrows + 1) & ~1));           // [t.total + 64 * nrows]
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < t.total; i += 256) cdf[i] = t.cdf[i];
+    for (int r = 0; r < t.nrows; ++r) {
+        const int ro = t.row_off[r], n = t.sizes[r] - 1;
+        uint16_t* dst = cm + ro + 64 * r;
+        for (int i = tid; i < n + 64; i += 256) dst[i] = i < n ? (uint16_t)(i ? t.cdf[ro + i] - 1 : 0) : (uint16_t)0xFFFFu;
+    }
     {
         // bucket entries: {first candidate | its start << 16, its frequency}; a candidate that is the row's escape slot
         // gets frequency 0 so the one range check of the fast path also routes escapes to the slow path
@@ -556,8 +563,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
             sl[i] = e;
         }
     }
-    for (int i = tid; i < t.nrows; i += 256)  // {row start : 16 | cdf_length : 16}, {offset (signed) : 16 | unused}
-        rowinfo[i] = make_uint2((uint32_t)t.row_off[i] | ((uint32_t)t.sizes[i] << 16), (uint32_t)t.offsets[i] & 0xFFFFu);
+    for (int i = tid; i < t.nrows; i += 256)  // {row start in cm : 16 | cdf_length : 16}, {offset (signed) : 16 | unused}
+        rowinfo[i] = make_uint2((uint32_t)(t.row_off[i] + 64 * i) | ((uint32_t)t.sizes[i] << 16),
+                                (uint32_t)t.offsets[i] & 0xFFFFu);
     __syncthreads();
     if (tid >= 64) return;
     const int lane = tid;
@@ -607,6 +615,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     };
     typedef __attribute__((address_space(3))) const uint2 lds_u2;
     const uint32_t dsm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm;
+    const uint32_t cm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)cm;
+    const uint32_t lane2 = (uint32_t)lane * 2u;
 
     const int64_t nb = (count + 63) >> 6;
     int ti_next = (lane < count) ? idx[base + lane] : 0;
@@ -615,6 +625,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         const int ti = ti_next;
         const uint32_t lutbase = dsm_addr + (uint32_t)(ti * lut_n) * 8u;  // LDS address of this lane's symbol's bucket row
         const uint2 rinfo = rowinfo[ti];  // this lane's row: {start : 16 | cdf_length : 16}, {offset : 16}
+        const uint32_t rowbase = cm_addr + (rinfo.x & 0xFFFFu) * 2u;  // LDS address of the row in cm
         uint32_t outv = 0;
         int j = 0;
         realign();  // before the prefetch below: its wait then only covers loads issued a whole batch ago
@@ -646,8 +657,10 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "v_readfirstlane_b32 %[freq], v63\n"
                     "s_lshr_b32 %[start], %[e0], 16\n"
                     "s_sub_u32 %[t0], %[cum], %[start]\n"
+                    "s_and_b32 %[a], %[e0], 0xffff\n"
                     "s_cmp_ge_u32 %[t0], %[freq]\n"
                     "s_cbranch_scc1 2f\n"                      // not resolved by the bucket entry
+                    "6:\n"
                     "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
                     "s_mul_i32 %[t1], s87, %[freq]\n"
                     "s_mul_hi_u32 s85, s86, %[freq]\n"
@@ -655,7 +668,6 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_add_u32 %[t1], %[t1], s85\n"
                     "s_add_u32 s84, s84, %[t0]\n"
                     "s_addc_u32 s85, %[t1], 0\n"
-                    "s_and_b32 %[a], %[e0], 0xffff\n"
                     "v_writelane_b32 %[outv], %[a], m0\n"
                     "s_lshr_b64 s[86:87], s[84:85], 31\n"      // renormalise when x < 2^31
                     "s_cmp_lg_u64 s[86:87], 0\n"
@@ -670,16 +682,41 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "3:\n"
                     "s_mov_b32 %[more], 0\n"
                     "s_branch 5f\n"
+                    // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
+                    // entries after a at once; k = #(entry < cum) locates it.  k = 0 (escape marker), k = 64 (further
+                    // away) and a probe ending on the pad (escape slot) are left to the C++ path below.
                     "2:\n"
+                    "v_readlane_b32 %[lb], %[rowbase], m0\n"
+                    "s_lshl1_add_u32 %[lb], %[a], %[lb]\n"
+                    "v_add_u32 v62, %[lb], %[lane2]\n"
+                    "ds_read_u16 v63, v62 offset:2\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_cmp_gt_u32 vcc, %[cum], v63\n"
+                    "s_bcnt1_i32_b64 %[t1], vcc\n"
+                    "s_sub_u32 %[t0], %[t1], 1\n"
+                    "s_cmp_gt_u32 %[t0], 62\n"                 // k == 0 (wraps) or k == 64
+                    "s_cbranch_scc1 8f\n"
+                    "v_readlane_b32 %[lb], v63, %[t1]\n"      // cm[a + 1 + k]  = next start - 1
+                    "v_readlane_b32 %[t0], v63, %[t0]\n"      // cm[a + k]      = start - 1
+                    "s_cmp_eq_u32 %[lb], 0xffff\n"
+                    "s_cbranch_scc1 8f\n"                      // the row's last slot: escape
+                    "s_add_u32 %[a], %[a], %[t1]\n"
+                    "s_sub_u32 %[freq], %[lb], %[t0]\n"
+                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
+                    "s_sub_u32 %[t0], %[t0], 1\n"             // cum - start
+                    "s_branch 6b\n"
+                    "8:\n"
                     "s_mov_b32 %[more], 1\n"
                     "s_and_b32 %[a], %[e0], 0xffff\n"
+                    "s_and_b32 %[freq], %[freq], 0xffff\n"
                     "5:\n"
                     "s_mov_b64 %[x], s[84:85]\n"
                     "s_mov_b32 %[j], m0\n"
                     : [x] "+s"(x), [j] "+s"(j), [wi] "+s"(wi), [outv] "+v"(outv), [a] "=&s"(a), [start] "=&s"(start),
                       [freq] "=&s"(freq), [cum] "=&s"(cum), [more] "=&s"(more), [lb] "=&s"(lb), [t0] "=&s"(t0),
                       [t1] "=&s"(t1), [e0] "=&s"(e0)
-                    : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur)
+                    : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
+                      [lane2] "v"(lane2)
                     : "m0", "s84", "s85", "s86", "s87", "v62", "v63", "scc", "memory");
             }
             if (!rfl(more)) break;
@@ -693,7 +730,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 uint32_t lo = a + 1, prev = start;
                 for (;;) {
                     const int ci = (int)lo + lane;
-                    const uint32_t c = (ci <= last) ? (uint32_t)cdf[ro + ci] : 65536u;  // entry i = start of symbol i
+                    const uint32_t c = (ci <= last) ? (uint32_t)cm[ro + ci] + 1u : 65536u;  // entry i = start of symbol i
                     const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c <= cum));
                     if (k == 64) {
                         prev = rdl(c, 63);
@@ -749,7 +786,7 @@ size_t rans_decode_lds_bytes(const DevTables& t)
 {
     const size_t lut_n = ((size_t)1 << t.lut_bits) + 1;
     return (((size_t)t.nrows * lut_n + 1) & ~(size_t)1) * 8 + (((size_t)t.nrows + 1) & ~(size_t)1) * 8 +
-           (((size_t)t.total * 2 + 15) & ~(size_t)15);
+           ((((size_t)t.total + 64 * (size_t)t.nrows) * 2 + 15) & ~(size_t)15);
 }
 
 int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,
@@ -758,7 +795,8 @@ int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words,
 {
     if (nstreams <= 0 || count <= 0) return RGBD_OK;
     const size_t lds = rans_decode_lds_bytes(t);
-    if (lds > 158 * 1024 || t.nrows * (((size_t)1 << t.lut_bits) + 1) > 65535) return RGBD_ENOSPC;
+    if (lds > 158 * 1024 || t.nrows * (((size_t)1 << t.lut_bits) + 1) > 65535 || t.total + 64 * t.nrows > 65535)
+        return RGBD_ENOSPC;
     static bool configured = false;
     if (!configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel),

@@ -365,9 +365,6 @@ class ELIC_united:
         other._dirty = False
         return other
 
-    def set_exclusive_transforms(self, on: bool):
-        check(lib().rgbd_elic_set_exclusive_transforms(self._h, 1 if on else 0), "set_exclusive_transforms")
-
     def set_profile(self, on: bool):
         check(lib().rgbd_elic_set_profile(self._h, 1 if on else 0), "set_profile")
 

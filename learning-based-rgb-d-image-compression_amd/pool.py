@@ -6,7 +6,6 @@ networks) that occupies a handful of CUs, while the transforms want the whole ch
 concurrently from W host threads: one group's serial coder phases overlap another group's convolutions.  Results are
 identical to coding each group alone (the kernels are batch-invariant); only the wall clock changes.
 """
-import os
 import threading
 from typing import List
 
@@ -32,7 +31,6 @@ class CodecPool:
             else:
                 net = self.nets[0].clone_shared()  # same packed weights in HBM, own workspace
             net.per_image_streams = per_image_streams
-            net.set_exclusive_transforms(workers > 1 and os.environ.get("RGBD_EXCLUSIVE_TRANSFORMS", "0") == "1")
             self.nets.append(net)
             self.streams.append(torch.cuda.Stream(device=self.device))
 
@@ -88,41 +86,26 @@ class CodecPool:
         xd = torch.cat([r[1]["x_hat"]["d"] for r in res])
         return [r[0] for r in res], xr, xd
 
-    def roundtrip_many(self, batches, stagger: bool = False):
-        """Software pipeline over whole batches: worker w codes batches[w::W]; a batch's serial coder phases overlap the
-        other workers' convolutions.  batches: list of (rgb, depth).  Returns [(compress_out, x_hat_r, x_hat_d)].
-
-        Identical workers started together run in lock step (all in their conv phases, then all in their serial phases)
-        and overlap nothing, so worker w starts w/W of a batch latency late; the latency is learnt from earlier calls."""
-        import time
-
+    def roundtrip_many(self, batches):
+        """Software pipeline over whole batches: worker w codes batches[w::W], so one batch's serial coder phases overlap
+        the other workers' convolutions.  batches: list of (rgb, depth).  Returns [(compress_out, x_hat_r, x_hat_d)]."""
         n = len(batches)
         torch.cuda.current_stream().synchronize()
         W = min(self.workers, n)
-        lat = getattr(self, "_latency", None)
 
         def fn(i):
             outs = []
-            if stagger and lat and i:
-                time.sleep(lat * i / W)
             for k in range(i, n, W):
-                t0 = time.perf_counter()
                 rgb, depth = batches[k]
                 out = self.nets[i].compress(rgb, depth)
                 rec = self.nets[i].decompress(out["r_strings"], out["d_strings"], out["shape"])
                 outs.append((k, out, rec["x_hat"]["r"], rec["x_hat"]["d"]))
-                if i == 0 and k == 0:
-                    self.streams[0].synchronize()
-                    self._last_first = time.perf_counter() - t0
             return outs
 
         res = [None] * n
         for lst in self._run(fn, W):
             for k, out, xr, xd in lst:
                 res[k] = (out, xr, xd)
-        if getattr(self, "_last_first", None):
-            # batch latency under load (first batch of worker 0), smoothed
-            self._latency = self._last_first if lat is None else 0.5 * (lat + self._last_first)
         return res
 
     def set_profile(self, on: bool):
