@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
             //   code 1: symbol j carries an escape payload (coded below, then the loop resumes at j)
             //   code 2: a 64-word output block is complete and wants storing
             // v[60:61] = x, v[62:67] scratch (v65 stays 0).  VALU->VALU reads of vcc need 2 wait states on gfx950.
-            uint32_t code, w2, fr, ml, mh, tt;
+            uint32_t code, w2, fr, ml, mh, tt, t2, t3, t4;
             j = (int)rfl((uint32_t)j);
             w = (int)rfl((uint32_t)w);
             asm volatile(
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                 "v_readlane_b32 %[mh], %[vmh], m0\n"
                 "s_cmp_lt_i32 %[w2], 0\n"
                 "s_cbranch_scc1 7f\n"
+                "10:\n"
                 "v_lshrrev_b64 v[62:63], 47, v[60:61]\n"   // x >= freq << 47 ?  (rans64.h:82-83)
                 "v_cmp_le_u32 vcc, %[fr], v62\n"
                 "s_cbranch_vccz 2f\n"
@@ -457,7 +458,57 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                 "s_cbranch_scc1 1b\n"
                 "s_mov_b32 %[code], 0\n"
                 "s_branch 9f\n"
+                // escape payload (reverse of rans_interface.cpp:147-162): the value's nibbles, then their count, pushed with
+                // 4-bit steps; afterwards the escape slot itself is coded like any symbol (label 10).  At most two words are
+                // emitted here, so with three free slots in the current output block no store can become due.
                 "7:\n"
+                "s_and_b32 %[tt], %[w], 63\n"
+                "s_cmp_lt_u32 %[tt], 3\n"
+                "s_cbranch_scc1 70f\n"
+                "v_readlane_b32 %[t4], %[vraw], m0\n"
+                "s_flbit_i32_b32 %[t2], %[t4]\n"
+                "s_sub_u32 %[t2], 35, %[t2]\n"
+                "s_lshr_b32 %[t2], %[t2], 2\n"             // nibbles = ceil(bits / 4)
+                "s_cmp_eq_u32 %[t4], 0\n"
+                "s_cselect_b32 %[t2], 0, %[t2]\n"
+                "s_mov_b32 %[t3], %[t2]\n"
+                "71:\n"
+                "s_cmp_eq_u32 %[t3], 0\n"
+                "s_cbranch_scc1 72f\n"
+                "s_sub_u32 %[t3], %[t3], 1\n"
+                "s_lshl_b32 %[tt], %[t3], 2\n"
+                "s_lshr_b32 %[code], %[t4], %[tt]\n"
+                "s_and_b32 %[code], %[code], 15\n"
+                "v_lshrrev_b64 v[62:63], 59, v[60:61]\n"   // x >= 2^59: emit first (rans_interface.cpp:67-68)
+                "v_cmp_ne_u32 vcc, 0, v62\n"
+                "s_cbranch_vccz 73f\n"
+                "s_sub_u32 %[w], %[w], 1\n"
+                "s_and_b32 %[tt], %[w], 63\n"
+                "v_cmp_eq_u32 vcc, %[tt], %[lane]\n"
+                "s_nop 1\n"
+                "v_cndmask_b32 %[ov], %[ov], v60, vcc\n"
+                "v_mov_b32 v60, v61\n"
+                "v_mov_b32 v61, 0\n"
+                "73:\n"
+                "v_lshlrev_b64 v[60:61], 4, v[60:61]\n"
+                "v_or_b32 v60, %[code], v60\n"
+                "s_branch 71b\n"
+                "72:\n"
+                "v_lshrrev_b64 v[62:63], 59, v[60:61]\n"   // x >= 2^59: emit first (rans_interface.cpp:67-68)
+                "v_cmp_ne_u32 vcc, 0, v62\n"
+                "s_cbranch_vccz 73f\n"
+                "s_sub_u32 %[w], %[w], 1\n"
+                "s_and_b32 %[tt], %[w], 63\n"
+                "v_cmp_eq_u32 vcc, %[tt], %[lane]\n"
+                "s_nop 1\n"
+                "v_cndmask_b32 %[ov], %[ov], v60, vcc\n"
+                "v_mov_b32 v60, v61\n"
+                "v_mov_b32 v61, 0\n"
+                "73:\n"
+                "v_lshlrev_b64 v[60:61], 4, v[60:61]\n"
+                "v_or_b32 v60, %[t2], v60\n"
+                "s_branch 10b\n"
+                "70:\n"
                 "s_mov_b32 %[code], 1\n"
                 "s_branch 9f\n"
                 "8:\n"
@@ -466,8 +517,9 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                 "s_mov_b32 %[j], m0\n"
                 "v_mov_b64 %[x], v[60:61]\n"
                 : [x] "+v"(x), [j] "+s"(j), [w] "+s"(w), [ov] "+v"(ov), [code] "=&s"(code), [w2] "=&s"(w2), [fr] "=&s"(fr),
-                  [ml] "=&s"(ml), [mh] "=&s"(mh), [tt] "=&s"(tt)
-                : [vw2] "v"(cur.w2), [vfr] "v"(cur.freq), [vml] "v"(cur.mlo), [vmh] "v"(cur.mhi), [lane] "v"(lane)
+                  [ml] "=&s"(ml), [mh] "=&s"(mh), [tt] "=&s"(tt), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4)
+                : [vw2] "v"(cur.w2), [vfr] "v"(cur.freq), [vml] "v"(cur.mlo), [vmh] "v"(cur.mhi), [lane] "v"(lane),
+                  [vraw] "v"(cur.raw)
                 : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "m0", "vcc", "scc", "memory");
             x = rfl64(x);
             code = rfl(code);
@@ -683,8 +735,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_mov_b32 %[more], 0\n"
                     "s_branch 5f\n"
                     // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
-                    // entries after a at once; k = #(entry < cum) locates it.  k = 0 (escape marker), k = 64 (further
-                    // away) and a probe ending on the pad (escape slot) are left to the C++ path below.
+                    // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
+                    // path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot.
                     "2:\n"
                     "v_readlane_b32 %[lb], %[rowbase], m0\n"
                     "s_lshl1_add_u32 %[lb], %[a], %[lb]\n"
@@ -693,22 +745,101 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_waitcnt lgkmcnt(0)\n"
                     "v_cmp_gt_u32 vcc, %[cum], v63\n"
                     "s_bcnt1_i32_b64 %[t1], vcc\n"
-                    "s_sub_u32 %[t0], %[t1], 1\n"
-                    "s_cmp_gt_u32 %[t0], 62\n"                 // k == 0 (wraps) or k == 64
+                    "s_cmp_eq_u32 %[t1], 64\n"
                     "s_cbranch_scc1 8f\n"
+                    "s_cmp_eq_u32 %[t1], 0\n"
+                    "s_cbranch_scc1 71f\n"                     // escape marker: symbol a is the escape slot
+                    "s_sub_u32 %[t0], %[t1], 1\n"
                     "v_readlane_b32 %[lb], v63, %[t1]\n"      // cm[a + 1 + k]  = next start - 1
                     "v_readlane_b32 %[t0], v63, %[t0]\n"      // cm[a + k]      = start - 1
                     "s_cmp_eq_u32 %[lb], 0xffff\n"
-                    "s_cbranch_scc1 8f\n"                      // the row's last slot: escape
+                    "s_cbranch_scc1 72f\n"                     // the row's last slot: escape
                     "s_add_u32 %[a], %[a], %[t1]\n"
                     "s_sub_u32 %[freq], %[lb], %[t0]\n"
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
                     "s_sub_u32 %[t0], %[t0], 1\n"             // cum - start
                     "s_branch 6b\n"
+                    // escape (rans_interface.cpp:323-345).  Worked on a copy of the state (s[88:89], word index in lb) and
+                    // committed at the end; an unusual shape (count nibble > 8, window nearly used up) leaves to the C++
+                    // path with the committed state untouched.  Temporaries: e0 = nibbles left, start = raw, cum = shift.
+                    "71:\n"
+                    "s_sub_u32 %[t0], %[cum], %[start]\n"
+                    "s_sub_u32 %[freq], 0x10000, %[start]\n"
+                    "s_branch 73f\n"
+                    "72:\n"
+                    "s_add_u32 %[a], %[a], %[t1]\n"
+                    "s_sub_u32 %[freq], 0xffff, %[t0]\n"
+                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
+                    "s_sub_u32 %[t0], %[t0], 1\n"
+                    "73:\n"
+                    "s_cmp_gt_u32 %[wi], 56\n"
+                    "s_cbranch_scc1 8f\n"
+                    "s_lshr_b64 s[86:87], s[84:85], 16\n"
+                    "s_mul_i32 %[t1], s87, %[freq]\n"
+                    "s_mul_hi_u32 s89, s86, %[freq]\n"
+                    "s_mul_i32 s88, s86, %[freq]\n"
+                    "s_add_u32 %[t1], %[t1], s89\n"
+                    "s_add_u32 s88, s88, %[t0]\n"
+                    "s_addc_u32 s89, %[t1], 0\n"
+                    "s_mov_b32 %[lb], %[wi]\n"
+                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
+                    "s_cmp_lg_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 91f\n"
+                    "s_mov_b32 s89, s88\n"
+                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
+                    "s_add_u32 %[lb], %[lb], 1\n"
+                    "91:\n"
+                    "s_and_b32 %[e0], s88, 15\n"              // count nibble
+                    "s_lshr_b64 s[88:89], s[88:89], 4\n"
+                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
+                    "s_cmp_lg_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 91f\n"
+                    "s_mov_b32 s89, s88\n"
+                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
+                    "s_add_u32 %[lb], %[lb], 1\n"
+                    "91:\n"
+                    "s_cmp_gt_u32 %[e0], 8\n"
+                    "s_cbranch_scc1 8f\n"
+                    "s_mov_b32 %[start], 0\n"
+                    "s_mov_b32 %[cum], 0\n"
+                    "74:\n"
+                    "s_cmp_eq_u32 %[e0], 0\n"
+                    "s_cbranch_scc1 75f\n"
+                    "s_and_b32 %[t1], s88, 15\n"
+                    "s_lshl_b32 %[t1], %[t1], %[cum]\n"
+                    "s_or_b32 %[start], %[start], %[t1]\n"
+                    "s_add_u32 %[cum], %[cum], 4\n"
+                    "s_lshr_b64 s[88:89], s[88:89], 4\n"
+                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
+                    "s_cmp_lg_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 91f\n"
+                    "s_mov_b32 s89, s88\n"
+                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
+                    "s_add_u32 %[lb], %[lb], 1\n"
+                    "91:\n"
+                    "s_sub_u32 %[e0], %[e0], 1\n"
+                    "s_branch 74b\n"
+                    "75:\n"
+                    "s_lshr_b32 %[t1], %[start], 1\n"          // raw >> 1
+                    "s_bitcmp1_b32 %[start], 0\n"
+                    "s_cbranch_scc1 76f\n"
+                    "s_add_u32 %[t1], %[t1], %[a]\n"          // even: value = last + raw / 2
+                    "s_branch 77f\n"
+                    "76:\n"
+                    "s_not_b32 %[t1], %[t1]\n"                // odd: value = -(raw >> 1) - 1
+                    "77:\n"
+                    "v_writelane_b32 %[outv], %[t1], m0\n"
+                    "s_mov_b64 s[84:85], s[88:89]\n"           // commit
+                    "s_mov_b32 %[wi], %[lb]\n"
+                    "s_sub_u32 %[t0], %[cnt], m0\n"           // rest of the batch still inside the word window?
+                    "s_add_u32 %[t0], %[t0], %[wi]\n"
+                    "s_cmp_le_u32 %[t0], 65\n"
+                    "s_cbranch_scc1 4b\n"
+                    "s_add_u32 m0, m0, 1\n"                   // no: hand the realign to the caller (symbol is done)
+                    "s_mov_b32 %[more], 2\n"
+                    "s_branch 5f\n"
                     "8:\n"
                     "s_mov_b32 %[more], 1\n"
-                    "s_and_b32 %[a], %[e0], 0xffff\n"
-                    "s_and_b32 %[freq], %[freq], 0xffff\n"
                     "5:\n"
                     "s_mov_b64 %[x], s[84:85]\n"
                     "s_mov_b32 %[j], m0\n"
@@ -717,10 +848,24 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                       [t1] "=&s"(t1), [e0] "=&s"(e0)
                     : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
                       [lane2] "v"(lane2)
-                    : "m0", "s84", "s85", "s86", "s87", "v62", "v63", "scc", "memory");
+                    : "m0", "s84", "s85", "s86", "s87", "s88", "s89", "v62", "v63", "scc", "memory");
             }
-            if (!rfl(more)) break;
-            a = rfl(a), start = rfl(start), freq = rfl(freq), cum = rfl(cum);
+            more = rfl(more);
+            if (!more) break;
+            if (more == 2) {  // an escape used up the word window: symbol j-1 is done, re-align before going on
+                realign();
+                continue;
+            }
+            // rare shapes (candidate more than 64 entries away, long escapes, window nearly used up): generic path,
+            // starting again from the bucket entry
+            cum = (uint32_t)x & 0xFFFFu;
+            {
+                const uint2 ev = sl[rdl((uint32_t)ti, j) * lut_n + (int)(cum >> shift)];
+                const uint32_t e0 = rfl(ev.x);
+                a = e0 & 0xFFFFu;
+                start = e0 >> 16;
+                freq = rfl(ev.y);
+            }
             const uint32_t r0 = rdl(rinfo.x, j);
             const int ro = (int)(r0 & 0xFFFFu), last = (int)(r0 >> 16) - 2;  // last = escape slot
             if ((int)a == last) freq = 65536u - start;                        // undo the fast-path marker
@@ -767,7 +912,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 v = raw >> 1;
                 if (raw & 1) v = -v - 1;
                 else v += last;
-                realign();  // an escape may have used many words: restore the window invariant
+                // an escape may have used many words: restore the window invariant -- but only when the rest of the
+                // batch (one word per symbol at most) could run past lane 63; a realign waits for a fresh global load
+                if (wi + (cnt - 1 - j) > 64) realign();
             }
             outv = wrl((uint32_t)v, j, outv);
             ++j;
