@@ -124,7 +124,7 @@ struct DevTables {  // packed CDF rows for the device coder
     const int32_t* row_off;  // [nrows] start of each row in cdf
     const int32_t* sizes;  // [nrows] reference cdf_length (= pmf_length + 2)
     const int32_t* offsets;  // [nrows]
-    const uint32_t* lut;  // [nrows][2^lut_bits + 1][2]: {j | row[j] << 16, freq_j}, j = largest index with row[j] <= bucket start
+    const uint32_t* lut;  // [nrows][2^lut_bits + 1][2]: {j | row[j] << 16, freq_j (0 if j is the escape slot)}, j = largest index with row[j] <= bucket start
     int lut_bits;
     int nrows;
     int total;  // total packed entries
@@ -132,6 +132,8 @@ struct DevTables {  // packed CDF rows for the device coder
     // multiply-high (Alverson; ryg_rans rans64.h:167-278 does the same for its Rans64EncSymbol):
     //   {m_lo, m_hi, bias | shift << 17, freq},  q = mulhi64(x, m) >> shift,  x' = x + bias + q * (65536 - freq)
     const uint32_t* enc;
+    // decoder side: the rows as cdf - 1, each padded with 64 entries 0xFFFF; row r starts at row_off[r] + 64 * r
+    const uint16_t* cm;
 };
 
 struct PartGeom {

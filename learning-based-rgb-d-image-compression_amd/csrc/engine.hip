@@ -56,7 +56,9 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
             const int64_t lim = (int64_t)b << (16 - bits);
             while (j + 1 <= len - 2 && row[j + 1] <= lim) ++j;
             lut[((size_t)r * LN + b) * 2] = (uint32_t)j | ((uint32_t)row[j] << 16);
-            lut[((size_t)r * LN + b) * 2 + 1] = (uint32_t)(row[j + 1] - row[j]);
+            // a candidate that is the row's escape slot gets frequency 0: the decoder's one range check then also routes
+            // escapes away from its fast path
+            lut[((size_t)r * LN + b) * 2 + 1] = j == len - 2 ? 0u : (uint32_t)(row[j + 1] - row[j]);
         }
     }
     // encoder entries: m = ceil(2^(63+s) / freq), s = ceil(log2 freq): floor(x * m / 2^(63+s)) == x / freq for every
@@ -87,11 +89,19 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
             e[3] = freq;
         }
     }
+    // decoder probe array: every row again as cdf - 1 (entry 0: 0) followed by 64 pad entries 0xFFFF (= 65536 - 1), so a
+    // 64-wide "entry < cum" probe needs no bounds and a probe that ends on the pad has found the row's escape slot
+    std::vector<uint16_t> cm((size_t)total + 64 * (size_t)nrows, (uint16_t)0xFFFFu);
+    for (int r = 0; r < nrows; ++r) {
+        const int32_t* row = cdf + (size_t)r * stride;
+        for (int j = 0; j < sizes[r] - 1; ++j) cm[(size_t)row_off[r] + 64 * (size_t)r + j] = (uint16_t)(j ? row[j] - 1 : 0);
+    }
+    const size_t b_cm = (cm.size() * 2 + 15) & ~(size_t)15;
     const size_t b_enc = (size_t)total * 16;
     const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
     const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
-    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc;
+    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm;
     if (ts->blob) (void)hipFree(ts->blob);
     ts->blob = nullptr;
     HIP_TRY(hipMalloc(&ts->blob, bytes));
@@ -103,6 +113,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     memcpy(p + b_cdf + b_lut + b_i32, sizes, (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + 3 * b_i32, enc.data(), b_enc);
+    memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc, cm.data(), cm.size() * 2);
     HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
     unsigned char* dp = (unsigned char*)ts->blob;
     ts->d.cdf = (const uint16_t*)dp;
@@ -112,6 +123,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     ts->d.sizes = (const int32_t*)(dp + b_cdf + b_lut + b_i32);
     ts->d.offsets = (const int32_t*)(dp + b_cdf + b_lut + 2 * b_i32);
     ts->d.enc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32);
+    ts->d.cm = (const uint16_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc);
     ts->d.nrows = nrows;
     ts->d.total = total;
     ts->ready = true;

@@ -599,21 +599,13 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int r = 0; r < t.nrows; ++r) {
-        const int ro = t.row_off[r], n = t.sizes[r] - 1;
-        uint16_t* dst = cm + ro + 64 * r;
-        for (int i = tid; i < n + 64; i += 256) dst[i] = i < n ? (uint16_t)(i ? t.cdf[ro + i] - 1 : 0) : (uint16_t)0xFFFFu;
-    }
     {
-        // bucket entries: {first candidate | its start << 16, its frequency}; a candidate that is the row's escape slot
-        // gets frequency 0 so the one range check of the fast path also routes escapes to the slow path
-        const uint2* gl = reinterpret_cast<const uint2*>(t.lut);
-        for (int i = tid; i < t.nrows * lut_n; i += 256) {
-            uint2 e = gl[i];
-            const int row = i / lut_n;
-            if ((int)(e.x & 0xFFFFu) == t.sizes[row] - 2) e.y = 0u;
-            sl[i] = e;
-        }
+        const int ncm16 = ((t.total + 64 * t.nrows) * 2 + 15) / 16;  // both images are padded to 16 bytes
+        const uint4* gcm = reinterpret_cast<const uint4*>(t.cm);
+        uint4* lcm = reinterpret_cast<uint4*>(cm);
+        for (int i = tid; i < ncm16; i += 256) lcm[i] = gcm[i];
+        const uint2* gl = reinterpret_cast<const uint2*>(t.lut);  // bucket entries (escape candidates carry frequency 0)
+        for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = gl[i];
     }
     for (int i = tid; i < t.nrows; i += 256)  // {row start in cm : 16 | cdf_length : 16}, {offset (signed) : 16 | unused}
         rowinfo[i] = make_uint2((uint32_t)(t.row_off[i] + 64 * i) | ((uint32_t)t.sizes[i] << 16),
