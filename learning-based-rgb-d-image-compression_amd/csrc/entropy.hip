@@ -460,10 +460,11 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                 "s_branch 9f\n"
                 // escape payload (reverse of rans_interface.cpp:147-162): the value's nibbles, then their count, pushed with
                 // 4-bit steps; afterwards the escape slot itself is coded like any symbol (label 10).  At most two words are
-                // emitted here, so with three free slots in the current output block no store can become due.
+                // emitted here and one more by the slot itself, so with four free slots in the current output block no store
+                // becomes due before the symbol is finished (a store exit re-enters at the symbol's start).
                 "7:\n"
                 "s_and_b32 %[tt], %[w], 63\n"
-                "s_cmp_lt_u32 %[tt], 3\n"
+                "s_cmp_lt_u32 %[tt], 4\n"
                 "s_cbranch_scc1 70f\n"
                 "v_readlane_b32 %[t4], %[vraw], m0\n"
                 "s_flbit_i32_b32 %[t2], %[t4]\n"

@@ -86,7 +86,9 @@ static int expand_symbols(orc_items *b, const int32_t *sym, const int32_t *idx, 
             return -1;
         if (v == top) {
             int32_t nn = 0;
-            while ((raw >> (nn * ORC_ESC_BITS)) != 0)
+            /* nn < 8: a 32-bit raw value has at most 8 nibbles; the reference's loop (rans_interface.cpp:143-145) shifts by
+             * 32 for raw >= 2^28, which is undefined behaviour there and never terminates on x86 */
+            while (nn < 8 && (raw >> (nn * ORC_ESC_BITS)) != 0)
                 ++nn;
             int32_t left = nn; /* nibble count, base-15 "unary" (cpp:147-154) */
             while (left >= (int32_t)ORC_ESC_MAX) {

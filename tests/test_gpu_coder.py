@@ -103,3 +103,52 @@ def test_bottleneck_tables(kat):
     s = ans._encode(t, sym, idx)
     assert s == coder.rans_encode(sym, idx, ot)
     assert np.array_equal(coder.rans_decode(s, idx, ot), sym)
+
+
+@pytest.mark.parametrize("esc_rate,n", [(0.2, 60000), (0.6, 20000), (1.0, 5000)])
+def test_escape_heavy_streams(esc_rate, n, kat, gc_tables, gpu_tables):
+    """Escapes of every payload length the reference can code (1..7 nibbles: its nibble-count loop is undefined for raw
+    values >= 2^28, rans_interface.cpp:143-145), both signs, at rates that keep the ISA escape paths, their window /
+    block-boundary fall-backs and the generic paths all busy."""
+    from rgbd_amd import ans
+
+    rng = np.random.RandomState(int(esc_rate * 10) + n)
+    idx = rng.randint(0, 64, n).astype(np.int32)
+    sym = np.rint(rng.standard_normal(n) * kat["scale_table"][idx]).astype(np.int64)
+    esc = rng.rand(n) < esc_rate
+    mag = (2.0 ** rng.uniform(0, 26.5, int(esc.sum()))).astype(np.int64)
+    sym[esc] = np.where(rng.rand(int(esc.sum())) < 0.5, mag, -mag)
+    sym = sym.astype(np.int32)
+    s = ans._encode(gpu_tables, sym, idx)
+    assert s == coder.rans_encode(sym, idx, gc_tables)
+    d = ans.RansDecoder()
+    d.set_stream(s)
+    assert np.array_equal(np.asarray(d.decode_stream(idx, kat["gc_cdf"], kat["gc_sizes"], kat["gc_offsets"]), np.int32), sym)
+
+
+def test_very_wide_row():
+    """A row with 20,000 symbols: more than 64 candidates per bucket, so the decoder's 64-lane probe has to continue
+    (generic path), next to a narrow row in the same table."""
+    require_gpu()
+    from rgbd_amd import ans
+
+    n_sym = 20000
+    freq = np.full(n_sym + 1, 3, np.int64)  # last entry = escape slot
+    freq[: 65536 - int(freq.sum())] += 1
+    wide = np.concatenate([[0], np.cumsum(freq)]).astype(np.int32)
+    assert wide[-1] == 65536
+    cdf = np.zeros((2, wide.shape[0]), np.int32)
+    cdf[0] = wide
+    cdf[1, :5] = [0, 20000, 40000, 65000, 65536]
+    sizes = np.array([wide.shape[0], 5], np.int32)
+    offsets = np.array([-10000, -1], np.int32)
+    t, ot = ans.Tables(cdf, sizes, offsets), coder.Tables(cdf, sizes, offsets)
+    rng = np.random.RandomState(3)
+    n = 40000
+    idx = (rng.rand(n) < 0.2).astype(np.int32)
+    sym = np.where(idx == 0, rng.randint(-10050, 10050, n), rng.randint(-3, 5, n)).astype(np.int32)
+    s = ans._encode(t, sym, idx)
+    assert s == coder.rans_encode(sym, idx, ot)
+    d = ans.RansDecoder()
+    d.set_stream(s)
+    assert np.array_equal(np.asarray(d.decode_stream(idx, cdf, sizes, offsets), np.int32), sym)
