@@ -99,9 +99,8 @@ def main():
         # every step codes one full batch (compress + decompress); the W engine instances keep W steps in flight, so
         # one step's serial coder phases overlap another step's convolutions.  All nsteps finish before this returns.
         res = net.roundtrip_many([(rgb, depth)] * nsteps)
-        if world > 1:  # the job's only exchange: finished streams to every rank (RCCL all_gather)
-            for o, _, _ in res:
-                distributed.gather_streams(o["r_strings"][0] + o["d_strings"][0])
+        if world > 1:  # the job's only exchange: the finished streams of these steps to every rank (one RCCL all_gather)
+            distributed.gather_streams([s for o, _, _ in res for s in o["r_strings"][0] + o["d_strings"][0]])
         return res
 
     if args.warmup:
