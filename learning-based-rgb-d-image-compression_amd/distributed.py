@@ -19,8 +19,10 @@ def init_from_env(backend: str = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # RGBD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+            backend = os.environ.get("RGBD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = min(local, torch.cuda.device_count() - 1)  # (only differs from LOCAL_RANK in such a rehearsal)
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
