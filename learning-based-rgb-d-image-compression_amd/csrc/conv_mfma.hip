@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Without DMA the stage is staged through registers (all loads issued back to back, then committed).
 template <int WM, int WN, int MT, int NT, int KC, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
-                                                         int taps_per_stage)
+                                                         int taps_per_stage, int tab_f)
 {
     constexpr int TM = 16 * MT * WM;
     constexpr int TP = 16 * NT * WN;
@@ -69,6 +69,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     float* wl = smem + (size_t)patch_f * (DMA ? 2 : 1);        // [DMA ? 2 : 1][taps_per_stage][TM][RS]
 
     const int ntaps = a.taps.n[phase];
+    // The tap table is int8 data in the kernel-argument segment; indexing it in the loops below would be a *vector* global
+    // load per tap (there are no sub-dword scalar loads) sitting in front of every MFMA burst and every weight fetch.
+    // Each workgroup therefore expands its phase's taps once into LDS (behind the stage / epilogue buffers):
+    //   tap_off[t] = LDS float offset of tap t inside the patch, tap_w[t] = its weight-slab index
+    int* tap_off = reinterpret_cast<int*>(smem + tab_f);
+    int* tap_w = tap_off + 32;
+    if (tid < ntaps) {
+        tap_off[tid] = ((a.taps.dy[phase][tid] - a.min_dy) * PW + (a.taps.dx[phase][tid] - a.min_dx)) * RS;
+        tap_w[tid] = (int)a.taps.wt[phase][tid] * a.cin_pad;
+    }
+    __syncthreads();
     const int iy0 = ty0 * a.IS + a.min_dy;
     const int ix0 = tx0 * a.IS + a.min_dx;
 
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c4x4 = ((tid + u * 256) % C4) * 4;
             if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
-                v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + (int)a.taps.wt[phase][t0 + gw_j[u]] * a.cin_pad + ci0);
+                v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + tap_w[t0 + gw_j[u]] + ci0);
             pw[DMA ? 0 : u] = v;
         }
     };
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         for (int u = 0; u < WR; ++u)
             if (gw_base[u] >= 0 && gw_j[u] < tg)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(a.w + gw_base[u] + (int)a.taps.wt[phase][t0 + gw_j[u]] * a.cin_pad + ci0),
+                    (const __attribute__((address_space(1))) void*)(a.w + gw_base[u] + tap_w[t0 + gw_j[u]] + ci0),
                     (__attribute__((address_space(3))) void*)(wl + buf * wl_f + (wave_slot0 + u * 256) * 4), 16, 0, 0);
     };
     auto dma_p = [&](int chunk, int buf) {
@@ -239,9 +250,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         const int nkk = min(KC / 16, (ci_hi - ci_lo - (stage / ngroups) * KC) / 16);  // no MFMAs on the zero tail
         for (int kk = 0; kk < nkk; ++kk) {
             for (int j = 0; j < tg; ++j) {
-                const int dy = a.taps.dy[phase][t0 + j] - a.min_dy;
-                const int dx = a.taps.dx[phase][t0 + j] - a.min_dx;
-                const int toff = (dy * PW + dx) * RS + kk * 16;  // wave-uniform
+                const int toff = tap_off[t0 + j] + kk * 16;  // wave-uniform
                 f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -362,7 +371,8 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;
     const size_t epi_bytes = (size_t)TP * (16 * WM * EMT + 4) * sizeof(float);
     const size_t stage_bytes = (patch_bytes + (size_t)tps * tap_bytes) * (DMA ? 2 : 1);
-    const size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    const size_t buf_bytes = ((stage_bytes > epi_bytes ? stage_bytes : epi_bytes) + 15) & ~(size_t)15;
+    const size_t lds = buf_bytes + 256;  // + the workgroup's expanded tap table (2 x 32 ints)
     auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
@@ -372,7 +382,7 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * a.N), (unsigned)((a.cout_pad + TM - 1) / TM),
               (unsigned)(a.nphase * a.splitk));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps, (int)(buf_bytes / 4));
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
