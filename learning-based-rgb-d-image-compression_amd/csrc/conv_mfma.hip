@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         tap_w[tid] = (int)a.taps.wt[phase][tid] * a.cin_pad;
     }
     __syncthreads();
+    const int my_tap_off = tap_off[lane & 31];  // lane t keeps tap t's offset: the loops fetch it with v_readlane
     const int iy0 = ty0 * a.IS + a.min_dy;
     const int ix0 = tx0 * a.IS + a.min_dx;
 
@@ -248,9 +249,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         // four sub-chunks in the OUTER loop (the launcher only picks KC=64 when one stage holds every tap), so the
         // fma chain of each output is the same for every KC / tile choice.
         const int nkk = min(KC / 16, (ci_hi - ci_lo - (stage / ngroups) * KC) / 16);  // no MFMAs on the zero tail
+        // (double-buffering the A/B fragments across taps was measured: +60 VGPRs drop the 128-pixel tiles to one
+        //  workgroup per CU and cost more than the hidden LDS latency gains)
         for (int kk = 0; kk < nkk; ++kk) {
             for (int j = 0; j < tg; ++j) {
-                const int toff = tap_off[t0 + j] + kk * 16;  // wave-uniform
+                const int toff = __builtin_amdgcn_readlane(my_tap_off, t0 + j) + kk * 16;  // wave-uniform
                 f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
