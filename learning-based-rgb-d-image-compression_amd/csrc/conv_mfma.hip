@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         } else {
             // all global loads of the stage are issued back to back (one memory round trip per stage), then committed
             // to LDS; the staging registers are dead during the MFMA phase so two workgroups fit per CU and hide each
-            // other's load phase
+            // other's load phase (keeping the next stage's loads in flight during the MFMAs was measured for the
+            // small-accumulator variants that have the registers for it: no gain)
             issue_w(stage);
             if (t0 == 0) issue_p(stage / ngroups);
             __syncthreads();  // every wave has finished reading the previous stage from LDS
