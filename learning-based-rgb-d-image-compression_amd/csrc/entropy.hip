@@ -410,12 +410,13 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
             //   code 1: symbol j carries an escape payload (coded below, then the loop resumes at j)
             //   code 2: a 64-word output block is complete and wants storing
             // v[60:61] = x, v[62:67] scratch (v65 stays 0).  VALU->VALU reads of vcc need 2 wait states on gfx950.
-            uint32_t code, w2, fr, ml, mh, tt, t2, t3, t4;
+            uint32_t code, w2, fr, ml, mh, tt, t2, t3, t4, m0s;
             j = (int)rfl((uint32_t)j);
             w = (int)rfl((uint32_t)w);
             asm volatile(
                 "v_mov_b64 v[60:61], %[x]\n"
                 "v_mov_b32 v65, 0\n"
+                "s_mov_b32 %[m0s], m0\n"                  // m0 is reserved: borrowed for the lane index, restored below
                 "s_mov_b32 m0, %[j]\n"
                 "1:\n"
                 "v_readlane_b32 %[w2], %[vw2], m0\n"
@@ -516,12 +517,14 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
                 "s_mov_b32 %[code], 2\n"
                 "9:\n"
                 "s_mov_b32 %[j], m0\n"
+                "s_mov_b32 m0, %[m0s]\n"
                 "v_mov_b64 %[x], v[60:61]\n"
                 : [x] "+v"(x), [j] "+s"(j), [w] "+s"(w), [ov] "+v"(ov), [code] "=&s"(code), [w2] "=&s"(w2), [fr] "=&s"(fr),
-                  [ml] "=&s"(ml), [mh] "=&s"(mh), [tt] "=&s"(tt), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4)
+                  [ml] "=&s"(ml), [mh] "=&s"(mh), [tt] "=&s"(tt), [t2] "=&s"(t2), [t3] "=&s"(t3), [t4] "=&s"(t4),
+                  [m0s] "=&s"(m0s)
                 : [vw2] "v"(cur.w2), [vfr] "v"(cur.freq), [vml] "v"(cur.mlo), [vmh] "v"(cur.mhi), [lane] "v"(lane),
                   [vraw] "v"(cur.raw)
-                : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "m0", "vcc", "scc", "memory");
+                : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "vcc", "scc", "memory");
             x = rfl64(x);
             code = rfl(code);
             j = (int)rfl((uint32_t)j);
@@ -684,9 +687,10 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
             //   s[84:85] = x, s[86:87] = scratch pair, v[62:63] = bucket entry
             uint32_t a, start, freq, cum, more;
             {
-                uint32_t lb, t0, t1, e0;
+                uint32_t lb, t0, t1, e0, m0s;
                 asm volatile(
                     "s_mov_b64 s[84:85], %[x]\n"
+                    "s_mov_b32 %[m0s], m0\n"                  // m0 is reserved: borrowed here, restored at the exit
                     "s_mov_b32 m0, %[j]\n"                    // symbol index lives in m0 (lane select of both lane ops)
                     "s_cmp_ge_i32 m0, %[cnt]\n"
                     "s_cbranch_scc1 3f\n"
@@ -836,12 +840,13 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "5:\n"
                     "s_mov_b64 %[x], s[84:85]\n"
                     "s_mov_b32 %[j], m0\n"
+                    "s_mov_b32 m0, %[m0s]\n"
                     : [x] "+s"(x), [j] "+s"(j), [wi] "+s"(wi), [outv] "+v"(outv), [a] "=&s"(a), [start] "=&s"(start),
                       [freq] "=&s"(freq), [cum] "=&s"(cum), [more] "=&s"(more), [lb] "=&s"(lb), [t0] "=&s"(t0),
-                      [t1] "=&s"(t1), [e0] "=&s"(e0)
+                      [t1] "=&s"(t1), [e0] "=&s"(e0), [m0s] "=&s"(m0s)
                     : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
                       [lane2] "v"(lane2)
-                    : "m0", "s84", "s85", "s86", "s87", "s88", "s89", "v62", "v63", "scc", "memory");
+                    : "s84", "s85", "s86", "s87", "s88", "s89", "v62", "v63", "vcc", "scc", "memory");
             }
             more = rfl(more);
             if (!more) break;

@@ -151,3 +151,26 @@ def test_synthetic_weights_are_reproducible():
     assert hashlib.sha256(w.tobytes()).hexdigest()[:16] == hashlib.sha256(
         synth.synthetic_state_dict.__globals__["make_tensor"]("g_a.rgb_analysis_transform.0.weight",
                                                               synth.elic_united_entries()["g_a.rgb_analysis_transform.0.weight"], 0).tobytes()).hexdigest()[:16]
+
+
+def test_tile_table_is_well_formed():
+    """csrc/tile_table.h is generated by tools/tune_tiles.py: 14 integers per entry, tile shapes that exist, unique keys."""
+    import os
+    import re
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "learning-based-rgb-d-image-compression_amd", "csrc", "tile_table.h")
+    tiles = {(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)} | {(1, m, n) for n in (2, 1) for m in (3, 2, 1)}
+    keys = set()
+    for ln in open(path):
+        ln = ln.strip()
+        if not ln.startswith("{"):
+            continue
+        v = [int(x) for x in re.findall(r"-?\d+", ln)]
+        assert len(v) == 14, ln
+        key, (wm, mt, nt, kc, dma) = tuple(v[:9]), v[9:]
+        assert key not in keys, ln
+        keys.add(key)
+        assert (wm, mt, nt) in tiles and kc in (16, 64) and dma in (0, 1) and not (dma and kc == 64), ln
+        assert all(x > 0 for x in key) and key[3] % 16 == 0 and key[4] % 16 == 0 and key[7] in (1, 4), ln
+    assert keys
