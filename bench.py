@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per engine instance (the HIP default of 4 makes streams share queues, and a long serial coder
 # kernel then blocks another instance's convolutions); must be set before the HIP runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 WORKLOADS = {
     # name: (batch per GPU, H, W, synthetic config id, model)
@@ -61,11 +61,11 @@ def cpu_baseline(sd, H, W, cid, model="ELIC_united", seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workers", type=int, default=12, help="engine instances (HIP streams) per GPU; 1 = no overlap")
+    ap.add_argument("--workers", type=int, default=16, help="engine instances (HIP streams) per GPU; 1 = no overlap")
     args = ap.parse_args()
 
     import torch
