@@ -42,8 +42,34 @@ def _comm_device():
     return torch.device("cpu")
 
 
-def gather_streams(streams: Sequence[bytes]) -> List[List[bytes]]:
-    """All ranks receive every rank's list of byte strings.  Ranks may hold different numbers of strings."""
+class RankStreams(Sequence):
+    """One rank's gathered byte strings: a view on the gathered payload, split into `bytes` objects only on access (a
+    job that gathers hundreds of MB per step batch should not pay for thousands of copies it may never look at)."""
+
+    def __init__(self, payload: np.ndarray, lens: np.ndarray):
+        self._p = payload
+        self._off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._p[self._off[i]:self._off[i + 1]].tobytes()
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
+def gather_streams(streams: Sequence[bytes]) -> List[Sequence[bytes]]:
+    """All ranks receive every rank's list of byte strings (ranks may hold different numbers of strings): two small
+    all_gathers (counts, lengths) and one all_gather of the zero-padded payload.  Element r of the result behaves like
+    rank r's list of `bytes`."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [list(streams)]
     world = dist.get_world_size()
@@ -51,6 +77,7 @@ def gather_streams(streams: Sequence[bytes]) -> List[List[bytes]]:
     count = torch.tensor([len(streams), sum(len(s) for s in streams)], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)
+    counts = [c.cpu() for c in counts]
     max_n = max(int(c[0]) for c in counts)
     max_b = max(int(c[1]) for c in counts)
     lens = torch.zeros(max(max_n, 1), dtype=torch.int64)
@@ -67,13 +94,7 @@ def gather_streams(streams: Sequence[bytes]) -> List[List[bytes]]:
     out = []
     for r in range(world):
         n = int(counts[r][0])
-        ls = all_lens[r][:n].cpu().tolist()
-        buf = all_payload[r].cpu().numpy().tobytes()
-        res, o = [], 0
-        for ln in ls:
-            res.append(buf[o:o + ln])
-            o += ln
-        out.append(res)
+        out.append(RankStreams(all_payload[r].cpu().numpy(), all_lens[r][:n].cpu().numpy()))
     return out
 
 
