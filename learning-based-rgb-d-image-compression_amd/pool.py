@@ -2,7 +2,7 @@
 
 The entropy stage is a serial chain per stream (rANS state recurrence, 20 decode phases interleaved with the context
 networks) that occupies a handful of CUs, while the transforms want the whole chip.  Image pairs are independent, so a
-`CodecPool` keeps W engine instances (own weights replica, own workspace, own HIP stream) and codes W groups of a batch
+`CodecPool` keeps W engine instances (shared packed weights, own workspace, own HIP stream) and codes W groups of a batch
 concurrently from W host threads: one group's serial coder phases overlap another group's convolutions.  Results are
 identical to coding each group alone (the kernels are batch-invariant); only the wall clock changes.
 """
