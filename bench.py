@@ -128,8 +128,9 @@ def main():
 
     traffic = None
     try:  # HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), see profiles/
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = round(json.load(f)["hbm_bytes_per_launch"]) if args.workload == "c2_8x256x256" else None
+        name = {"c2_8x256x256": "r01_pmc_traffic.json", "c3_4x480x640": "r01_c3_pmc_traffic.json"}[args.workload]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
     if rank == 0:

@@ -21,4 +21,11 @@ steps=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.lo
 { python3 profiles/summarize.py "$out/stats_w1" 10; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_default_kernel_stats.csv"
 python3 profiles/pmc_traffic.py "$out/fetch" "$out/write" "$out/$tag" 28420875.4
+# the same two PMC passes for the 480x640 workload (BASELINE config 3's per-GPU share): 4 x 512x640 padded pixels x 30.28 KB
+# + 1.01 GB weights per step over 594 launches = 68.5 MB algorithmic per launch
+cd /tmp
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_c3" -o run -- python3 "$root/bench.py" --workload c3_4x480x640 --steps 2 --warmup 1 --workers 1 --no-cpu-baseline > "$out/fetch_c3.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write_c3" -o run -- python3 "$root/bench.py" --workload c3_4x480x640 --steps 2 --warmup 1 --workers 1 --no-cpu-baseline > "$out/write_c3.log" 2>&1
+cd "$root"
+python3 profiles/pmc_traffic.py "$out/fetch_c3" "$out/write_c3" "$out/${tag}_c3" 68516164 "--workload c3_4x480x640"
 ls "$out"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) into
-HBM bytes per conv launch.  Usage: pmc_traffic.py <fetch_dir> <write_dir> <out_prefix> [algorithmic_bytes_per_launch]"""
+HBM bytes per conv launch.  Usage: pmc_traffic.py <fetch_dir> <write_dir> <out_prefix> [algorithmic_bytes_per_launch [extra bench args]]"""
 import collections
 import csv
 import glob
@@ -9,6 +9,7 @@ import sys
 
 fetch_dir, write_dir, prefix = sys.argv[1:4]
 algo = float(sys.argv[4]) if len(sys.argv) > 4 else None
+extra = (" " + sys.argv[5]) if len(sys.argv) > 5 else ""
 
 
 def load(d, counter):
@@ -39,7 +40,7 @@ n = sum(v[0] for v in cf)
 fetch_kib, write_kib = sum(v[1] for v in cf) / n, sum(v[1] for v in cw) / max(sum(v[0] for v in cw), 1)
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
-               "--steps 2 --warmup 1 --workers 1 --no-cpu-baseline",
+               "--steps 2 --warmup 1 --workers 1 --no-cpu-baseline" + extra,
     "kernel": "conv_mfma_kernel (all instantiations; split-K reducers not included)",
     "launches": n,
     "fetch_size_kib_per_launch_raw": fetch_kib,
