@@ -53,8 +53,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     const int TH = TP >> tw_log2;
     const int phase = blockIdx.z / a.splitk;
     const int split = blockIdx.z - phase * a.splitk;
-    const int co0 = blockIdx.y * TM;
-    int bt = blockIdx.x;
+    // Workgroup -> (pixel tile, cout tile).  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+    // the linear id is first remapped to give every XCD a contiguous chunk of the work list (bijective for any count),
+    // and the work list runs cout-tile-fastest: the workgroups that read the same input patch then sit on one XCD back
+    // to back and the second one finds the patch in that L2 instead of HBM.  Placement is a speed matter only.
+    const int ycount = (a.cout_pad + TM - 1) / TM;
+    int wid;
+    {
+        const int orig = blockIdx.x, nwg = gridDim.x;
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+        wid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    }
+    const int co0 = (wid % ycount) * TM;
+    int bt = wid / ycount;
     const int tile_x = bt % tiles_x;
     bt /= tiles_x;
     const int tile_y = bt % tiles_y;
@@ -384,7 +395,7 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
                                     (int)(160 * 1024)));
         configured = 160 * 1024;
     }
-    dim3 grid((unsigned)(tiles_x * tiles_y * a.N), (unsigned)((a.cout_pad + TM - 1) / TM),
+    dim3 grid((unsigned)(tiles_x * tiles_y * a.N) * (unsigned)((a.cout_pad + TM - 1) / TM), 1,
               (unsigned)(a.nphase * a.splitk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps, (int)(buf_bytes / 4));
     HIP_TRY(hipGetLastError());
