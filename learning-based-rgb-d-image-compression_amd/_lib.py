@@ -8,6 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librgbd_amd.so")
+_SO = os.environ.get("RGBD_AMD_LIB", _SO)  # A/B builds: point at another librgbd_amd.so
 _SRCS = ["conv_mfma.hip", "pointwise.hip", "swin.hip", "entropy.hip", "engine.hip"]
 _LIB = None
 

@@ -690,13 +690,47 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 uint32_t lb, t0, t1, e0, m0s;
                 asm volatile(
                     "s_mov_b64 s[84:85], %[x]\n"
-                    "s_mov_b32 %[m0s], m0\n"                  // m0 is reserved: borrowed here, restored at the exit
-                    "s_mov_b32 m0, %[j]\n"                    // symbol index lives in m0 (lane select of both lane ops)
+                    "s_mov_b32 %[m0s], m0\n"
+                    "s_mov_b32 m0, %[j]\n"
                     "s_cmp_ge_i32 m0, %[cnt]\n"
                     "s_cbranch_scc1 3f\n"
+                    // First level: every lane holds one slot of the symbol's padded cm row (cm = cdf - 1, 0xFFFF
+                    // pad), loaded one symbol AHEAD so the LDS hop overlaps the previous symbol's update.
+                    "v_readlane_b32 %[lb], %[rowbase], m0\n"
+                    "v_add_u32 v60, %[lb], %[lane2]\n"
+                    "ds_read_u16 v59, v60 offset:2\n"
                     "1:\n"
-                    "v_readlane_b32 %[lb], %[lutbase], m0\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_mov_b32 v58, v59\n"                      // this symbol's row slots
+                    "s_add_u32 %[t1], m0, 1\n"                  // prefetch the next symbol's row (clamped: the
+                    "s_min_u32 %[t1], %[t1], 63\n"              // last lane re-reads itself, value unused)
+                    "v_readlane_b32 %[lb], %[rowbase], %[t1]\n"
+                    "v_add_u32 v60, %[lb], %[lane2]\n"
+                    "ds_read_u16 v59, v60 offset:2\n"
                     "s_and_b32 %[cum], s84, 0xffff\n"
+                    "v_cmp_gt_u32 vcc, %[cum], v58\n"           // lanes with cdf[i+1] <= cum
+                    "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index when it is < 64
+                    "s_cmp_eq_u32 %[a], 64\n"
+                    "s_cbranch_scc1 60f\n"                      // beyond the first 64 slots: bucket table
+                    "s_sub_u32 %[t0], %[a], 1\n"
+                    "v_readlane_b32 %[t1], v58, %[a]\n"         // cdf[a+1]-1
+                    "s_and_b32 %[t0], %[t0], 63\n"
+                    "v_readlane_b32 %[t0], v58, %[t0]\n"        // cdf[a]-1 (a == 0: -1 below)
+                    "s_cmp_eq_u32 %[a], 0\n"
+                    "s_cselect_b32 %[t0], -1, %[t0]\n"
+                    "s_cmp_eq_u32 %[t1], 0xffff\n"              // cdf[a+1] == 65536: last slot = escape
+                    "s_cbranch_scc1 61f\n"
+                    "s_sub_u32 %[freq], %[t1], %[t0]\n"
+                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
+                    "s_sub_u32 %[t0], %[t0], 1\n"               // cum - start
+                    "s_branch 6f\n"
+                    "61:\n"
+                    "s_sub_u32 %[freq], 0xffff, %[t0]\n"
+                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
+                    "s_sub_u32 %[t0], %[t0], 1\n"
+                    "s_branch 73f\n"
+                    "60:\n"
+                    "v_readlane_b32 %[lb], %[lutbase], m0\n"
                     "s_lshr_b32 %[t0], %[cum], %[shift]\n"
                     "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n"
                     "v_mov_b32 v62, %[lb]\n"
@@ -708,7 +742,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_sub_u32 %[t0], %[cum], %[start]\n"
                     "s_and_b32 %[a], %[e0], 0xffff\n"
                     "s_cmp_ge_u32 %[t0], %[freq]\n"
-                    "s_cbranch_scc1 2f\n"                      // not resolved by the bucket entry
+                    "s_cbranch_scc1 2f\n"
                     "6:\n"
                     "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
                     "s_mul_i32 %[t1], s87, %[freq]\n"
@@ -735,6 +769,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
                     // path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot.
                     "2:\n"
+                    "s_cmp_eq_u32 %[freq], 0\n"               // escape marker: the bucket's first candidate is the row's
+                    "s_cbranch_scc1 71f\n"                     // last slot, so the symbol is that slot -- no probe needed
                     "v_readlane_b32 %[lb], %[rowbase], m0\n"
                     "s_lshl1_add_u32 %[lb], %[a], %[lb]\n"
                     "v_add_u32 v62, %[lb], %[lane2]\n"
@@ -838,6 +874,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "8:\n"
                     "s_mov_b32 %[more], 1\n"
                     "5:\n"
+                    "s_waitcnt lgkmcnt(0)\n"                    // drain the row prefetch
                     "s_mov_b64 %[x], s[84:85]\n"
                     "s_mov_b32 %[j], m0\n"
                     "s_mov_b32 m0, %[m0s]\n"
@@ -846,7 +883,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                       [t1] "=&s"(t1), [e0] "=&s"(e0), [m0s] "=&s"(m0s)
                     : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
                       [lane2] "v"(lane2)
-                    : "s84", "s85", "s86", "s87", "s88", "s89", "v62", "v63", "vcc", "scc", "memory");
+                    : "s84", "s85", "s86", "s87", "s88", "s89", "v58", "v59", "v60", "v62", "v63", "vcc", "scc", "memory");
             }
             more = rfl(more);
             if (!more) break;
