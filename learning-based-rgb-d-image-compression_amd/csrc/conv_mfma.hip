@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     }
     __syncthreads();
     const int my_tap_off = tap_off[lane & 31];  // lane t keeps tap t's offset: the loops fetch it with v_readlane
+    const int my_tap_w = tap_w[lane & 31];      // likewise its weight-slab offset
     const int iy0 = ty0 * a.IS + a.min_dy;
     const int ix0 = tx0 * a.IS + a.min_dx;
 
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             const int f = tid + u * 256;
             const int c4 = f % C4;
             const int m = (f / C4) % TM;
-            gw_j[u] = (f / C4) / TM;
+            gw_j[u] = __builtin_amdgcn_readfirstlane((f / C4) / TM);  // a wave's 64 slots are 64/C4 rows of one tap (TM % 16 == 0)
             const int co = co0 + m;
             gw_base[u] = co < a.cout_pad ? (co * a.ntaps_total) * a.cin_pad + c4 * 4 : -1;
         }
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c4x4 = ((tid + u * 256) % C4) * 4;
             if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
-                v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + tap_w[t0 + gw_j[u]] + ci0);
+                v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + __builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0);
             pw[DMA ? 0 : u] = v;
         }
     };
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         for (int u = 0; u < WR; ++u)
             if (gw_base[u] >= 0 && gw_j[u] < tg)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(a.w + gw_base[u] + tap_w[t0 + gw_j[u]] + ci0),
+                    (const __attribute__((address_space(1))) void*)(a.w + gw_base[u] + __builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0),
                     (__attribute__((address_space(3))) void*)(wl + buf * wl_f + (wave_slot0 + u * 256) * 4), 16, 0, 0);
     };
     auto dma_p = [&](int chunk, int buf) {
