@@ -174,6 +174,8 @@ int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, in
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
 int rgbd_debug_force_splitk(int32_t s);
+int rgbd_debug_force_ckbd(int32_t part); /* rgbd_conv2d_nchw / rgbd_conv_bench: 0 = all outputs, 1 = anchor positions only
+                                           ((row + col) odd, utils/ckbd.py:37-48), 2 = non-anchor only; the rest reads 0 */
 int rgbd_debug_conv_log(int32_t on);                      /* record the shape of every conv launch (tools/tune_tiles.py) */
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap); /* CSV text of the recorded shapes; returns the size needed */
 int rgbd_debug_force_tile(const char* cfg); /* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */

@@ -70,10 +70,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     bt /= tiles_x;
     const int tile_y = bt % tiles_y;
     const int n = bt / tiles_y;
-    const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+    // checkerboard output (a.ckbd): the tile's TW columns are every second column of a 2*TW-wide strip -- pixel (py, k)
+    // sits at column 2k + par(row); the staged patch is the whole strip, only the B-fragment rows and the stores move
+    const int ck = a.ckbd ? 1 : 0;
+    const int ty0 = tile_y * TH, tx0 = tile_x * (TW << ck);
 
     const int PH = (TH - 1) * a.IS + a.span_y;
-    const int PW = (TW - 1) * a.IS + a.span_x;
+    const int PW = ((TW << ck) - 1) * a.IS + a.span_x;
     const int patch_f = PH * PW * RS;                         // floats per patch buffer
     const int wl_f = taps_per_stage * TM * RS;                 // floats per weight buffer
     float* patch = smem;                                       // [DMA ? 2 : 1][PH*PW][RS]
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         const int p = (wn * NT + j) * 16 + l15;
         ppy[j] = p >> tw_log2;
         ppx[j] = p & (TW - 1);
+        if (ck) ppx[j] = 2 * ppx[j] + (((ty0 + ppy[j]) & 1) ^ (a.ckbd == 1 ? 1 : 0));
     }
 
     const int npatch4 = PH * PW * C4;
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 const int p = f / S4, c4 = f - p * S4;
                 const int wmc = c4 / (4 * EMT), ii = (c4 / 4) % EMT;
                 const int cb = co0 + (wmc * MT + ip + ii) * 16 + (c4 & 3) * 4;
-                const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+                const int gy = ty0 + (p >> tw_log2);
+                const int gx = tx0 + (ck ? 2 * (p & (TW - 1)) + ((gy & 1) ^ (a.ckbd == 1 ? 1 : 0)) : (p & (TW - 1)));
                 ok[u] = ip + ii < MT && cb < a.cout_store && gy < a.GH && gx < a.GW;
                 cbs[u] = cb;
                 pixs[u] = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
@@ -368,8 +373,9 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     constexpr int TP = 16 * NT * WN;
     constexpr int RS = KC > 16 ? KC + 4 : KC;
     const int TW = 1 << tw_log2, TH = TP / TW;
-    const int tiles_x = (a.GW + TW - 1) / TW, tiles_y = (a.GH + TH - 1) / TH;
-    const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
+    const int TWx = a.ckbd ? 2 * TW : TW;  // columns a tile spans (checkerboard output: every second one is computed)
+    const int tiles_x = (a.GW + TWx - 1) / TWx, tiles_y = (a.GH + TH - 1) / TH;
+    const int PH = (TH - 1) * a.IS + a.span_y, PW = (TWx - 1) * a.IS + a.span_x;
     const size_t patch_bytes = (size_t)PH * PW * RS * sizeof(float);
     const size_t tap_bytes = (size_t)TM * RS * sizeof(float);
     int max_taps = 1;
@@ -437,17 +443,19 @@ Choice choose(const ConvArgs& a)
     int max_taps = 1;
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
     const double K = (double)max_taps * a.cin_pad / a.splitk;
+    const int ck = a.ckbd ? 1 : 0;
+    const int GWe = ck ? (a.GW + 1) / 2 : a.GW;  // computed columns per row
     Choice best{2, 4, 4, 16, 4, false};
     double best_cost = -1.0;
     long best_blocks = 0;
     for (const auto& c : cand) {
         const int wm = c[0], mt = c[1], nt = c[2];
         const int tm = 16 * mt * wm, tp = 16 * nt * (wm == 2 ? 2 : 4);
-        const int twl = pick_tw_log2(a.GW, a.GH, tp);
+        const int twl = pick_tw_log2(GWe, a.GH, tp);
         const int TW = 1 << twl, TH = tp / TW;
-        const long tiles = (long)((a.GW + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
+        const long tiles = (long)((GWe + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
         const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase * a.splitk;
-        const int PH = (TH - 1) * a.IS + a.span_y, PW = (TW - 1) * a.IS + a.span_x;
+        const int PH = (TH - 1) * a.IS + a.span_y, PW = ((TW << ck) - 1) * a.IS + a.span_x;
         const int pr = tp >= 128 ? 12 : (tp >= 64 ? 6 : 4);
         if ((long)PH * PW * 4 > pr * 256 || (long)tm * 4 > 8 * 256) continue;  // register-staging limits (KC=16)
         // a wave with one or two accumulator tiles cannot cover the MFMA latency / its LDS reads
@@ -467,10 +475,10 @@ Choice choose(const ConvArgs& a)
     if (a.cin_pad >= 64) {
         const int tp = 16 * best.nt * (best.wm == 2 ? 2 : 4);
         const int TW = 1 << best.tw_log2, TH = tp / TW;
-        const size_t patch64 = (size_t)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 68 * 4;
+        const size_t patch64 = (size_t)((TH - 1) * a.IS + a.span_y) * (((TW << ck) - 1) * a.IS + a.span_x) * 68 * 4;
         const size_t tap64 = (size_t)16 * best.mt * best.wm * 68 * 4;
         const long mfma_per_stage16 = (long)max_taps * 4 * best.mt * best.nt;
-        const long p4 = (long)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 16;
+        const long p4 = (long)((TH - 1) * a.IS + a.span_y) * (((TW << ck) - 1) * a.IS + a.span_x) * 16;
         const long w4 = (long)max_taps * 16 * best.mt * best.wm * 16;
         const int pr = tp >= 128 ? 12 : (tp >= 64 ? 6 : 4);
         if (patch64 + (size_t)max_taps * tap64 <= (size_t)LDS_BUDGET && mfma_per_stage16 < 400 && p4 <= pr * 256 &&
@@ -481,7 +489,7 @@ Choice choose(const ConvArgs& a)
     {
         const int tp = 16 * best.nt * (best.wm == 2 ? 2 : 4);
         const int TW = 1 << best.tw_log2, TH = tp / TW;
-        const long patch = (long)((TH - 1) * a.IS + a.span_y) * ((TW - 1) * a.IS + a.span_x) * 64;
+        const long patch = (long)((TH - 1) * a.IS + a.span_y) * (((TW << ck) - 1) * a.IS + a.span_x) * 64;
         const long tap = (long)16 * best.mt * best.wm * 64;
         const int need = max_taps < 2 ? max_taps : 2;
         best.dma = best.kc == 16 && 2 * patch + 2 * need * tap <= (long)LDS_BUDGET;
@@ -507,6 +515,10 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
         const size_t pix = i / c4n;
         const int cb = (int)(i - pix * c4n) * 4;
         if (cb >= a.cout_store) continue;
+        if (a.ckbd) {  // checkerboard output: the other half was not computed
+            const int gx = (int)(pix % a.OW), gy = (int)((pix / a.OW) % a.OH);
+            if (((gy + gx) & 1) != (a.ckbd == 1 ? 1 : 0)) continue;
+        }
         f32x4 v = *reinterpret_cast<const f32x4*>(a.partial + pix * a.cout_pad + cb);
         for (int s = 1; s < a.splitk; ++s) v += *reinterpret_cast<const f32x4*>(a.partial + s * plane + pix * a.cout_pad + cb);
         v += *reinterpret_cast<const f32x4*>(a.bias + cb);
@@ -539,7 +551,7 @@ char g_conv_force[64] = {0};  // rgbd_debug_force_tile (tools/tile_sweep.py)
 // tile_table.h; a launch whose shape is listed takes the measured winner, everything else the cost model.  The choice
 // never changes results (every output keeps its fma chain), so the table is a pure performance database.
 struct TunedTile {
-    int N, H, W, cin_pad, cout_pad, ntaps, stride, nphase, splitk;  // key
+    int N, H, W, cin_pad, cout_pad, ntaps, stride, nphase, splitk;  // key (nphase + 10 * ckbd for checkerboard launches)
     int wm, mt, nt, kc, dma;                                        // measured best
 };
 static const TunedTile kTuned[] = {
@@ -553,7 +565,7 @@ static const TunedTile* tuned_lookup(const ConvArgs& a)
     const int stride = a.nphase > 1 ? a.OS : a.IS;
     for (const TunedTile* t = kTuned; t->N; ++t)
         if (t->N == a.N && t->H == a.H && t->W == a.W && t->cin_pad == a.cin_pad && t->cout_pad == a.cout_pad &&
-            t->ntaps == a.ntaps_total && t->stride == stride && t->nphase == a.nphase && t->splitk == a.splitk)
+            t->ntaps == a.ntaps_total && t->stride == stride && t->nphase == a.nphase + 10 * a.ckbd && t->splitk == a.splitk)
             return t;
     return nullptr;
 }
@@ -592,6 +604,7 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
     if (a.splitk < 1) a.splitk = 1;
     if (a.splitk > a.cin_pad / 16) a.splitk = a.cin_pad / 16;
     if (a.splitk > 1 && !a.partial) return RGBD_EINVAL;
+    if (a.ckbd && (a.ckbd > 2 || a.ckbd < 0 || a.nphase != 1 || a.IS != 1 || a.OS != 1)) return RGBD_EINVAL;
     const int rc = launch_conv_main(a, s);
     if (rc || a.splitk == 1) return rc;
     const size_t total4 = (size_t)a.N * a.OH * a.OW * (a.cout_pad / 4);
@@ -614,12 +627,12 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.nt = t->nt;
         c.kc = t->kc;
         c.dma = t->dma != 0;
-        c.tw_log2 = pick_tw_log2(a.GW, a.GH, 16 * t->nt * (t->wm == 2 ? 2 : 4));
+        c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * t->nt * (t->wm == 2 ? 2 : 4));
     }
     if (g_log_on) {
         char key[160];
         snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", a.N, a.H, a.W, a.cin_pad, a.cout_pad, a.ntaps_total,
-                 a.nphase > 1 ? a.OS : a.IS, a.nphase, a.splitk);
+                 a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd, a.splitk);
         std::lock_guard<std::mutex> lk(g_log_mu);
         ++g_log[key];
     }
@@ -633,7 +646,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.nt = nt;
         c.kc = kc;
         c.dma = dm != 0 && kc == 16;
-        c.tw_log2 = pick_tw_log2(a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
+        c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
     }
     static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;
     if (debug)

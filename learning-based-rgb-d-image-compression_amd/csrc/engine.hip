@@ -228,6 +228,8 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
 }
 
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
+int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
+const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
 
 // ------------------------------------------------------------------------------------------------
 // the model
@@ -251,6 +253,7 @@ struct Epi {
     const Act* res1 = nullptr;
     const Act* mul = nullptr;
     const Act* res2 = nullptr;
+    int ckbd = 0;  // ConvArgs::ckbd: compute / store only one checkerboard half of the output
 };
 
 }  // namespace
@@ -391,6 +394,7 @@ struct rgbd_elic {
         a.GH = pc->transposed ? x.h : OH;
         a.GW = pc->transposed ? x.w : OW;
         a.act = ep.act;
+        a.ckbd = ep.ckbd;
         if (ep.res1) {
             a.res1 = ep.res1->p;
             a.r1cs = ep.res1->cs;
@@ -753,7 +757,9 @@ struct rgbd_elic {
     // [r_loc | d_loc | hyper_r | hyper_d | ch_ctx_r | ch_ctx_d]: every EntropyParametersEX input of the reference
     // (elic_united.py:288-333) is a suffix of that layout, so no concatenation copy is needed; SE-rescaling writes the
     // rescaled copy the 1x1 conv reads (params + se(params), keeping the reference's association).
-    Act entropy_params(const std::string& p, const Act& ctx, const Act* dst = nullptr)
+    // `part` (1 anchor / 2 non-anchor): the caller only reads that checkerboard half of (scales, means)
+    // (ckbd.py:83-125), so the last -- and largest -- conv computes just that half; the values are those of the full conv.
+    Act entropy_params(const std::string& p, const Act& ctx, int part, const Act* dst = nullptr)
     {
         const PackedConv* last = conv_of(p + ".fusion.4.weight");
         if (!last) return Act();
@@ -766,7 +772,9 @@ struct rgbd_elic {
         relu.act = ACT_RELU;
         Act t = conv(p + ".fusion.0", cat, 1, 0, relu);
         t = conv(p + ".fusion.2", t, 1, 1, relu);
-        conv(p + ".fusion.4", t, 1, 2, Epi(), &out);
+        Epi last_e;
+        last_e.ckbd = g_ckbd_conv ? part : 0;
+        conv(p + ".fusion.4", t, 1, 2, last_e, &out);
         arena.top = mark;
         return out;
     }
@@ -876,7 +884,7 @@ struct rgbd_elic {
             const int64_t part_syms = (int64_t)C * h * (w / 2);
             const Act r_loc = view(ctx, 0, 2 * C), d_loc = view(ctx, 2 * C, 2 * C);
             // rgb anchor: [hyper, ch ctx]
-            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(ctx, 4 * C, wide - 4 * C));
+            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(ctx, 4 * C, wide - 4 * C), 1);
             code_part(cd, 0, 1, p_ra, yr, hr, part_off);
             conv("rgb_local_context." + si, hr, 1, 2, Epi(), &r_loc);
             // depth anchor: [r_loc, hyper, ch ctx] -- d_loc's slot sits between them, so this one input is gathered
@@ -886,17 +894,17 @@ struct rgbd_elic {
                 Act in = alloc(hyp_r.n, h, w, wide - 2 * C);
                 copy_ch(r_loc, view(in, 0, 2 * C));
                 copy_ch(view(ctx, 4 * C, wide - 4 * C), view(in, 2 * C, wide - 4 * C));
-                entropy_params("depth_entropy_parameters_anchor." + si, in, &p_da);
+                entropy_params("depth_entropy_parameters_anchor." + si, in, 1, &p_da);
                 arena.top = m2;
             }
             code_part(cd, 1, 1, p_da, yd, hd, part_off);
             conv("depth_local_context." + si, hd, 1, 2, Epi(), &d_loc);
             // rgb non-anchor: the whole buffer
-            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, ctx);
+            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, ctx, 2);
             code_part(cd, 0, 0, p_rn, yr, hr, part_off + part_syms);
             conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2, Epi(), &r_loc);  // replaces r_loc
             // depth non-anchor
-            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, ctx);
+            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, ctx, 2);
             code_part(cd, 1, 0, p_dn, yd, hd, part_off + part_syms);
             part_off += 2 * part_syms;
             c0 += C;
@@ -1133,7 +1141,7 @@ struct rgbd_elic {
             const int64_t part_syms = (int64_t)C * h * (w / 2);
             const Act r_loc = view(cr, 0, 2 * C), r_loc_d = view(cdx, 0, 2 * C), d_loc = view(cdx, 2 * C, 2 * C);
             // rgb anchor: [hyper_r, ch_r]
-            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(cr, 2 * C, wide_r - 2 * C));
+            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(cr, 2 * C, wide_r - 2 * C), 1);
             code_part(cd, 0, 1, p_ra, yr, hr, part_off);
             conv("rgb_local_context." + si, hr, 1, 2, Epi(), &r_loc);
             // depth anchor: [r_loc, hyper_r, hyper_d, ch_r, ch_d] (gathered: d_loc's slot sits in between)
@@ -1143,17 +1151,17 @@ struct rgbd_elic {
                 Act in = alloc(hyp_r.n, h, w, wide_d - 2 * C);
                 copy_ch(r_loc, view(in, 0, 2 * C));
                 copy_ch(view(cdx, 4 * C, wide_d - 4 * C), view(in, 2 * C, wide_d - 4 * C));
-                entropy_params("depth_entropy_parameters_anchor." + si, in, &p_da);
+                entropy_params("depth_entropy_parameters_anchor." + si, in, 1, &p_da);
                 arena.top = m2;
             }
             code_part(cd, 1, 1, p_da, yd, hd, part_off);
             conv("depth_local_context." + si, hd, 1, 2, Epi(), &d_loc);
             // rgb non-anchor: [r_loc, hyper_r, ch_r]
-            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, cr);
+            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, cr, 2);
             code_part(cd, 0, 0, p_rn, yr, hr, part_off + part_syms);
             conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2, Epi(), &r_loc_d);
             // depth non-anchor: the whole depth buffer
-            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, cdx);
+            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, cdx, 2);
             code_part(cd, 1, 0, p_dn, yd, hd, part_off + part_syms);
             part_off += 2 * part_syms;
             c0 += C;
@@ -1205,17 +1213,19 @@ struct rgbd_elic {
         return conv("h_s.increase.4", t, 1, 1, Epi(), dst);
     }
     // entropy.py:7-29: three 1x1 convolutions
-    Act entropy_params1(const std::string& p, const Act& ctx)
+    // `part` as in entropy_params(): 1x1 convolutions do not mix positions, so the whole net runs on one half only
+    Act entropy_params1(const std::string& p, const Act& ctx, int part)
     {
-        Epi relu;
+        Epi relu, lin;
         relu.act = ACT_RELU;
+        relu.ckbd = lin.ckbd = g_ckbd_conv ? part : 0;
         const PackedConv* last = conv_of(p + ".fusion.4.weight");
         if (!last) return Act();
         Act out = alloc(ctx.n, ctx.h, ctx.w, last->cout);
         const size_t mark = arena.top;
         Act t = conv(p + ".fusion.0", ctx, 1, 0, relu);
         t = conv(p + ".fusion.2", t, 1, 0, relu);
-        conv(p + ".fusion.4", t, 1, 0, Epi(), &out);
+        conv(p + ".fusion.4", t, 1, 0, lin, &out);
         arena.top = mark;
         return out;
     }
@@ -1241,11 +1251,11 @@ struct rgbd_elic {
             const Act ys = y ? view(*y, c0, C) : Act();
             const Act hs = view(yhat, c0, C);
             const int64_t part_syms = (int64_t)C * h * (w / 2);
-            Act pa = entropy_params1("entropy_parameters_anchor." + si, view(ctx, 2 * C, wide - 2 * C));
+            Act pa = entropy_params1("entropy_parameters_anchor." + si, view(ctx, 2 * C, wide - 2 * C), 1);
             code_part(cd, 0, 1, pa, ys, hs, part_off);
             const Act loc = view(ctx, 0, 2 * C);
             conv("local_context." + si, hs, 1, 2, Epi(), &loc);
-            Act pn = entropy_params1("entropy_parameters_nonanchor." + si, ctx);
+            Act pn = entropy_params1("entropy_parameters_nonanchor." + si, ctx, 2);
             code_part(cd, 0, 0, pn, ys, hs, part_off + part_syms);
             part_off += 2 * part_syms;
             c0 += C;
@@ -2135,6 +2145,8 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
             HIP_TRY(hipMalloc((void**)&part, (size_t)a.splitk * yb));
             a.partial = part;
         }
+        a.ckbd = g_force_ckbd;
+        if (a.ckbd) HIP_TRY(hipMemsetAsync(yout, 0, yb, s));  // the half that is not computed reads as zero
         rc = launch_conv(a, s);
         if (part) {
             (void)hipStreamSynchronize(s);
@@ -2160,6 +2172,13 @@ int rgbd_debug_force_tile(const char* cfg)
 
 int rgbd_debug_conv_log(int32_t on) { return conv_log_enable(on); }
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap) { return conv_log_read(buf, (long)cap); }
+
+int rgbd_debug_force_ckbd(int32_t part)
+{
+    if (part < 0 || part > 2) return RGBD_EINVAL;
+    g_force_ckbd = part;
+    return RGBD_OK;
+}
 
 int rgbd_debug_force_splitk(int32_t s)
 {
@@ -2229,6 +2248,7 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
             a.partial = part;
         }
     }
+    a.ckbd = g_force_ckbd;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));

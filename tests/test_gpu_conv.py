@@ -120,3 +120,41 @@ def test_split_k_matches_and_is_deterministic(split):
         assert torch.equal(got, run(x)) and torch.equal(got[1:2], run(x[1:2]))
     finally:
         lib().rgbd_debug_force_splitk(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [0, 4])
+@pytest.mark.parametrize("k,cin,cout,h,w", [(5, 224, 128, 16, 16), (5, 48, 32, 16, 24), (1, 96, 64, 32, 40), (3, 64, 96, 8, 12)])
+def test_conv_checkerboard_output(k, cin, cout, h, w, split):
+    """ConvArgs::ckbd (entropy-parameter nets, engine.hip entropy_params): only one checkerboard half of the output is
+    computed; those values are bit-identical to the full convolution, the other half is left alone (reads 0 here)."""
+    dev = require_gpu()
+    from rgbd_amd._lib import check, lib
+
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    x = torch.randn(3, cin, h, w, generator=g)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (k * cin ** 0.5)).contiguous()
+    b = torch.randn(cout, generator=g)
+    f32p = ctypes.POINTER(ctypes.c_float)
+
+    def run():
+        xd = x.to(dev).contiguous()
+        yd = torch.empty((3, cout, h, w), device=dev)
+        check(lib().rgbd_conv2d_nchw(ctypes.c_void_p(xd.data_ptr()), 3, cin, h, w, wt.numpy().ctypes.data_as(f32p),
+                                     b.numpy().ctypes.data_as(f32p), cout, k, 1, k // 2, 0, 1, None,
+                                     ctypes.c_void_p(yd.data_ptr()), None), "conv2d")
+        return yd.cpu()
+
+    lib().rgbd_debug_force_splitk(split)
+    try:
+        full = run()
+        yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        for part in (1, 2):
+            lib().rgbd_debug_force_ckbd(part)
+            got = run()
+            keep = ((yy + xx) % 2 == (1 if part == 1 else 0))  # anchor: (row + col) odd (ckbd.py:37-48)
+            assert torch.equal(got[..., keep], full[..., keep])
+            assert got[..., ~keep].abs().max().item() == 0.0
+    finally:
+        lib().rgbd_debug_force_ckbd(0)
+        lib().rgbd_debug_force_splitk(0)

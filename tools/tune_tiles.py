@@ -3,7 +3,7 @@
 stage depth / staging mode for each distinct shape (kernel-only, rgbd_conv_bench) and writes the winners to
 csrc/tile_table.h (a pure performance database: tile choice never changes results).
 
-    python tools/tune_tiles.py [--write] [--model STF_united] B,H,W [B,H,W ...]
+    python tools/tune_tiles.py [--write] [--only-ckbd] [--model STF_united] B,H,W [B,H,W ...]
                                                       (default: 8,256,256 4,512,640 1,256,256 1,512,640, ELIC_united)
 Entries already in tile_table.h for other shapes are kept (the table is merged, not rebuilt).
 """
@@ -26,6 +26,7 @@ if "--model" in argv:
     del argv[argv.index("--model"):argv.index("--model") + 2]
 args = [a for a in argv if not a.startswith("--")]
 WRITE = "--write" in sys.argv
+ONLY_CKBD = "--only-ckbd" in sys.argv  # only the checkerboard-output launches (key field nphase >= 10)
 WORKLOADS = [tuple(int(v) for v in a.split(",")) for a in args] or [(8, 256, 256), (4, 512, 640), (1, 256, 256), (1, 512, 640)]
 L = lib()
 os.environ["RGBD_NO_TILE_TABLE"] = "1"  # (read at first launch) measure the cost model, not a previous table
@@ -60,6 +61,8 @@ def bench(key, iters):
     N, H, W, cin, cout, ntaps, stride, nphase, splitk = key
     k = int(round(ntaps ** 0.5))
     ms = ctypes.c_float(0)
+    L.rgbd_debug_force_ckbd(nphase // 10)  # the key's phase field carries 10 * ckbd
+    nphase %= 10
     rc = L.rgbd_conv_bench(N, cin, H, W, cout, k, stride, k // 2, 1 if nphase > 1 else 0, 0, iters, ctypes.byref(ms))
     return ms.value if rc == 0 else float("inf")
 
@@ -70,6 +73,8 @@ for B, H, W in WORKLOADS:
     w_auto = w_best = 0.0
     for row in rows:
         key, cnt = row[:9], row[9]
+        if ONLY_CKBD and key[7] < 10:
+            continue
         measured.add(key)
         L.rgbd_debug_force_splitk(key[8])
         L.rgbd_debug_force_tile(b"")
@@ -102,6 +107,7 @@ for B, H, W in WORKLOADS:
     tot_best += w_best
 L.rgbd_debug_force_tile(b"")
 L.rgbd_debug_force_splitk(0)
+L.rgbd_debug_force_ckbd(0)
 print(f"total auto {tot_auto:.2f} ms -> tuned {tot_best:.2f} ms, {len(table)} table entries")
 TABLE = os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc", "tile_table.h")
 if os.path.exists(TABLE):  # keep what earlier runs measured for other shapes
