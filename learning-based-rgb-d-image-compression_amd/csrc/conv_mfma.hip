@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     f32x4 pw[DMA ? 1 : WR], pp[DMA ? 1 : PR];
     int gw_base[WR];   // (co0+m) * ntaps_total * cin_pad + c4*4, or -1 when the row is outside cout_pad
     int gw_j[WR];      // tap slot inside the stage
-    int gp_off[PR];    // ((n*H + iy)*W + ix) * xcs + c4*4, or -1 when outside the image / patch
+    unsigned gw_voff[WR];  // byte offset of the slot's weight row (DMA path; always a valid row)
+    int gp_off[PR];    // (iy*W + ix) * xcs + c4*4 inside image n, or -1 when outside the image / patch
+    const float* xn = a.x + (size_t)n * a.H * a.W * a.xcs;  // wave-uniform base of the tile's image
     {
 #pragma unroll
         for (int u = 0; u < WR; ++u) {
@@ -146,6 +148,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             gw_j[u] = __builtin_amdgcn_readfirstlane((f / C4) / TM);  // a wave's 64 slots are 64/C4 rows of one tap (TM % 16 == 0)
             const int co = co0 + m;
             gw_base[u] = co < a.cout_pad ? (co * a.ntaps_total) * a.cin_pad + c4 * 4 : -1;
+            // direct-to-LDS path: rows past cout_pad re-read the tile's first row instead of being masked off (their
+            // outputs are never stored), so the load needs no per-lane predicate
+            gw_voff[u] = (unsigned)((co < a.cout_pad ? co : co0) * a.ntaps_total * a.cin_pad + c4 * 4) * 4u;
         }
 #pragma unroll
         for (int u = 0; u < PR; ++u) {
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             const int pr = row / PW, pc = row - pr * PW;
             const int iy = iy0 + pr, ix = ix0 + pc;
             const bool ok = f < npatch4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            gp_off[u] = ok ? (int)(((size_t)n * a.H * a.W + (size_t)iy * a.W + ix) * a.xcs) + c4 * 4 : -1;
+            gp_off[u] = ok ? (iy * a.W + ix) * a.xcs + c4 * 4 : -1;  // inside image n (xn below): fits 32 bits
         }
     }
     const int w_lds0 = (tid / C4) * RS + (tid % C4) * 4;  // slot u adds u * (256 / C4) * RS floats
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c4x4 = ((tid + u * 256) % C4) * 4;
             if (gp_off[u] >= 0 && (KC == 16 || ci0 + c4x4 < ci_hi))
-                v = *reinterpret_cast<const f32x4*>(a.x + gp_off[u] + ci0);
+                v = *reinterpret_cast<const f32x4*>(xn + gp_off[u] + ci0);
             pp[DMA ? 0 : u] = v;
         }
     };
@@ -202,12 +207,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         const int ci0 = ci_lo + (stage / ngroups) * KC;
         const int t0 = (stage % ngroups) * taps_per_stage;
         const int tg = min(taps_per_stage, ntaps - t0);
+        float* lds_w = wl + buf * wl_f + wave_slot0 * 4;
+        // address = wave-uniform pointer (tap slab + channel chunk, SALU) + hoisted per-lane byte offset: a handful of
+        // scalar instructions per load and no exec masking -- the issue slots of this code come out of the MFMA stream
 #pragma unroll
         for (int u = 0; u < WR; ++u)
-            if (gw_base[u] >= 0 && gw_j[u] < tg)
+            if (gw_j[u] < tg) {  // wave-uniform
+                const unsigned so = (unsigned)(__builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0) * 4u;
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(a.w + gw_base[u] + __builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0),
-                    (__attribute__((address_space(3))) void*)(wl + buf * wl_f + (wave_slot0 + u * 256) * 4), 16, 0, 0);
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.w) + (size_t)(gw_voff[u] + so)),
+                    (__attribute__((address_space(3))) void*)(lds_w + u * 1024), 16, 0, 0);
+            }
     };
     auto dma_p = [&](int chunk, int buf) {
         const int ci0 = ci_lo + chunk * KC;
@@ -215,10 +225,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         for (int u = 0; u < PR; ++u) {
             const int f = tid + u * 256;
             if (f < npatch4) {
-                if (gp_off[u] >= 0)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.x + gp_off[u] + ci0),
-                                                     (__attribute__((address_space(3))) void*)(patch + buf * patch_f + (wave_slot0 + u * 256) * 4),
-                                                     16, 0, 0);
+                if (gp_off[u] >= 0)  // uniform base + 32-bit per-lane byte offset (saddr form, no 64-bit VALU adds)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(xn) +
+                                                                        (size_t)((unsigned)(gp_off[u] + ci0) * 4u)),
+                        (__attribute__((address_space(3))) void*)(patch + buf * patch_f + (wave_slot0 + u * 256) * 4), 16, 0, 0);
                 else
                     *reinterpret_cast<f32x4*>(patch + buf * patch_f + f * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
