@@ -134,9 +134,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     // global element offsets (weights: without the tap/chunk term; patch: pixel offset or -1 outside the image) --
     // the per-stage work is then one add and one 16-byte load per slot.  LDS destinations are affine in u.
     f32x4 pw[DMA ? 1 : WR], pp[DMA ? 1 : PR];
-    int gw_base[WR];   // (co0+m) * ntaps_total * cin_pad + c4*4, or -1 when the row is outside cout_pad
     int gw_j[WR];      // tap slot inside the stage
-    unsigned gw_voff[WR];  // byte offset of the slot's weight row (DMA path; always a valid row)
+    unsigned gw_voff[WR];  // byte offset of the slot's weight row ((co0+m) * ntaps_total * cin_pad + c4*4 floats; always a valid row)
     int gp_off[PR];    // (iy*W + ix) * xcs + c4*4 inside image n, or -1 when outside the image / patch
     const float* xn = a.x + (size_t)n * a.H * a.W * a.xcs;  // wave-uniform base of the tile's image
     {
@@ -147,9 +146,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
             const int m = (f / C4) % TM;
             gw_j[u] = __builtin_amdgcn_readfirstlane((f / C4) / TM);  // a wave's 64 slots are 64/C4 rows of one tap (TM % 16 == 0)
             const int co = co0 + m;
-            gw_base[u] = co < a.cout_pad ? (co * a.ntaps_total) * a.cin_pad + c4 * 4 : -1;
-            // direct-to-LDS path: rows past cout_pad re-read the tile's first row instead of being masked off (their
-            // outputs are never stored), so the load needs no per-lane predicate
+            // rows past cout_pad re-read the tile's first row instead of being masked off (their outputs are never
+            // stored), so the loads need no per-lane predicate
             gw_voff[u] = (unsigned)((co < a.cout_pad ? co : co0) * a.ntaps_total * a.cin_pad + c4 * 4) * 4u;
         }
 #pragma unroll
@@ -171,8 +169,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         for (int u = 0; u < WR; ++u) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int c4x4 = ((tid + u * 256) % C4) * 4;
-            if (gw_base[u] >= 0 && gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
-                v = *reinterpret_cast<const f32x4*>(a.w + gw_base[u] + __builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0);
+            if (gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
+                v = *reinterpret_cast<const f32x4*>(
+                    reinterpret_cast<const char*>(a.w) +
+                    (size_t)(gw_voff[u] + (unsigned)(__builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0) * 4u));
             pw[DMA ? 0 : u] = v;
         }
     };
