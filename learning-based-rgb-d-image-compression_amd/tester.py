@@ -115,11 +115,12 @@ class TesterUnited:
         return rec_dir
 
     # tester_united.py:141-167
-    def compress_one_image_united(self, x, stream_path, H, W, img_name):
-        torch.cuda.synchronize()
+    def compress_one_image_united(self, x, stream_path, H, W, img_name, net=None, sync=torch.cuda.synchronize):
+        net = net or self.net
+        sync()
         start = time.time()
-        out = self.net.compress(x[0], x[1])
-        torch.cuda.synchronize()
+        out = net.compress(x[0], x[1])
+        sync()
         enc_time = time.time() - start
         bpps = []
         for path, key in ((stream_path[0], "r_strings"), (stream_path[1], "d_strings")):
@@ -132,57 +133,104 @@ class TesterUnited:
         return bpps[0], bpps[1], enc_time
 
     # tester_united.py:169-195
-    def decompress_one_image_united(self, stream_path, img_name, mode="reflect0"):
+    def decompress_one_image_united(self, stream_path, img_name, mode="reflect0", net=None, sync=torch.cuda.synchronize):
+        net = net or self.net
         strings = []
         for path in stream_path:
             with Path(os.path.join(path, img_name)).open("rb") as f:
                 original_size = read_uints(f, 2)
                 s, shape = read_body(f)
                 strings.append(s)
-        torch.cuda.synchronize()
+        sync()
         start = time.time()
-        out = self.net.decompress(strings[0], strings[1], shape)
-        torch.cuda.synchronize()
+        out = net.decompress(strings[0], strings[1], shape)
+        sync()
         dec_time = time.time() - start
         cropper = crop0 if mode.find("0") != -1 else crop1
         return cropper(out["x_hat"]["r"], original_size), cropper(out["x_hat"]["d"], original_size), dec_time
 
     # tester_united.py:48-88 (the rgb stream really lands in "depth_bin" and vice versa, :62-63)
+    def _one_image(self, i, rec_dir, padding_mode, net=None, sync=torch.cuda.synchronize):
+        rgb, depth, rgb_name, _ = self.test_dataloader[i]
+        _, _, H, W = rgb.shape
+        rgb, depth = rgb.to(self.device), depth.to(self.device)
+        paths = (os.path.join(rec_dir, "depth_bin"), os.path.join(rec_dir, "rgb_bin"))
+        rb, db, et = self.compress_one_image_united((pad(rgb, padding_mode), pad(depth, padding_mode)), paths, H, W,
+                                                    rgb_name[0], net=net, sync=sync)
+        xr, xd, dt = self.decompress_one_image_united(paths, rgb_name[0], mode=padding_mode, net=net, sync=sync)
+        rp, rm = compute_metrics(xr, rgb)
+        dp, dm = compute_metrics(xd, depth)
+        if getattr(self, "save_reconstructions", True):  # tester_united.py:98-109
+            save_image(xr, os.path.join(rec_dir, "rgb_rec", f"{rgb_name[0]}_{rb:.4f}_{rp:.4f}__rec.png"))
+            save_image(xd, os.path.join(rec_dir, "depth_rec", f"{rgb_name[0]}_{db:.4f}_{dp:.4f}__rec_8bit.png"))
+            save_depth16(xd, os.path.join(rec_dir, "depth_rec", f"{rgb_name[0]}_{db:.4f}_{dp:.4f}__rec_16bit.png"),
+                         100000 if rec_dir.find("sun") != -1 else 10000)
+        return rgb_name[0], H * W, (rp, rm, rb, dp, dm, db, dt, et)
+
     @torch.no_grad()
-    def test_model(self, padding_mode="reflect0", padding=True):
+    def test_model(self, padding_mode="reflect0", padding=True, workers=1):
+        """workers == 1: the reference loop (one image at a time, device-wide timing brackets).  workers > 1 keeps that
+        many images in flight, each on its own engine instance (shared weights, own stream / workspace) and host thread:
+        files, bpp and PSNR are identical, the per-image latencies then include time-sharing of the GPU, and the job
+        throughput is reported as `self.job_mpx_per_s` (one image's serial coder chain hides behind the others' convs)."""
         self.net.eval()
         names = ("avg_rgb_psnr", "avg_rgb_ms_ssim", "avg_rgb_bpp", "avg_depth_psnr", "avg_depth_ms_ssim",
                  "avg_depth_bpp", "avg_deocde_time", "avg_encode_time")
         meters = {k: AverageMeter() for k in names}
         rec_dir = self.get_rec_dir(padding=padding, padding_mode=padding_mode)
+        n = len(self.test_dataloader)
+        results = [None] * n
+        torch.cuda.synchronize()
+        t_job = time.time()
+        if workers <= 1:
+            for i in range(n):
+                results[i] = self._one_image(i, rec_dir, padding_mode)
+        else:
+            import threading
+
+            W = min(workers, n)
+            nets = [self.net] + [self.net.clone_shared() for _ in range(W - 1)]
+            dev = torch.device("cuda", torch.cuda.current_device())
+            errs = [None] * W
+
+            def work(w):
+                try:
+                    torch.cuda.set_device(dev)
+                    stream = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(stream), torch.no_grad():
+                        for i in range(w, n, W):
+                            results[i] = self._one_image(i, rec_dir, padding_mode, net=nets[w], sync=stream.synchronize)
+                except BaseException as e:  # re-raised on the caller's thread
+                    errs[w] = e
+
+            threads = [threading.Thread(target=work, args=(w,)) for w in range(W)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for e in errs:
+                if e is not None:
+                    raise e
+        torch.cuda.synchronize()
+        wall = time.time() - t_job
+        self.job_mpx_per_s = sum(r[1] for r in results) / max(wall, 1e-9) / 1e6
         rows = []
-        for i in range(len(self.test_dataloader)):
-            rgb, depth, rgb_name, _ = self.test_dataloader[i]
-            _, _, H, W = rgb.shape
-            rgb, depth = rgb.to(self.device), depth.to(self.device)
-            paths = (os.path.join(rec_dir, "depth_bin"), os.path.join(rec_dir, "rgb_bin"))
-            rb, db, et = self.compress_one_image_united((pad(rgb, padding_mode), pad(depth, padding_mode)), paths, H, W,
-                                                        rgb_name[0])
-            xr, xd, dt = self.decompress_one_image_united(paths, rgb_name[0], mode=padding_mode)
-            rp, rm = compute_metrics(xr, rgb)
-            dp, dm = compute_metrics(xd, depth)
-            if getattr(self, "save_reconstructions", True):  # tester_united.py:98-109
-                save_image(xr, os.path.join(rec_dir, "rgb_rec", f"{rgb_name[0]}_{rb:.4f}_{rp:.4f}__rec.png"))
-                save_image(xd, os.path.join(rec_dir, "depth_rec", f"{rgb_name[0]}_{db:.4f}_{dp:.4f}__rec_8bit.png"))
-                save_depth16(xd, os.path.join(rec_dir, "depth_rec", f"{rgb_name[0]}_{db:.4f}_{dp:.4f}__rec_16bit.png"),
-                             100000 if rec_dir.find("sun") != -1 else 10000)
-            for k, v in zip(names, (rp, rm, rb, dp, dm, db, dt, et)):
+        for i, (name, _, vals) in enumerate(results):
+            rp, rm, rb, dp, dm, db, dt, et = vals
+            for k, v in zip(names, vals):
                 meters[k].update(v)
             self.logger_test.info(
-                f"Image[{i}:{rgb_name[0]}] | rBpp loss: {rb:.4f} | dBpp loss: {db:.4f} | rPSNR: {rp:.4f} | dPSNR: {dp:.4f} | "
+                f"Image[{i}:{name}] | rBpp loss: {rb:.4f} | dBpp loss: {db:.4f} | rPSNR: {rp:.4f} | dPSNR: {dp:.4f} | "
                 f"rMS-SSIM: {rm:.4f} | dMS-SSIM: {dm:.4f} | Encoding Latency: {et:.4f} | Decoding latency: {dt:.4f}")
-            rows.append({"name": rgb_name[0], "rgb_bpp": rb, "depth_bpp": db, "rgb_psnr": rp, "depth_psnr": dp,
+            rows.append({"name": name, "rgb_bpp": rb, "depth_bpp": db, "rgb_psnr": rp, "depth_psnr": dp,
                          "enc_time": et, "dec_time": dt})
         self.logger_test.info(
             f"Epoch:[{self.epoch}] | Avg rBpp: {meters['avg_rgb_bpp'].avg:.7f} | Avg dBpp: {meters['avg_depth_bpp'].avg:.7f} | "
             f"Avg rPSNR: {meters['avg_rgb_psnr'].avg:.7f} | Avg dPSNR: {meters['avg_depth_psnr'].avg:.7f} | "
             f"Avg rMS-SSIM: {meters['avg_rgb_ms_ssim'].avg:.7f} | Avg dMS-SSIM: {meters['avg_depth_ms_ssim'].avg:.7f} | "
             f"Avg Encoding Latency: {meters['avg_encode_time'].avg:.6f} | Avg Decoding latency: {meters['avg_deocde_time'].avg:.6f}")
+        if workers > 1:
+            self.logger_test.info(f"Job throughput with {workers} images in flight: {self.job_mpx_per_s:.3f} Mpx/s (enc+dec+I/O)")
         return rows, meters
 
 

@@ -68,6 +68,46 @@ def test_tester_united_on_files(net, tmp_path, monkeypatch):
     assert d16.dtype == np.uint16 and d16.shape == (100, 150)
 
 
+def test_tester_united_images_in_flight(net, tmp_path, monkeypatch):
+    """test_model(workers=W): W images in flight on W engine instances write the same files and report the same bpp /
+    PSNR as the reference's one-image-at-a-time loop (tester_united.py:48-88)."""
+    from PIL import Image
+
+    import rgbd_amd
+    from rgbd_amd import synth
+
+    root = tmp_path / "nyu_test"
+    (root / "rgb").mkdir(parents=True)
+    (root / "depth").mkdir()
+    sizes = [(100, 150), (128, 128), (130, 70), (100, 150), (70, 200)]  # padded to >= 128: the ESA pooling needs it
+    for i, (h, w) in enumerate(sizes):
+        r, d = synth.synthetic_pair(i, h, w, config_id=6, smooth=True)
+        Image.fromarray((r.transpose(1, 2, 0) * 255).astype(np.uint8)).save(root / "rgb" / f"{i:04d}.png")
+        Image.fromarray((d[0] * 9000).astype(np.uint16)).save(root / "depth" / f"{i:04d}.png")
+    monkeypatch.chdir(tmp_path)
+    res = {}
+    for exp, workers in (("seq", 1), ("par", 3)):
+        args = types.SimpleNamespace(channel=4, debug=False, experiment=exp, dataset=str(root), model="ELIC_united",
+                                     quality="2_2", checkpoint=None)
+        t = rgbd_amd.TesterUnited(args, rgbd_amd.model_config(), net=net)
+        t.save_reconstructions = False
+        rows, meters = t.test_model(padding_mode="replicate0", padding=True, workers=workers)
+        rec_dir = t.get_rec_dir(padding=True, padding_mode="replicate0")
+        files = {}
+        for sub in ("depth_bin", "rgb_bin"):
+            for fn in sorted(os.listdir(os.path.join(rec_dir, sub))):
+                files[sub + "/" + fn] = open(os.path.join(rec_dir, sub, fn), "rb").read()
+        res[exp] = (rows, meters, files)
+        assert t.job_mpx_per_s > 0
+    (r0, m0, f0), (r1, m1, f1) = res["seq"], res["par"]
+    assert f0 == f1 and len(f0) == 2 * len(sizes)
+    for a, b in zip(r0, r1):
+        assert a["name"] == b["name"]
+        for k in ("rgb_bpp", "depth_bpp", "rgb_psnr", "depth_psnr"):
+            assert a[k] == b[k], (a["name"], k)
+    assert m0["avg_rgb_bpp"].avg == m1["avg_rgb_bpp"].avg and m0["avg_depth_psnr"].avg == m1["avg_depth_psnr"].avg
+
+
 def test_pool_matches_single_instance(net, synth_sd):
     import rgbd_amd
     from rgbd_amd import synth
