@@ -29,6 +29,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // double-buffered LDS image; the loads of stage s+1 are in flight under the MFMAs of stage s and one barrier per stage
 // both retires them (vmcnt) and frees the other buffer.  Out-of-image patch slots are zeroed with ordinary LDS stores.
 // Without DMA the stage is staged through registers (all loads issued back to back, then committed).
+// 1 / (1 + e^-x) with the hardware exp2 / rcp (1 ulp each): four instructions per value.  The libm expf and the IEEE
+// division expand to ~60 instructions per value, unrolled for every output slot of the epilogue -- together with GELU's
+// erff that was three quarters of the kernel's code (8150 -> 2100 instructions per instantiation).
+__device__ __forceinline__ float sigmoid_f32(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
 template <int WM, int WN, int MT, int NT, int KC, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
                                                          int taps_per_stage, int tab_f)
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 if (!ok[u]) continue;
                 const int cb = cbs[u];
                 f32x4 w = v[u];
-                if (a.splitk > 1) {  // raw partial sums; bias / activation / fused operands are applied by the reducer
+                if (a.partial) {  // raw partial sums; bias / activation / fused operands are applied by the reducer
                     *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + pixs[u]) * a.cout_pad + cb) = w;
                     continue;
                 }
@@ -360,11 +368,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                     for (int e = 0; e < 4; ++e) w[e] = w[e] > 0.f ? w[e] : w[e] * 0.01f;
                 } else if (a.act == ACT_SIGMOID) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = 1.0f / (1.0f + expf(-w[e]));
-                } else if (a.act == ACT_GELU) {  // nn.GELU (erf form)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = 0.5f * w[e] * (1.0f + erff(w[e] * 0.70710678118654752f));
-                }
+                    for (int e = 0; e < 4; ++e) w[e] = sigmoid_f32(w[e]);
+                }  // ACT_GELU never reaches this kernel's epilogue: launch_conv routes it through the reducer (the erff
+                   // expansion, unrolled for every output slot, used to be 2/3 of this kernel's code)
                 if (a.mul) w *= ml[u];
                 if (a.res2) w += r2[u];
                 *reinterpret_cast<f32x4*>(a.y + pixs[u] * a.ycs + cb) = w;
@@ -542,7 +548,7 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
         } else if (a.act == ACT_SIGMOID) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+            for (int e = 0; e < 4; ++e) v[e] = sigmoid_f32(v[e]);
         } else if (a.act == ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
@@ -615,9 +621,10 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
     if (a.splitk < 1) a.splitk = 1;
     if (a.splitk > a.cin_pad / 16) a.splitk = a.cin_pad / 16;
     if (a.splitk > 1 && !a.partial) return RGBD_EINVAL;
+    if (a.act == ACT_GELU && !a.partial) return RGBD_EINVAL;  // GELU is applied by the reducer: needs one partial plane
     if (a.ckbd && (a.ckbd > 2 || a.ckbd < 0 || a.nphase != 1 || a.IS != 1 || a.OS != 1)) return RGBD_EINVAL;
     const int rc = launch_conv_main(a, s);
-    if (rc || a.splitk == 1) return rc;
+    if (rc || !a.partial) return rc;
     const size_t total4 = (size_t)a.N * a.OH * a.OW * (a.cout_pad / 4);
     size_t g = (total4 + 255) / 256;
     if (g > 2048) g = 2048;

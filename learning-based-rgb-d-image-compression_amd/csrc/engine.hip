@@ -420,7 +420,9 @@ struct rgbd_elic {
                 break;
             }
         const size_t pmark = arena.top;
-        if (a.splitk > 1) a.partial = (float*)arena.take((size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float));
+        // split-K partial planes; a GELU layer (STF_united's MLP) also goes through the reducer, with a single plane
+        if (a.splitk > 1 || a.act == ACT_GELU)
+            a.partial = (float*)arena.take((size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) {
             if (ev_used + 2 > ev_pool.size()) {

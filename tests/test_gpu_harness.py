@@ -59,7 +59,7 @@ def test_tester_united_on_files(net, tmp_path, monkeypatch):
     xr, xd, _ = t.decompress_one_image_united((os.path.join(rec_dir, "depth_bin"), os.path.join(rec_dir, "rgb_bin")),
                                               name[0], mode="replicate0")
     assert torch.equal(xr, rec["x_hat"]["r"][:, :, :100, :150]) and torch.equal(xd, rec["x_hat"]["d"][:, :, :100, :150])
-    assert abs(eo.psnr(xr.cpu(), rgb) - rows[0]["rgb_psnr"]) < 1e-9
+    assert abs(eo.psnr(xr.cpu(), rgb) - rows[0]["rgb_psnr"]) < 1e-5  # same pixels; fp32 mean on the GPU vs on the CPU
     assert abs(meters["avg_rgb_bpp"].avg - np.mean([r["rgb_bpp"] for r in rows])) < 1e-12
     # reconstructions are written like the reference does (8-bit PNGs + 16-bit depth)
     recs = sorted(os.listdir(os.path.join(rec_dir, "depth_rec")))
