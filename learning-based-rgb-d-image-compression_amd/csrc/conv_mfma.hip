@@ -312,6 +312,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     // therefore staged through LDS as [pixel][cout] and written back by all 256 threads with consecutive lanes on
     // consecutive couts of the same pixel (full lines for TM >= 32 couts), which is also how the fused
     // residual / gate / skip operands are read.
+    const size_t img_px = (size_t)n * a.OH * a.OW;  // wave-uniform per-image bases (byte pointers)
+    char* yn = reinterpret_cast<char*>(a.y + img_px * a.ycs);
+    const char* r1n = reinterpret_cast<const char*>(a.res1 + img_px * a.r1cs);
+    const char* mln = reinterpret_cast<const char*>(a.mul + img_px * a.mcs);
+    const char* r2n = reinterpret_cast<const char*>(a.res2 + img_px * a.r2cs);
+    char* ptn = reinterpret_cast<char*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + img_px) * a.cout_pad);
     for (int ip = 0; ip < MT; ip += EMT) {
         __syncthreads();  // LDS is free: the last stage (or the previous pass) has been consumed
 #pragma unroll
@@ -329,8 +335,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         static_assert(TP * S4 % 256 == 0, "epilogue tiling");
         for (int u0 = 0; u0 < EU; u0 += UB) {
             f32x4 r1[UB], ml[UB], r2[UB], v[UB];
-            size_t pixs[UB];
-            int cbs[UB];
+            unsigned pixs[UB];  // pixel index inside image n: every operand is addressed as a wave-uniform per-image
+            int cbs[UB];        // base + a 32-bit byte offset (no 64-bit VALU multiplies per slot)
             bool ok[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -342,12 +348,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 const int gx = tx0 + (ck ? 2 * (p & (TW - 1)) + ((gy & 1) ^ (a.ckbd == 1 ? 1 : 0)) : (p & (TW - 1)));
                 ok[u] = ip + ii < MT && cb < a.cout_store && gy < a.GH && gx < a.GW;
                 cbs[u] = cb;
-                pixs[u] = ((size_t)n * a.OH + (gy * a.OS + oy_off)) * a.OW + (gx * a.OS + ox_off);
+                pixs[u] = (unsigned)((gy * a.OS + oy_off) * a.OW + (gx * a.OS + ox_off));
                 v[u] = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                r1[u] = (ok[u] && a.res1) ? *reinterpret_cast<const f32x4*>(a.res1 + pixs[u] * a.r1cs + cb) : z;
-                ml[u] = (ok[u] && a.mul) ? *reinterpret_cast<const f32x4*>(a.mul + pixs[u] * a.mcs + cb) : z;
-                r2[u] = (ok[u] && a.res2) ? *reinterpret_cast<const f32x4*>(a.res2 + pixs[u] * a.r2cs + cb) : z;
+                r1[u] = (ok[u] && a.res1) ? *reinterpret_cast<const f32x4*>(r1n + (size_t)((pixs[u] * (unsigned)a.r1cs + cb) * 4u)) : z;
+                ml[u] = (ok[u] && a.mul) ? *reinterpret_cast<const f32x4*>(mln + (size_t)((pixs[u] * (unsigned)a.mcs + cb) * 4u)) : z;
+                r2[u] = (ok[u] && a.res2) ? *reinterpret_cast<const f32x4*>(r2n + (size_t)((pixs[u] * (unsigned)a.r2cs + cb) * 4u)) : z;
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                 const int cb = cbs[u];
                 f32x4 w = v[u];
                 if (a.partial) {  // raw partial sums; bias / activation / fused operands are applied by the reducer
-                    *reinterpret_cast<f32x4*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + pixs[u]) * a.cout_pad + cb) = w;
+                    *reinterpret_cast<f32x4*>(ptn + (size_t)((pixs[u] * (unsigned)a.cout_pad + cb) * 4u)) = w;
                     continue;
                 }
                 w += *reinterpret_cast<const f32x4*>(a.bias + cb);
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
                    // expansion, unrolled for every output slot, used to be 2/3 of this kernel's code)
                 if (a.mul) w *= ml[u];
                 if (a.res2) w += r2[u];
-                *reinterpret_cast<f32x4*>(a.y + pixs[u] * a.ycs + cb) = w;
+                *reinterpret_cast<f32x4*>(yn + (size_t)((pixs[u] * (unsigned)a.ycs + cb) * 4u)) = w;
             }
         }
     }
