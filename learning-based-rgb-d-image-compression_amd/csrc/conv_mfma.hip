@@ -676,6 +676,9 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     if (debug)
         fprintf(stderr, "[conv] N=%d GH=%d GW=%d cin=%d cout=%d taps=%d IS=%d nph=%d -> WM=%d MT=%d NT=%d KC=%d tw=%d dma=%d\n", a.N,
                 a.GH, a.GW, a.cin_pad, a.cout_pad, a.taps.n[0], a.IS, a.nphase, c.wm, c.mt, c.nt, c.kc, 1 << c.tw_log2, (int)c.dma);
+    // 256-pixel tiles (half the weight staging per MFMA, one round of workgroups on the 128x128 maps): reached through
+    // measured table entries only, the cost model does not propose them
+    RGBD_CASE(2, 2, 3, 8) RGBD_CASE(2, 2, 2, 8) RGBD_CASE(2, 2, 1, 8) RGBD_CASE(1, 4, 3, 4) RGBD_CASE(1, 4, 2, 4) RGBD_CASE(1, 4, 1, 4)
     RGBD_CASE(2, 2, 5, 4) RGBD_CASE(2, 2, 4, 4) RGBD_CASE(2, 2, 3, 4) RGBD_CASE(2, 2, 2, 4) RGBD_CASE(2, 2, 1, 4)
     RGBD_CASE(2, 2, 5, 2) RGBD_CASE(2, 2, 4, 2) RGBD_CASE(2, 2, 3, 2) RGBD_CASE(2, 2, 2, 2) RGBD_CASE(2, 2, 1, 2)
     RGBD_CASE(2, 2, 5, 1) RGBD_CASE(2, 2, 4, 1) RGBD_CASE(2, 2, 3, 1) RGBD_CASE(2, 2, 2, 1) RGBD_CASE(2, 2, 1, 1)

@@ -17,7 +17,8 @@ S = [("ep 1x1 1280->213", 1280, 213, 1), ("ep 1x1 1664->277", 1664, 277, 1), ("e
      ("chctx 5x5 128->224", 128, 224, 5), ("chctx 5x5 224->128", 224, 128, 5), ("chctx 5x5 128->384", 128, 384, 5),
      ("locctx 5x5 192->384", 192, 384, 5), ("locctx 5x5 64->128", 64, 128, 5), ("attn 3x3 160->160", 160, 160, 3),
      ("attn 1x1 320->160", 320, 160, 1), ("attn 1x1 160->320", 160, 320, 1)]
-TILES = [(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)] + [(1, m, n) for n in (2, 1) for m in (3, 2, 1)]
+TILES = ([(2, m, 8) for m in (3, 2, 1)] + [(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)] +
+         [(1, m, n) for n in (4, 2, 1) for m in (3, 2, 1)])
 
 
 def run(cin, cout, k, iters=4):

@@ -38,7 +38,8 @@ net.update(force=True)
 net = net.to("cuda")
 net.per_image_streams = True
 
-TILES = [(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)] + [(1, m, n) for n in (2, 1) for m in (3, 2, 1)]
+TILES = ([(2, m, 8) for m in (3, 2, 1)] + [(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)] +
+         [(1, m, n) for n in (4, 2, 1) for m in (3, 2, 1)])
 MODES = ((16, 1), (16, 0), (64, 0))
 
 
