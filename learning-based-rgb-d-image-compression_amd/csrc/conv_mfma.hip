@@ -460,7 +460,7 @@ Choice choose(const ConvArgs& a)
     // each workgroup pulls from L2 (its weight slab K*TM plus the input patch per channel chunk).  Multi-tap layers on
     // small feature maps are weight-traffic bound, so narrow cout tiles x wide pixel tiles win there; big feature maps
     // pick the large square-ish tiles.  The choice never changes results: every output keeps its fma chain.
-    static const int cand[][3] = {{2, 5, 4}, {2, 4, 4}, {2, 3, 4}, {2, 2, 4}, {2, 1, 4}, {2, 5, 2}, {2, 4, 2},
+    static const int cand[][3] = {{2, 3, 8}, {2, 2, 8}, {2, 5, 4}, {2, 4, 4}, {2, 3, 4}, {2, 2, 4}, {2, 1, 4}, {2, 5, 2}, {2, 4, 2},
                                   {2, 3, 2}, {2, 2, 2}, {2, 1, 2}, {2, 5, 1}, {2, 4, 1}, {2, 3, 1}, {2, 2, 1},
                                   {2, 1, 1}, {1, 3, 2}, {1, 2, 2}, {1, 1, 2}, {1, 3, 1}, {1, 2, 1}, {1, 1, 1}};
     int max_taps = 1;
@@ -486,7 +486,9 @@ Choice choose(const ConvArgs& a)
         const double mfma = (double)mt * nt * (K / 4.0) * 32.0 / ilp + 3000.0;      // cycles per workgroup (+ prologue)
         const double load = (K * tm * 4.0 + (double)PH * PW * a.cin_pad * 4.0) / 12.0;  // ~12 B/clk/CU from L2
         const long nb = (blocks + 255) / 256;
-        const double cost = nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load);
+        double cost = nb >= 2 ? nb * (mfma > load ? mfma : load) * (blocks < 512 ? 1.15 : 1.0) : (mfma + load);
+        // 256-pixel tiles stage half the weights per MFMA: measured +5-8 % once they still fill every CU twice, a loss below
+        if (nt == 8) cost *= blocks >= 512 ? 0.93 : 1.25;
         if (best_cost < 0 || cost < best_cost * 0.999) {
             best_cost = cost;
             best = Choice{wm, mt, nt, 16, twl, false};
