@@ -588,11 +588,20 @@ static const TunedTile* tuned_lookup(const ConvArgs& a)
     static const bool off = getenv("RGBD_NO_TILE_TABLE") != nullptr;
     if (off) return nullptr;
     const int stride = a.nphase > 1 ? a.OS : a.IS;
-    for (const TunedTile* t = kTuned; t->N; ++t)
-        if (t->N == a.N && t->H == a.H && t->W == a.W && t->cin_pad == a.cin_pad && t->cout_pad == a.cout_pad &&
-            t->ntaps == a.ntaps_total && t->stride == stride && t->nphase == a.nphase + 10 * a.ckbd && t->splitk == a.splitk)
-            return t;
-    return nullptr;
+    // exact batch size first.  A batch size that was never measured on this map (no entry of any layer has it) takes the
+    // entry of the same layer whose batch size is closest -- the winner depends on N only through the number of tiles,
+    // so a neighbour beats the cost model; for a measured batch size a missing entry means the cost model's pick won.
+    const TunedTile* near = nullptr;
+    bool measured = false;
+    for (const TunedTile* t = kTuned; t->N; ++t) {
+        if (t->H == a.H && t->W == a.W && t->N == a.N) measured = true;
+        if (t->H != a.H || t->W != a.W || t->cin_pad != a.cin_pad || t->cout_pad != a.cout_pad || t->ntaps != a.ntaps_total ||
+            t->stride != stride || t->nphase != a.nphase + 10 * a.ckbd || t->splitk != a.splitk)
+            continue;
+        if (t->N == a.N) return t;
+        if (!near || abs(t->N - a.N) < abs(near->N - a.N)) near = t;
+    }
+    return measured ? nullptr : near;
 }
 
 // shape log for the tuner (rgbd_debug_conv_log): key -> launches
