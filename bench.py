@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per engine instance (the HIP default of 4 makes streams share queues, and a long serial coder
 # kernel then blocks another instance's convolutions); must be set before the HIP runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+_USER_QUEUES = "GPU_MAX_HW_QUEUES" in os.environ
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # refined in main() once --workers is known (still before HIP starts)
 
 WORKLOADS = {
     # name: (batch per GPU, H, W, synthetic config id, model)
@@ -65,8 +66,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workers", type=int, default=16, help="engine instances (HIP streams) per GPU; 1 = no overlap")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="engine instances (HIP streams) per GPU; 1 = no overlap; default 16 (24 for the one-pair-per-step "
+                         "STF_united workload, whose steps are almost all serial coder chain)")
     args = ap.parse_args()
+    if args.workers <= 0:
+        args.workers = 24 if args.workload == "c5_stf_1x512x512" else 16
+    if not _USER_QUEUES:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))
 
     import torch
 
