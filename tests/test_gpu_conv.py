@@ -158,3 +158,45 @@ def test_conv_checkerboard_output(k, cin, cout, h, w, split):
     finally:
         lib().rgbd_debug_force_ckbd(0)
         lib().rgbd_debug_force_splitk(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", ["2,3,8,16,1", "2,2,8,16,0", "1,3,4,16,1", "2,5,4,16,0", "1,1,1,16,1", "2,3,4,64,0"])
+def test_tile_choice_never_changes_a_bit(tile):
+    """The determinism contract behind the tile table / cost model: every tile shape, stage depth and
+    staging mode produces the same fp32 bits, so tile selection is a pure speed matter (256-pixel tiles included)."""
+    dev = require_gpu()
+    from rgbd_amd._lib import check, lib
+
+    f32p = ctypes.POINTER(ctypes.c_float)
+    shapes = [(2, 96, 32, 48, 96, 3, 1, 1, 0), (1, 192, 40, 24, 96, 1, 1, 0, 0), (1, 64, 16, 24, 96, 5, 2, 2, 1),
+              (1, 64, 33, 47, 80, 3, 1, 1, 0)]
+    launched = 0
+    for n, cin, h, w, cout, k, s, p, tr in shapes:
+        g = torch.Generator().manual_seed(n + cin + h + w + cout)
+        x = torch.randn(n, cin, h, w, generator=g).to(dev)
+        wt = (torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) / (k * cin ** 0.5)).contiguous()
+        b = torch.randn(cout, generator=g)
+        oh = (h - 1) * s - 2 * p + k + (s - 1) if tr else (h + 2 * p - k) // s + 1
+        ow = (w - 1) * s - 2 * p + k + (s - 1) if tr else (w + 2 * p - k) // s + 1
+
+        def run():
+            y = torch.empty((n, cout, oh, ow), device=dev)
+            rc = lib().rgbd_conv2d_nchw(ctypes.c_void_p(x.data_ptr()), n, cin, h, w, wt.numpy().ctypes.data_as(f32p),
+                                        b.numpy().ctypes.data_as(f32p), cout, k, s, p, tr, 1, None,
+                                        ctypes.c_void_p(y.data_ptr()), None)
+            return rc, y.cpu()
+
+        rc0, y0 = run()
+        check(rc0, "conv2d")
+        lib().rgbd_debug_force_tile(tile.encode())
+        try:
+            rc1, y1 = run()
+        finally:
+            lib().rgbd_debug_force_tile(b"")
+        if rc1 == -28:  # this tile cannot hold the layer's patch / taps: the launcher refuses it, nothing to compare
+            continue
+        check(rc1, "conv2d (forced tile)")
+        assert torch.equal(y0, y1), (tile, (n, cin, h, w, cout, k, s, p, tr))
+        launched += 1
+    assert launched >= 1  # (a 64-channel stage only exists for layers whose taps all fit one stage)
