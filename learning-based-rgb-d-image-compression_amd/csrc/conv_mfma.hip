@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -638,6 +639,14 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
     if (a.splitk < 1) a.splitk = 1;
     if (a.splitk > a.cin_pad / 16) a.splitk = a.cin_pad / 16;
     if (a.splitk > 1 && !a.partial) return RGBD_EINVAL;
+    {   // the kernels address one image's input / output / fused operands with 32-bit byte offsets from a per-image base
+        const size_t lim = (size_t)1 << 32;
+        const size_t opx = (size_t)a.OH * a.OW * 4;
+        const int ocs = std::max(std::max(a.ycs, a.cout_pad), std::max(a.r1cs, std::max(a.mcs, a.r2cs)));
+        if ((size_t)a.H * a.W * a.xcs * 4 >= lim || opx * ocs >= lim ||
+            (size_t)a.cout_pad * a.ntaps_total * a.cin_pad * 4 >= lim)
+            return RGBD_EINVAL;
+    }
     if (a.act == ACT_GELU && !a.partial) return RGBD_EINVAL;  // GELU is applied by the reducer: needs one partial plane
     if (a.ckbd && (a.ckbd > 2 || a.ckbd < 0 || a.nphase != 1 || a.IS != 1 || a.OS != 1)) return RGBD_EINVAL;
     const int rc = launch_conv_main(a, s);
