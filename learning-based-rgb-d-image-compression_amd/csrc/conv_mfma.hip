@@ -391,8 +391,9 @@ namespace {
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
 template <int WM, int WN, int MT, int NT, int KC, bool DMA>
-int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
+int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
 {
+    const long budget = lds_cap > 0 ? lds_cap : LDS_BUDGET;
     constexpr int TM = 16 * MT * WM;
     constexpr int TP = 16 * NT * WN;
     constexpr int RS = KC > 16 ? KC + 4 : KC;
@@ -408,7 +409,7 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s)
     if ((long)PH * PW * (KC / 4) > PR * 256) return RGBD_ENOSPC;  // patch registers
     long room = (8 * 256) / ((long)TM * (KC / 4));               // weight slots per stage (WR)
     if (DMA) {
-        const long lds_room = ((long)LDS_BUDGET - 2 * (long)patch_bytes) / (2 * (long)tap_bytes);
+        const long lds_room = (budget - 2 * (long)patch_bytes) / (2 * (long)tap_bytes);
         room = room < lds_room ? room : lds_room;
     }
     if (room < 1) return RGBD_ENOSPC;
@@ -453,6 +454,7 @@ int pick_tw_log2(int GW, int GH, int TP)
 struct Choice {
     int wm, mt, nt, kc, tw_log2;
     bool dma;
+    int lds_cap = 0;  // 0: LDS_BUDGET (two workgroups per CU); else a smaller cap (three per CU: 52 KiB)
 };
 
 Choice choose(const ConvArgs& a)
@@ -527,7 +529,7 @@ Choice choose(const ConvArgs& a)
 #define RGBD_CASE(WM_, WN_, MT_, NT_)                                              \
     if (c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                                 \
         return c.kc == 64 ? launch_cfg<WM_, WN_, MT_, NT_, 64, false>(a, c.tw_log2, s)            \
-                          : (c.dma ? launch_cfg<WM_, WN_, MT_, NT_, 16, true>(a, c.tw_log2, s)    \
+                          : (c.dma ? launch_cfg<WM_, WN_, MT_, NT_, 16, true>(a, c.tw_log2, s, c.lds_cap)    \
                                    : launch_cfg<WM_, WN_, MT_, NT_, 16, false>(a, c.tw_log2, s));
 
 }  // namespace
@@ -671,6 +673,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.nt = t->nt;
         c.kc = t->kc;
         c.dma = t->dma != 0;
+        c.lds_cap = t->dma == 2 ? 52 * 1024 : 0;
         c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * t->nt * (t->wm == 2 ? 2 : 4));
     }
     if (g_log_on) {
@@ -690,6 +693,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.nt = nt;
         c.kc = kc;
         c.dma = dm != 0 && kc == 16;
+        c.lds_cap = dm == 2 ? 52 * 1024 : 0;
         c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
     }
     static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;
