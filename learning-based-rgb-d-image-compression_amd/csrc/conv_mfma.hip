@@ -454,7 +454,7 @@ int pick_tw_log2(int GW, int GH, int TP)
 struct Choice {
     int wm, mt, nt, kc, tw_log2;
     bool dma;
-    int lds_cap = 0;  // 0: LDS_BUDGET (two workgroups per CU); else a smaller cap (three per CU: 52 KiB)
+    int lds_cap = 0;  // 0: LDS_BUDGET (two workgroups per CU); else a smaller cap (52 KiB: three per CU, 38 KiB: four)
 };
 
 Choice choose(const ConvArgs& a)
@@ -673,7 +673,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.nt = t->nt;
         c.kc = t->kc;
         c.dma = t->dma != 0;
-        c.lds_cap = t->dma == 2 ? 52 * 1024 : 0;
+        c.lds_cap = t->dma == 2 ? 52 * 1024 : (t->dma == 3 ? 38 * 1024 : 0);
         c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * t->nt * (t->wm == 2 ? 2 : 4));
     }
     if (g_log_on) {
@@ -693,7 +693,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.nt = nt;
         c.kc = kc;
         c.dma = dm != 0 && kc == 16;
-        c.lds_cap = dm == 2 ? 52 * 1024 : 0;
+        c.lds_cap = dm == 2 ? 52 * 1024 : (dm == 3 ? 38 * 1024 : 0);
         c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
     }
     static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;

@@ -172,6 +172,6 @@ def test_tile_table_is_well_formed():
         key, (wm, mt, nt, kc, dma) = tuple(v[:9]), v[9:]
         assert key not in keys, ln
         keys.add(key)
-        assert (wm, mt, nt) in tiles and kc in (16, 64) and dma in (0, 1, 2) and not (dma and kc == 64), ln
+        assert (wm, mt, nt) in tiles and kc in (16, 64) and dma in (0, 1, 2, 3) and not (dma and kc == 64), ln
         assert all(x > 0 for x in key) and key[3] % 16 == 0 and key[4] % 16 == 0 and key[7] in (1, 4, 11, 21), ln  # 11 / 21: checkerboard-output launches (nphase + 10 * ckbd)
     assert keys
