@@ -66,12 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workers", type=int, default=0,
-                    help="engine instances (HIP streams) per GPU; 1 = no overlap; default 16 (24 for the one-pair-per-step "
-                         "STF_united workload, whose steps are almost all serial coder chain)")
+    ap.add_argument("--workers", type=int, default=16, help="engine instances (HIP streams) per GPU; 1 = no overlap")
     args = ap.parse_args()
-    if args.workers <= 0:
-        args.workers = 24 if args.workload == "c5_stf_1x512x512" else 16
     if not _USER_QUEUES:
         os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))
 
