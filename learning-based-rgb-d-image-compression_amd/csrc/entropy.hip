@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                                                           uint64_t* __restrict__ state, int init,
                                                           const int32_t* __restrict__ idx, int32_t* __restrict__ sym,
                                                           const int64_t* __restrict__ sym_base, int64_t part_off,
-                                                          int64_t count, DevTables t)
+                                                          int64_t count, DevTables t, int nstreams)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int lut_n = (1 << t.lut_bits) + 1;
@@ -601,8 +601,10 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     // the pad has found the row's last (= escape) slot.  Row r starts at row_off[r] + 64 * r.
     uint16_t* cm = reinterpret_cast<uint16_t*>(rowinfo + ((t.nrows + 1) & ~1));           // [t.total + 64 * nrows]
 
-    const int s = blockIdx.x;
+    // Four streams per workgroup, one per wavefront (each on its own SIMD): the ~125 KB of tables in LDS are shared, so a
+    // decode launch of 16 streams holds 4 CUs' LDS instead of 16 (a conv workgroup cannot co-reside with these tables).
     const int tid = threadIdx.x;
+    const int s = blockIdx.x * 4 + (tid >> 6);
     {
         const int ncm16 = ((t.total + 64 * t.nrows) * 2 + 15) / 16;  // both images are padded to 16 bytes
         const uint4* gcm = reinterpret_cast<const uint4*>(t.cm);
@@ -615,8 +617,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         rowinfo[i] = make_uint2((uint32_t)(t.row_off[i] + 64 * i) | ((uint32_t)t.sizes[i] << 16),
                                 (uint32_t)t.offsets[i] & 0xFFFFu);
     __syncthreads();
-    if (tid >= 64) return;
-    const int lane = tid;
+    if (s >= nstreams) return;
+    const int lane = tid & 63;
 
     const uint32_t* st = streams + stream_off[s];
     const int64_t nwords = stream_len[s];
@@ -985,8 +987,8 @@ int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    hipLaunchKernelGGL(rans_decode_kernel, dim3(nstreams), dim3(256), lds, s, streams, stream_off_words, stream_len_words,
-                       state, init, idx, sym, sym_base, part_off, count, t);
+    hipLaunchKernelGGL(rans_decode_kernel, dim3((nstreams + 3) / 4), dim3(256), lds, s, streams, stream_off_words,
+                       stream_len_words, state, init, idx, sym, sym_base, part_off, count, t, nstreams);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
