@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--workload", default="c2_8x256x256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workers", type=int, default=16, help="engine instances (HIP streams) per GPU; 1 = no overlap")
+    ap.add_argument("--tile-mode", default="auto", choices=["auto", "latency", "throughput"],
+                    help="conv tile tables: auto = throughput tiles when >= 4 engine instances share the GPU (CodecPool's rule)")
     args = ap.parse_args()
     if not _USER_QUEUES:
         os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))
@@ -89,6 +91,11 @@ def main():
     # phases with another group's convolutions
     net = CodecPool(sd, config=rgbd_amd.model_config(), workers=args.workers, device=dev, per_image_streams=True,
                     model_cls=rgbd_amd.modelZoo[model])
+
+    if args.tile_mode != "auto":
+        for n_ in net.nets:
+            n_.set_tile_mode(args.tile_mode)
+    tile_mode = args.tile_mode if args.tile_mode != "auto" else ("throughput" if args.workers >= 4 else "latency")
 
     r, d = synth.synthetic_batch(B, H, W, config_id=cid, start=rank * B)
     rgb, depth = torch.from_numpy(r).to(dev), torch.from_numpy(d).to(dev)
@@ -156,7 +163,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)" if model == "ELIC_united" else "STF_united ch4 (N=192,M=384)", "images_per_gpu": B,
                        "image": [H, W], "padded": [H + ph, W + pw], "weights": "synthetic seed 0 (stress recipe)",
-                       "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers},
+                       "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers,
+                       "conv_tiles": tile_mode},
             # `achieved`: conv FLOPs of the timed steps / wall time of the timed region -- with several engine instances
             # sharing the chip a per-launch event bracket also contains the time the launch spends sharing CUs with other
             # instances' kernels, so the per-launch figures are reported twice: as measured inside the timed region

@@ -174,6 +174,12 @@ int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, in
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
 int rgbd_debug_force_splitk(int32_t s);
+/* Convolution tile tables: mode 0 (default) = the winners of isolated launches (lowest latency of one compress / decompress),
+ * mode 1 = the winners with the chip shared between several engine instances (highest job throughput; CodecPool sets it).
+ * Results are bit-identical in both modes -- tile choice never changes an output. */
+int rgbd_elic_set_tile_mode(rgbd_elic* m, int32_t mode);
+int rgbd_debug_bench_streams(int32_t n); /* rgbd_conv_bench: issue every launch on n streams at once (1 = isolated) and
+                                            report the time per launch -- the cost of a launch on a shared chip */
 int rgbd_debug_force_ckbd(int32_t part); /* rgbd_conv2d_nchw / rgbd_conv_bench: 0 = all outputs, 1 = anchor positions only
                                            ((row + col) odd, utils/ckbd.py:37-48), 2 = non-anchor only; the rest reads 0 */
 int rgbd_debug_conv_log(int32_t on);                      /* record the shape of every conv launch (tools/tune_tiles.py) */

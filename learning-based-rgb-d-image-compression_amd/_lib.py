@@ -29,7 +29,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into librgbd_amd.so (in-tree, next to this file)."""
     csrc = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in _SRCS]
-    deps = srcs + [os.path.join(csrc, "common.h"), os.path.join(csrc, "tile_table.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
+    deps = srcs + [os.path.join(csrc, "common.h"), os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -91,6 +91,8 @@ def lib():
         "rgbd_elic_set_profile": (ctypes.c_int, [c_vp, c_i32]),
         "rgbd_debug_force_splitk": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_ckbd": (ctypes.c_int, [c_i32]),
+        "rgbd_debug_bench_streams": (ctypes.c_int, [c_i32]),
+        "rgbd_elic_set_tile_mode": (ctypes.c_int, [ctypes.c_void_p, c_i32]),
         "rgbd_debug_force_tile": (ctypes.c_int, [ctypes.c_char_p]),
         "rgbd_debug_conv_log": (ctypes.c_int, [c_i32]),
         "rgbd_debug_conv_log_read": (c_i64, [ctypes.c_char_p, c_i64]),
@@ -113,5 +115,5 @@ EXPORTS = ["rgbd_abi_version", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create"
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_profile",
-           "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_ckbd", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
+           "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_ckbd", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]

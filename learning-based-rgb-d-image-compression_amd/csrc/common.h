@@ -65,6 +65,7 @@ struct ConvArgs {
     int r2cs;
     int splitk;      // >1: reduce the input channels in `splitk` fixed ranges (partials + ordered sum); 0/1 = off
     float* partial;  // [splitk][N*OH*OW][cout_pad] scratch when splitk > 1
+    int loaded;      // tile-table flavour: 0 = winners of isolated launches (latency), 1 = winners with the chip shared (throughput)
     int ckbd;        // checkerboard output: 0 = every position, 1 = anchor positions only ((row + col) odd, ckbd.py:37-48),
                      // 2 = non-anchor positions only; the other half of y is left untouched (stride-1, single-phase convs)
     TapTable taps;

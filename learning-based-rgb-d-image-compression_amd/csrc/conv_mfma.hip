@@ -585,26 +585,42 @@ struct TunedTile {
 static const TunedTile kTuned[] = {
 #include "tile_table.h"
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+// the same shapes timed with 8 copies of the launch in flight (tools/tune_tiles.py --streams 8): what a launch costs in CU
+// time on a shared chip.  Engine instances of a pool use it (ConvArgs::loaded); the winners are larger tiles / fewer
+// workgroups than the isolated-launch winners (+2.7 % job throughput on c2, but 15 % slower launches on an idle chip).
+static const TunedTile kTunedLoaded[] = {
+#include "tile_table_loaded.h"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
-static const TunedTile* tuned_lookup(const ConvArgs& a)
+// *measured: some entry of the table has this map size and batch size, i.e. a miss means "the cost model's pick won"
+static const TunedTile* table_lookup(const TunedTile* table, const ConvArgs& a, bool* measured)
 {
-    static const bool off = getenv("RGBD_NO_TILE_TABLE") != nullptr;
-    if (off) return nullptr;
     const int stride = a.nphase > 1 ? a.OS : a.IS;
-    // exact batch size first.  A batch size that was never measured on this map (no entry of any layer has it) takes the
-    // entry of the same layer whose batch size is closest -- the winner depends on N only through the number of tiles,
-    // so a neighbour beats the cost model; for a measured batch size a missing entry means the cost model's pick won.
     const TunedTile* near = nullptr;
-    bool measured = false;
-    for (const TunedTile* t = kTuned; t->N; ++t) {
-        if (t->H == a.H && t->W == a.W && t->N == a.N) measured = true;
+    *measured = false;
+    for (const TunedTile* t = table; t->N; ++t) {
+        if (t->H == a.H && t->W == a.W && t->N == a.N) *measured = true;
         if (t->H != a.H || t->W != a.W || t->cin_pad != a.cin_pad || t->cout_pad != a.cout_pad || t->ntaps != a.ntaps_total ||
             t->stride != stride || t->nphase != a.nphase + 10 * a.ckbd || t->splitk != a.splitk)
             continue;
         if (t->N == a.N) return t;
         if (!near || abs(t->N - a.N) < abs(near->N - a.N)) near = t;
     }
-    return measured ? nullptr : near;
+    // A batch size that was never measured on this map takes the entry of the same layer whose batch size is closest --
+    // the winner depends on N only through the number of tiles, so a neighbour beats the cost model.
+    return *measured ? nullptr : near;
+}
+
+static const TunedTile* tuned_lookup(const ConvArgs& a)
+{
+    static const bool off = getenv("RGBD_NO_TILE_TABLE") != nullptr;
+    if (off) return nullptr;
+    bool measured = false;
+    if (a.loaded) {  // throughput flavour first; maps it never saw fall back to the isolated-launch table
+        const TunedTile* t = table_lookup(kTunedLoaded, a, &measured);
+        if (t || measured) return t;
+    }
+    return table_lookup(kTuned, a, &measured);
 }
 
 // shape log for the tuner (rgbd_debug_conv_log): key -> launches

@@ -228,6 +228,7 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
 }
 
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
+int g_bench_streams = 1;  // rgbd_debug_bench_streams: rgbd_conv_bench issues every launch on this many streams at once
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
 const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
 
@@ -264,6 +265,7 @@ struct rgbd_tables {
 
 struct rgbd_elic {
     int N = 192, M = 320;
+    int tile_mode = 0;  // rgbd_elic_set_tile_mode: 0 latency tiles (isolated launches), 1 throughput tiles (shared chip)
     int variant = 0;  // 0: ELIC_united (RGB + depth), 1: single-modal ELIC (models/elic.py)
     int in_ch = 3;    // image channels of the single-modal variant
     std::vector<int> slice_ch;
@@ -395,6 +397,7 @@ struct rgbd_elic {
         a.GW = pc->transposed ? x.w : OW;
         a.act = ep.act;
         a.ckbd = ep.ckbd;
+        a.loaded = tile_mode;
         if (ep.res1) {
             a.res1 = ep.res1->p;
             a.r1cs = ep.res1->cs;
@@ -2175,6 +2178,20 @@ int rgbd_debug_force_tile(const char* cfg)
 int rgbd_debug_conv_log(int32_t on) { return conv_log_enable(on); }
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap) { return conv_log_read(buf, (long)cap); }
 
+int rgbd_elic_set_tile_mode(rgbd_elic* m, int32_t mode)
+{
+    if (!m || mode < 0 || mode > 1) return RGBD_EINVAL;
+    m->tile_mode = mode;
+    return RGBD_OK;
+}
+
+int rgbd_debug_bench_streams(int32_t n)
+{
+    if (n < 1 || n > 32) return RGBD_EINVAL;
+    g_bench_streams = n;
+    return RGBD_OK;
+}
+
 int rgbd_debug_force_ckbd(int32_t part)
 {
     if (part < 0 || part > 2) return RGBD_EINVAL;
@@ -2251,18 +2268,47 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
         }
     }
     a.ckbd = g_force_ckbd;
+    a.loaded = g_bench_streams > 1 ? 1 : 0;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     rc = launch_conv(a, nullptr);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(a, nullptr);
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *ms_out = ms / iters;
+    if (g_bench_streams <= 1) {
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(a, nullptr);
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / iters;
+    } else {
+        // loaded mode (rgbd_debug_bench_streams): the same launch on S streams at once -- what a launch costs in CU time
+        // when the chip is shared with other engine instances, the regime the job throughput is measured in
+        const int S = g_bench_streams;
+        std::vector<hipStream_t> st(S);
+        std::vector<hipEvent_t> done(S);
+        for (int k = 0; k < S; ++k) {
+            HIP_TRY(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        for (int k = 0; k < S; ++k) HIP_TRY(hipStreamWaitEvent(st[k], e0, 0));
+        for (int i = 0; i < iters && !rc; ++i)
+            for (int k = 0; k < S && !rc; ++k) rc = launch_conv(a, st[k]);
+        for (int k = 0; k < S; ++k) {
+            HIP_TRY(hipEventRecord(done[k], st[k]));
+            HIP_TRY(hipStreamWaitEvent(nullptr, done[k], 0));
+        }
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms / (iters * S);
+        for (int k = 0; k < S; ++k) {
+            (void)hipEventDestroy(done[k]);
+            (void)hipStreamDestroy(st[k]);
+        }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(x);

@@ -365,6 +365,13 @@ class ELIC_united:
         other._dirty = False
         return other
 
+    def set_tile_mode(self, mode: str):
+        """Convolution tile tables: "latency" (default; winners of isolated launches) or "throughput" (winners with the
+        chip shared between several engine instances -- what `CodecPool` / `test_model(workers > 1)` select).  The outputs
+        are bit-identical in both modes."""
+        self._ready()
+        check(lib().rgbd_elic_set_tile_mode(self._h, {"latency": 0, "throughput": 1}[mode]), "set_tile_mode")
+
     def set_profile(self, on: bool):
         check(lib().rgbd_elic_set_profile(self._h, 1 if on else 0), "set_profile")
 

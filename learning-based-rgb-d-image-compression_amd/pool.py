@@ -31,6 +31,8 @@ class CodecPool:
             else:
                 net = self.nets[0].clone_shared()  # same packed weights in HBM, own workspace
             net.per_image_streams = per_image_streams
+            if workers >= 4:  # the chip is shared: tiles that cost the least CU time, not the ones that finish first alone
+                net.set_tile_mode("throughput")
             self.nets.append(net)
             self.streams.append(torch.cuda.Stream(device=self.device))
 

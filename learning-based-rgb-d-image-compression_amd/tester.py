@@ -190,6 +190,9 @@ class TesterUnited:
 
             W = min(workers, n)
             nets = [self.net] + [self.net.clone_shared() for _ in range(W - 1)]
+            if W >= 4:
+                for nt in nets:
+                    nt.set_tile_mode("throughput")
             dev = torch.device("cuda", torch.cuda.current_device())
             errs = [None] * W
 
@@ -208,6 +211,8 @@ class TesterUnited:
                 t.start()
             for t in threads:
                 t.join()
+            if W >= 4:
+                self.net.set_tile_mode("latency")
             for e in errs:
                 if e is not None:
                     raise e

@@ -40,7 +40,7 @@ n = sum(v[0] for v in cf)
 fetch_kib, write_kib = sum(v[1] for v in cf) / n, sum(v[1] for v in cw) / max(sum(v[0] for v in cw), 1)
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
-               "--steps 2 --warmup 1 --workers 1 --no-cpu-baseline" + extra,
+               "--steps 2 --warmup 1 --workers 1 --tile-mode throughput --no-cpu-baseline" + extra,
     "kernel": "conv_mfma_kernel (all instantiations; split-K reducers not included)",
     "launches": n,
     "fetch_size_kib_per_launch_raw": fetch_kib,

@@ -153,13 +153,14 @@ def test_synthetic_weights_are_reproducible():
                                                               synth.elic_united_entries()["g_a.rgb_analysis_transform.0.weight"], 0).tobytes()).hexdigest()[:16]
 
 
-def test_tile_table_is_well_formed():
-    """csrc/tile_table.h is generated by tools/tune_tiles.py: 14 integers per entry, tile shapes that exist, unique keys."""
+@pytest.mark.parametrize("table", ["tile_table.h", "tile_table_loaded.h"])
+def test_tile_table_is_well_formed(table):
+    """csrc/tile_table*.h are generated by tools/tune_tiles.py: 14 integers per entry, tile shapes that exist, unique keys."""
     import os
     import re
 
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                        "learning-based-rgb-d-image-compression_amd", "csrc", "tile_table.h")
+                        "learning-based-rgb-d-image-compression_amd", "csrc", table)
     tiles = ({(2, m, 8) for m in (3, 2, 1)} | {(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)} |
              {(1, m, n) for n in (4, 2, 1) for m in (3, 2, 1)})
     keys = set()

@@ -24,11 +24,17 @@ MODEL = "ELIC_united"
 if "--model" in argv:
     MODEL = argv[argv.index("--model") + 1]
     del argv[argv.index("--model"):argv.index("--model") + 2]
+STREAMS = 1  # --streams S: time every variant with S copies of the launch in flight (CU-time on a shared chip)
+if "--streams" in argv:
+    STREAMS = int(argv[argv.index("--streams") + 1])
+    del argv[argv.index("--streams"):argv.index("--streams") + 2]
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(STREAMS + 4))
 args = [a for a in argv if not a.startswith("--")]
 WRITE = "--write" in sys.argv
 ONLY_CKBD = "--only-ckbd" in sys.argv  # only the checkerboard-output launches (key field nphase >= 10)
 WORKLOADS = [tuple(int(v) for v in a.split(",")) for a in args] or [(8, 256, 256), (4, 512, 640), (1, 256, 256), (1, 512, 640)]
 L = lib()
+L.rgbd_debug_bench_streams(STREAMS)
 os.environ["RGBD_NO_TILE_TABLE"] = "1"  # (read at first launch) measure the cost model, not a previous table
 
 sd = synth.synthetic_state_dict(0, model=MODEL)
@@ -110,7 +116,8 @@ L.rgbd_debug_force_tile(b"")
 L.rgbd_debug_force_splitk(0)
 L.rgbd_debug_force_ckbd(0)
 print(f"total auto {tot_auto:.2f} ms -> tuned {tot_best:.2f} ms, {len(table)} table entries")
-TABLE = os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc", "tile_table.h")
+TABLE_NAME = "tile_table.h" if STREAMS <= 1 else "tile_table_loaded.h"  # isolated-launch winners / shared-chip winners
+TABLE = os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc", TABLE_NAME)
 if os.path.exists(TABLE):  # keep what earlier runs measured for other shapes
     for ln in open(TABLE):
         ln = ln.strip()
@@ -118,12 +125,13 @@ if os.path.exists(TABLE):  # keep what earlier runs measured for other shapes
             v = [int(x) for x in ln.strip("{},").replace(" ", "").split(",")]
             if tuple(v[:9]) not in measured:  # a shape measured in this run keeps this run's verdict
                 table.setdefault(tuple(v[:9]), tuple(v[9:]))
-lines = ["// generated by tools/tune_tiles.py on MI355X -- measured winners, see conv_mfma.hip (kTuned)",
+lines = ["// generated by tools/tune_tiles.py on MI355X -- measured winners, see conv_mfma.hip (kTuned)" if STREAMS <= 1 else
+         f"// generated by tools/tune_tiles.py --streams {STREAMS} on MI355X -- winners with {STREAMS} copies of the launch in flight "
+         "(kTunedLoaded in conv_mfma.hip)",
          "// N, H, W, cin_pad, cout_pad, ntaps, stride, nphase, splitk,   wm, mt, nt, kc, dma"]
 for key, b in sorted(table.items()):
     lines.append("{" + ", ".join(str(v) for v in key) + ",   " + ", ".join(str(v) for v in b) + "},")
-out = os.path.join(ROOT, "gpurun_out", "tile_table.h") if not WRITE else \
-    os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc", "tile_table.h")
+out = os.path.join(ROOT, "gpurun_out", TABLE_NAME) if not WRITE else TABLE
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
     f.write("\n".join(lines) + "\n")
