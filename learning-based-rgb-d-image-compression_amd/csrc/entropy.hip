@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                                                           uint64_t* __restrict__ state, int init,
                                                           const int32_t* __restrict__ idx, int32_t* __restrict__ sym,
                                                           const int64_t* __restrict__ sym_base, int64_t part_off,
-                                                          int64_t count, DevTables t, int nstreams)
+                                                          int64_t count, DevTables t, int nstreams, int spw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int lut_n = (1 << t.lut_bits) + 1;
@@ -603,8 +603,10 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 
     // Four streams per workgroup, one per wavefront (each on its own SIMD): the ~125 KB of tables in LDS are shared, so a
     // decode launch of 16 streams holds 4 CUs' LDS instead of 16 (a conv workgroup cannot co-reside with these tables).
+    // (spw = streams per workgroup: 4, or 1 for a call with one or two streams -- a single image -- where sharing the
+    // LDS between waves only costs latency)
     const int tid = threadIdx.x;
-    const int s = blockIdx.x * 4 + (tid >> 6);
+    const int s = blockIdx.x * spw + (tid >> 6);
     {
         const int ncm16 = ((t.total + 64 * t.nrows) * 2 + 15) / 16;  // both images are padded to 16 bytes
         const uint4* gcm = reinterpret_cast<const uint4*>(t.cm);
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         rowinfo[i] = make_uint2((uint32_t)(t.row_off[i] + 64 * i) | ((uint32_t)t.sizes[i] << 16),
                                 (uint32_t)t.offsets[i] & 0xFFFFu);
     __syncthreads();
-    if (s >= nstreams) return;
+    if ((tid >> 6) >= spw || s >= nstreams) return;
     const int lane = tid & 63;
 
     const uint32_t* st = streams + stream_off[s];
@@ -987,8 +989,9 @@ int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    hipLaunchKernelGGL(rans_decode_kernel, dim3((nstreams + 3) / 4), dim3(256), lds, s, streams, stream_off_words,
-                       stream_len_words, state, init, idx, sym, sym_base, part_off, count, t, nstreams);
+    const int spw = nstreams <= 2 ? 1 : 4;
+    hipLaunchKernelGGL(rans_decode_kernel, dim3((nstreams + spw - 1) / spw), dim3(256), lds, s, streams, stream_off_words,
+                       stream_len_words, state, init, idx, sym, sym_base, part_off, count, t, nstreams, spw);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
