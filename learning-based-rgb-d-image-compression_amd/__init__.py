@@ -6,6 +6,7 @@ repository root (`import rgbd_amd`), which resolves to this package.
 from . import arch, synth  # noqa: F401
 from .arch import Config, model_config  # noqa: F401
 from . import _lib, ans, distributed, entropy_models  # noqa: F401,E402
+from ._lib import RgbdError  # noqa: F401,E402
 from .elic_united import ELIC_united, modelZoo  # noqa: F401,E402
 from .elic import ELIC  # noqa: F401,E402
 

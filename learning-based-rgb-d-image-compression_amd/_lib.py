@@ -26,17 +26,31 @@ def check(rc: int, what: str = ""):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into librgbd_amd.so (in-tree, next to this file)."""
+    """Compile the HIP sources for gfx950 into librgbd_amd.so (in-tree, next to this file): one object per source
+    (only stale ones are recompiled, up to four at a time), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
     csrc = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(csrc, s) for s in _SRCS]
-    deps = srcs + [os.path.join(csrc, "common.h"), os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
-    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
-        return _SO
+    objdir = os.path.join(csrc, "build")
+    hdrs = [os.path.join(csrc, "common.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
+    extra = {"conv_mfma.hip": [os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h")]}
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"] + srcs + ["-o", _SO]
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for name in _SRCS:
+        src, obj = os.path.join(csrc, name), os.path.join(objdir, name + ".o")
+        objs.append(obj)
+        deps = [src] + hdrs + extra.get(name, [])
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            jobs.append([hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-c", src, "-o", obj])
+    if not jobs and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(o) for o in objs):
+        return _SO
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        for j in jobs:
+            print(" ".join(j))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", _SO])
     return _SO
 
 

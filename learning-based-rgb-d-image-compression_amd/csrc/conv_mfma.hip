@@ -421,11 +421,17 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     const size_t buf_bytes = ((stage_bytes > epi_bytes ? stage_bytes : epi_bytes) + 15) & ~(size_t)15;
     const size_t lds = buf_bytes + 256;  // + the workgroup's expanded tap table (2 x 32 ints)
     auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
-    static size_t configured = 0;  // per instantiation
-    if (lds > 64 * 1024 && lds > configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(160 * 1024)));
-        configured = 160 * 1024;
+    if (lds > 64 * 1024) {  // the attribute is per device: one flag per (instantiation, device), set under a lock
+        static std::mutex mu;
+        static bool configured[64] = {false};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !configured[dev]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(160 * 1024)));
+            if (dev >= 0 && dev < 64) configured[dev] = true;
+        }
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * a.N) * (unsigned)((a.cout_pad + TM - 1) / TM), 1,
               (unsigned)(a.nphase * a.splitk));

@@ -20,11 +20,23 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // device tables
 // ------------------------------------------------------------------------------------------------
+// One generation of device buffers: freed when the last engine instance that still points into it lets go.  A parent
+// engine and its rgbd_elic_clone_shared() clones share generations, so re-uploading weights or tables on one of them
+// (finalize / set_tables / set_scale_table build a NEW generation) can never free memory another one still reads.
+struct DevGen {
+    std::vector<void*> p;
+    ~DevGen()
+    {
+        for (void* q : p) (void)hipFree(q);
+    }
+};
+
 struct TableSet {
     DevTables d{};
     void* blob = nullptr;
     bool ready = false;
     int stride_src = 0;
+    std::shared_ptr<DevGen> hold;  // owner of blob (engine table slots); rgbd_tables frees its blob itself
 };
 
 int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int32_t* offsets, int nrows, TableSet* ts)
@@ -102,8 +114,8 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
     const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm;
-    if (ts->blob) (void)hipFree(ts->blob);
-    ts->blob = nullptr;
+    ts->blob = nullptr;  // a previous blob stays with its owner (TableSet::hold / rgbd_tables_destroy)
+    ts->ready = false;
     HIP_TRY(hipMalloc(&ts->blob, bytes));
     std::vector<unsigned char> host(bytes, 0);
     unsigned char* p = host.data();
@@ -146,7 +158,7 @@ struct PackedConv {
     bool transposed = false;
 };
 
-int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedConv* pc)
+int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedConv* pc, DevGen* gen = nullptr)
 {
     if (w.shape.size() != 4 || w.shape[2] != w.shape[3]) return RGBD_EINVAL;
     const int k = (int)w.shape[2];
@@ -172,7 +184,9 @@ int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedC
         memcpy(hb.data(), b->v.data(), sizeof(float) * cout);
     }
     HIP_TRY(hipMalloc((void**)&pc->w, n * sizeof(float)));
+    if (gen) gen->p.push_back(pc->w);  // registered at once: a later failure leaves nothing behind
     HIP_TRY(hipMalloc((void**)&pc->bias, hb.size() * sizeof(float)));
+    if (gen) gen->p.push_back(pc->bias);
     HIP_TRY(hipMemcpy(pc->w, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pc->bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
     return RGBD_OK;
@@ -274,6 +288,8 @@ struct rgbd_elic {
     std::map<std::string, float*> dense;  // SE fc weights, EB medians (device)
     TableSet tables[4];
     float* scale_table = nullptr;
+    std::shared_ptr<DevGen> gen_w;      // owner of every pointer in convs / dense
+    std::shared_ptr<DevGen> gen_scale;  // owner of scale_table
     bool finalized = false;
 
     Arena arena;
@@ -288,7 +304,7 @@ struct rgbd_elic {
     int32_t* dbg_idx = nullptr;
     int64_t dbg_per_mod = 0;
 
-    bool owns_weights = true;  // false for instances created by rgbd_elic_clone_shared (they borrow device weights)
+    bool is_clone = false;  // created by rgbd_elic_clone_shared: shares the parent's buffer generations (DevGen)
 
     // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
     bool profile = false;
@@ -303,6 +319,7 @@ struct rgbd_elic {
 
     // --- small helpers -------------------------------------------------------------------------
     bool dry() const { return arena.dry; }
+    void graphs_invalidate() {}
     void fail(int code)
     {
         if (!rc) rc = code;
@@ -1951,7 +1968,10 @@ int rgbd_tables_create(const int32_t* cdf, int32_t cdf_stride, const int32_t* cd
     if (!out) return RGBD_EINVAL;
     std::unique_ptr<rgbd_tables> t(new rgbd_tables());
     const int r = build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &t->ts);
-    if (r) return r;
+    if (r) {
+        if (t->ts.blob) (void)hipFree(t->ts.blob);
+        return r;
+    }
     *out = t.release();
     return RGBD_OK;
 }
@@ -2420,12 +2440,14 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
     m->slice_ch = src->slice_ch;
     m->variant = src->variant;
     m->in_ch = src->in_ch;
-    m->convs = src->convs;    // device pointers are shared, read-only
+    m->convs = src->convs;    // device pointers are shared, read-only; the generations below keep them alive
     m->dense = src->dense;
+    m->gen_w = src->gen_w;
     for (int i = 0; i < 4; ++i) m->tables[i] = src->tables[i];
     m->scale_table = src->scale_table;
+    m->gen_scale = src->gen_scale;
     m->finalized = true;
-    m->owns_weights = false;
+    m->is_clone = true;
     *out = m;
     return RGBD_OK;
 }
@@ -2433,16 +2455,7 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
 void rgbd_elic_destroy(rgbd_elic* m)
 {
     if (!m) return;
-    if (m->owns_weights) {
-        for (auto& kv : m->convs) {
-            (void)hipFree(kv.second.w);
-            (void)hipFree(kv.second.bias);
-        }
-        for (auto& kv : m->dense) (void)hipFree(kv.second);
-        for (auto& t : m->tables)
-            if (t.blob) (void)hipFree(t.blob);
-        if (m->scale_table) (void)hipFree(m->scale_table);
-    }
+    // weights, tables and the scale table belong to shared generations (DevGen) that go when their last user does
     if (m->arena.base) (void)hipFree(m->arena.base);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
@@ -2468,14 +2481,30 @@ int rgbd_elic_set_tables(rgbd_elic* m, int32_t which, const int32_t* cdf, int32_
                          const int32_t* offsets, int32_t n_cdf)
 {
     if (!m || which < 0 || which > 3) return RGBD_EINVAL;
-    return build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &m->tables[which]);
+    TableSet fresh;
+    const int r = build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &fresh);
+    if (r) {
+        if (fresh.blob) (void)hipFree(fresh.blob);
+        return r;
+    }
+    fresh.hold = std::make_shared<DevGen>();
+    fresh.hold->p.push_back(fresh.blob);
+    m->tables[which] = fresh;  // the previous blob goes when no clone points at it any more
+    m->graphs_invalidate();
+    return RGBD_OK;
 }
 
 int rgbd_elic_set_scale_table(rgbd_elic* m, const float* table, int32_t n)
 {
     if (!m || !table || n != 64) return RGBD_EINVAL;
-    if (!m->scale_table) HIP_TRY(hipMalloc((void**)&m->scale_table, 64 * sizeof(float)));
-    HIP_TRY(hipMemcpy(m->scale_table, table, 64 * sizeof(float), hipMemcpyHostToDevice));
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 64 * sizeof(float)));
+    auto g = std::make_shared<DevGen>();
+    g->p.push_back(d);
+    HIP_TRY(hipMemcpy(d, table, 64 * sizeof(float), hipMemcpyHostToDevice));
+    m->scale_table = d;
+    m->gen_scale = g;
+    m->graphs_invalidate();
     return RGBD_OK;
 }
 
@@ -2488,13 +2517,21 @@ static bool ends_with(const std::string& s, const char* suf)
 int rgbd_elic_finalize(rgbd_elic* m)
 {
     if (!m) return RGBD_EINVAL;
-    for (auto& kv : m->convs) {
-        (void)hipFree(kv.second.w);
-        (void)hipFree(kv.second.bias);
-    }
-    m->convs.clear();
-    for (auto& kv : m->dense) (void)hipFree(kv.second);
-    m->dense.clear();
+    // a shared-weight clone has no host tensors of its own: re-finalising it would only drop the weights it borrows
+    if (m->is_clone && m->raw.empty()) return RGBD_ESTATE;
+    // the new weights are packed into a fresh generation and swapped in at the end; the old generation is released
+    // here but lives on for as long as a clone still points into it (no use-after-free between parent and clones)
+    auto gen = std::make_shared<DevGen>();
+    std::map<std::string, PackedConv> convs;
+    std::map<std::string, float*> dense;
+    auto dev_copy = [&](const float* src, size_t n, float** out) -> int {
+        float* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, n * sizeof(float)));
+        gen->p.push_back(d);
+        HIP_TRY(hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
+        *out = d;
+        return RGBD_OK;
+    };
     for (auto& kv : m->raw) {
         const std::string& name = kv.first;
         const HostTensor& t = kv.second;
@@ -2511,9 +2548,9 @@ int rgbd_elic_finalize(rgbd_elic* m)
             const std::string bname = name.substr(0, name.size() - 6) + "bias";
             auto bit = m->raw.find(bname);
             PackedConv pc;
-            const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc);
+            const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc, gen.get());
             if (r) return r;
-            m->convs[name] = pc;
+            convs[name] = pc;
         } else if (ends_with(name, ".weight") && t.shape.size() == 2) {
             // SE_Block linears; fc.2 ([C][hidden]) is kept transposed so the gate kernel reads it coalesced
             std::vector<float> hv = t.v;
@@ -2523,25 +2560,22 @@ int rgbd_elic_finalize(rgbd_elic* m)
                     for (size_t j = 0; j < Hd; ++j) hv[j * C + c] = t.v[c * Hd + j];
             }
             float* d = nullptr;
-            HIP_TRY(hipMalloc((void**)&d, hv.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(d, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
-            m->dense[name] = d;
+            if (const int r = dev_copy(hv.data(), hv.size(), &d)) return r;
+            dense[name] = d;
         } else if ((t.shape.size() == 1 && (name.find(".norm") != std::string::npos)) ||
                    ends_with(name, "relative_position_bias_table")) {
             // Swin LayerNorm affine parameters and relative position bias tables: plain device arrays
             float* d = nullptr;
-            HIP_TRY(hipMalloc((void**)&d, t.v.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(d, t.v.data(), t.v.size() * sizeof(float), hipMemcpyHostToDevice));
-            m->dense[name] = d;
+            if (const int r = dev_copy(t.v.data(), t.v.size(), &d)) return r;
+            dense[name] = d;
         } else if (ends_with(name, "entropy_bottleneck.quantiles")) {
             // medians = quantiles[:, 0, 1]  (entropy_models.py:316-318)
             const int C = (int)t.shape[0];
             std::vector<float> med(C);
             for (int c = 0; c < C; ++c) med[c] = t.v[(size_t)c * 3 + 1];
             float* d = nullptr;
-            HIP_TRY(hipMalloc((void**)&d, C * sizeof(float)));
-            HIP_TRY(hipMemcpy(d, med.data(), C * sizeof(float), hipMemcpyHostToDevice));
-            m->dense[name.substr(0, name.size() - 9) + "medians"] = d;
+            if (const int r = dev_copy(med.data(), (size_t)C, &d)) return r;
+            dense[name.substr(0, name.size() - 9) + "medians"] = d;
             // softplus(matrix_i) / bias_i / tanh(factor_i) per channel for the eval-mode likelihood (58 floats/channel)
             const std::string pre = name.substr(0, name.size() - 9);
             std::vector<float> prm((size_t)C * 58, 0.f);
@@ -2571,12 +2605,15 @@ int rgbd_elic_finalize(rgbd_elic* m)
             }
             if (ok) {
                 float* dp = nullptr;
-                HIP_TRY(hipMalloc((void**)&dp, prm.size() * sizeof(float)));
-                HIP_TRY(hipMemcpy(dp, prm.data(), prm.size() * sizeof(float), hipMemcpyHostToDevice));
-                m->dense[pre + "cumulative"] = dp;
+                if (const int r = dev_copy(prm.data(), prm.size(), &dp)) return r;
+                dense[pre + "cumulative"] = dp;
             }
         }
     }
+    m->convs.swap(convs);
+    m->dense.swap(dense);
+    m->gen_w = gen;
+    m->graphs_invalidate();
     m->finalized = true;
     return RGBD_OK;
 }

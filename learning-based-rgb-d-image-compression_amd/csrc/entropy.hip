@@ -6,6 +6,8 @@
 // The coder is integer work and bit-exact against the oracle by construction; streams are little-endian u32 words.
 // One wavefront serves one stream: all 64 lanes expand symbols to (start, freq) pairs / fetch table metadata for a
 // chunk in parallel, then lane 0 walks the serial state recurrence out of LDS.
+#include <mutex>
+
 #include "common.h"
 
 #define PROB_BITS 16
@@ -983,11 +985,17 @@ int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words,
     const size_t lds = rans_decode_lds_bytes(t);
     if (lds > 158 * 1024 || t.nrows * (((size_t)1 << t.lut_bits) + 1) > 65535 || t.total + 64 * t.nrows > 65535)
         return RGBD_ENOSPC;
-    static bool configured = false;
-    if (!configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
+    {   // the attribute is per device and this is called from several host threads (CodecPool)
+        static std::mutex mu;
+        static bool configured[64] = {false};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !configured[dev]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rans_decode_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev >= 0 && dev < 64) configured[dev] = true;
+        }
     }
     const int spw = nstreams <= 2 ? 1 : 4;
     hipLaunchKernelGGL(rans_decode_kernel, dim3((nstreams + spw - 1) / spw), dim3(256), lds, s, streams, stream_off_words,

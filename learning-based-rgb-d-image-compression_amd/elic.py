@@ -42,6 +42,8 @@ class ELIC(ELIC_united):
         self._h = None
         self._device = None
         self._dirty = True
+        self._gen = 0
+        self._parent = None
 
     def _materialize(self):
         if self._params is None:

@@ -11,6 +11,7 @@ kernels); this class only holds the checkpoint, builds the integer tables once (
 There is no CPU execution path: compress()/decompress() raise if the HIP library or a GPU is missing.
 """
 import ctypes
+import logging
 import time
 from collections import OrderedDict
 
@@ -23,6 +24,7 @@ from .arch import elic_united_entries, model_config
 from .entropy_models import EntropyBottleneck, GaussianConditional, get_scale_table
 
 _TABLE_KEYS = ("_offset", "_quantized_cdf", "_cdf_length")
+_log = logging.getLogger("rgbd_amd")
 
 
 class ELIC_united:
@@ -46,6 +48,8 @@ class ELIC_united:
         self._h = None
         self._device = None
         self._dirty = True
+        self._gen = 0        # bumped by every upload of weights / tables to the GPU
+        self._parent = None  # set on shared-weight clones (clone_shared)
 
     # ---- torch.nn.Module-like surface ------------------------------------------------------------------
     _MODEL = "ELIC_united"
@@ -106,11 +110,28 @@ class ELIC_united:
         return out
 
     def load_state_dict(self, state_dict, strict=False):
-        """Accepts the reference's key set; unknown / missing keys raise when strict."""
+        """Accepts the reference's key set.  Like the reference (models/elic_united.py:613-620:
+        strict first, traceback printed, then strict=False) a partial checkpoint is accepted but never silently: the
+        missing / unexpected key lists are logged, a DDP "module." prefix is stripped, and a checkpoint that matches no
+        parameter at all raises instead of leaving the model on its synthetic initialisation."""
+        self._require_owner("load_state_dict")
+        if state_dict and all(k.startswith("module.") for k in state_dict):  # saved from a DDP / DataParallel wrapper
+            state_dict = OrderedDict((k[len("module."):], v) for k, v in state_dict.items())
         missing = [k for k in self._entries if k not in state_dict]
         unexpected = [k for k in state_dict if k not in self._entries]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        n_params = sum(1 for k, e in self._entries.items() if e.is_param)
+        hit = sum(1 for k, e in self._entries.items() if e.is_param and k in state_dict)
+        if n_params and not hit:
+            raise RuntimeError(f"load_state_dict: none of the {n_params} parameter keys of {self._MODEL} is in the checkpoint "
+                               f"(first checkpoint keys: {list(state_dict)[:3]})")
+        if missing:
+            _log.warning("%s.load_state_dict: %d missing keys keep their initial values: %s%s", self._MODEL, len(missing),
+                         missing[:8], " ..." if len(missing) > 8 else "")
+        if unexpected:
+            _log.warning("%s.load_state_dict: %d unexpected keys ignored: %s%s", self._MODEL, len(unexpected),
+                         unexpected[:8], " ..." if len(unexpected) > 8 else "")
         params = self._materialize() if missing else OrderedDict()
         holders = self._holders()
         for name, e in self._entries.items():
@@ -134,6 +155,7 @@ class ELIC_united:
 
     def update(self, scale_table=None, force=False):
         """models/elic_united.py:580-586 + compressai/models/priors.py:73-92."""
+        self._require_owner("update")
         self._materialize()
         if scale_table is None:
             scale_table = get_scale_table()
@@ -186,10 +208,33 @@ class ELIC_united:
               "set_scale_table")
         check(L.rgbd_elic_finalize(self._h), "finalize")
         self._dirty = False
+        self._gen += 1
+
+    def _require_owner(self, what):
+        if self._parent is not None:
+            raise RgbdError(f"{what}() on a shared-weight clone: call it on the parent engine (clones follow it)")
 
     def _ready(self):
         if self._h is None or self._device is None:
             raise RgbdError("call .to('cuda') before compress()/decompress()")
+        if self._parent is not None:
+            # shared-weight clone: follow the parent.  If the parent has re-uploaded weights or tables since this clone
+            # was made (update() / load_state_dict()), take a fresh clone of it -- the old device buffers stay valid
+            # until then (they are reference-counted in the library), they are merely stale.
+            par = self._parent
+            par._ready()
+            if par._gen != self._gen:
+                L = lib()
+                h = ctypes.c_void_p()
+                check(L.rgbd_elic_clone_shared(par._h, ctypes.byref(h)), "clone_shared")
+                L.rgbd_elic_destroy(self._h)
+                self._h = h
+                self._gen = par._gen
+                self._params = par._params
+                if getattr(self, "_tile_mode", None):
+                    check(L.rgbd_elic_set_tile_mode(self._h, {"latency": 0, "throughput": 1}[self._tile_mode]), "tile_mode")
+            torch.cuda.set_device(self._device)
+            return
         if self._dirty:
             self._upload()
         torch.cuda.set_device(self._device)
@@ -362,6 +407,7 @@ class ELIC_united:
         check(lib().rgbd_elic_clone_shared(self._h, ctypes.byref(h)), "clone_shared")
         other._h = h
         other._parent = self
+        other._gen = self._gen
         other._dirty = False
         return other
 
@@ -370,6 +416,7 @@ class ELIC_united:
         chip shared between several engine instances -- what `CodecPool` / `test_model(workers > 1)` select).  The outputs
         are bit-identical in both modes."""
         self._ready()
+        self._tile_mode = mode
         check(lib().rgbd_elic_set_tile_mode(self._h, {"latency": 0, "throughput": 1}[mode]), "set_tile_mode")
 
     def set_profile(self, on: bool):

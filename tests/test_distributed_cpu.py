@@ -62,3 +62,40 @@ def test_single_process_passthrough():
     assert D.gather_streams([b"ab", b""]) == [[b"ab", b""]]
     assert D.shard(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.max_over_ranks(3.5) == 3.5
+
+
+def _bench(*argv, env=None, timeout=150):
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.timeout(200)
+def test_bench_spawns_its_own_ranks():
+    """`bench.py --gpus 2` with no launcher around it starts 2 ranks itself (one process per GPU; here a gloo rehearsal of
+    the plumbing: rendezvous, barrier, max-over-ranks timing, the stream all-gather) and prints rank 0's one JSON line."""
+    import json
+
+    p = _bench("--gpus", "2", "--steps", "3", "--rehearse")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["gathered_ok"] is True
+    assert rec["streams_per_rank"] == [4, 5]
+
+
+@pytest.mark.timeout(200)
+def test_bench_rank_count_mismatch_is_an_error():
+    # started as one of 3 ranks but told --gpus 2: refuse instead of reporting a wrong n_gpus
+    p = _bench("--gpus", "2", "--rehearse", env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode == 2 and "does not match" in p.stderr
+    # a failing rank takes the whole job down with a non-zero exit code
+    p = _bench("--gpus", "2", "--rehearse", "--steps", "1", env={"RGBD_REHEARSE_FAIL_RANK": "1"})
+    assert p.returncode != 0
