@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -241,6 +242,12 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
     a->span_y = a->span_x = mx - mn + 1;
 }
 
+// Stream capture vs device-wide operations: a hipFree / hipDeviceSynchronize / synchronous hipMemcpy issued by ANY host
+// thread while another thread's stream is capturing fails ("operation not permitted when stream is capturing") and
+// poisons that capture.  Captures hold this lock shared (several engine instances may capture at once); everything that
+// frees or synchronises device-wide takes it exclusively.
+std::shared_mutex g_capture_mu;
+int g_cfg_epoch = 0;     // bumped by every debug switch that changes kernel choices: cached HIP graphs of older epochs are not reused
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 int g_bench_streams = 1;  // rgbd_debug_bench_streams: rgbd_conv_bench issues every launch on this many streams at once
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
@@ -319,7 +326,150 @@ struct rgbd_elic {
 
     // --- small helpers -------------------------------------------------------------------------
     bool dry() const { return arena.dry; }
-    void graphs_invalidate() {}
+
+    // ---- HIP graphs ---------------------------------------------------------------------------------------------
+    // The launch sequence of a compress() / decompress() call (~750 dependent kernels for ELIC_united) depends only on
+    // the call shape: workspace addresses are a deterministic function of (B, H, W, stream format), weights and tables
+    // are fixed.  The second call of a shape therefore captures its "body" -- everything between the upload of the
+    // inputs and the fetch of the results -- into a HIP graph, and later calls replay it with one hipGraphLaunch: no
+    // per-launch host work (name lookups, tap tables, tile choice, argument marshalling), which is what the 16 host
+    // threads of a pooled rank used to burn their cores on.  Anything that would stale a baked pointer or a baked
+    // kernel choice drops the graphs: workspace re-allocation, new weights / tables, tile-mode and debug switches.
+    struct GraphEntry {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;                       // completed calls of this shape (the first one runs eagerly)
+        std::map<std::string, Act> named;   // debug tensors of the body (same workspace addresses on every replay)
+        Act out[2];                         // body outputs the epilogue reads (x_hat or y_hat per modality)
+    };
+    std::map<std::string, GraphEntry> graphs;
+    GraphEntry* cur_ge = nullptr;  // entry of the call in progress (nullptr: graphs off for this call)
+    int body_mode = 0;             // 0 eager, 1 capturing, 2 replaying
+    const bool use_graphs = getenv("RGBD_NO_GRAPH") == nullptr;
+    const bool blocking_wait = getenv("RGBD_SPIN_WAIT") == nullptr;
+    hipEvent_t done_ev = nullptr;  // blocking-sync event: the host thread sleeps instead of spinning on the stream
+    // pinned staging for the per-call uploads (stream bytes, offsets): truly asynchronous copies, no per-call pinning
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    hipEvent_t pin_ev = nullptr;
+    bool pin_busy = false;
+
+    void graphs_invalidate()
+    {
+        for (auto& kv : graphs) {
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+            if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+        }
+        graphs.clear();
+        cur_ge = nullptr;
+    }
+    GraphEntry* graph_entry(const std::string& key)
+    {
+        if (!use_graphs || profile) return nullptr;
+        return &graphs[key + "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch)];
+    }
+    // Start of the capturable part of a call.  Returns true when the caller has to run the body code (eagerly, into a
+    // capture, or as a sizing pass), false when a cached graph stands in for it.
+    bool body_begin()
+    {
+        body_mode = 0;
+        if (dry() || !cur_ge) return true;
+        if (cur_ge->exec) {
+            body_mode = 2;
+            return false;
+        }
+        if (cur_ge->seen < 1) return true;
+        // relaxed: other host threads (other engine instances) keep launching while this one captures; the operations
+        // that must not overlap a capture are fenced off with g_capture_mu
+        g_capture_mu.lock_shared();
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            g_capture_mu.unlock_shared();
+            (void)hipGetLastError();
+            return true;
+        }
+        body_mode = 1;
+        return true;
+    }
+    int body_end()
+    {
+        const int mode = body_mode;
+        body_mode = 0;
+        if (dry()) return RGBD_OK;
+        if (mode == 1) {
+            hipGraph_t gr = nullptr;
+            const hipError_t e = hipStreamEndCapture(s, &gr);
+            g_capture_mu.unlock_shared();
+            if (e != hipSuccess || rc) {
+                if (gr) (void)hipGraphDestroy(gr);
+                (void)hipGetLastError();
+                return rc ? rc : RGBD_EHIP;
+            }
+            hipGraphExec_t ex = nullptr;
+            if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGraphDestroy(gr);
+                (void)hipGetLastError();
+                return RGBD_EHIP;
+            }
+            cur_ge->graph = gr;
+            cur_ge->exec = ex;
+            cur_ge->named = named;
+        }
+        if (mode) {
+            HIP_TRY(hipGraphLaunch(cur_ge->exec, s));
+            if (mode == 2) named = cur_ge->named;
+        }
+        if (cur_ge && !rc) ++cur_ge->seen;
+        return RGBD_OK;
+    }
+    // an error return between body_begin() and body_end() must not leave the stream capturing
+    void body_abort()
+    {
+        if (body_mode == 1) {
+            hipGraph_t gr = nullptr;
+            (void)hipStreamEndCapture(s, &gr);
+            g_capture_mu.unlock_shared();
+            if (gr) (void)hipGraphDestroy(gr);
+            (void)hipGetLastError();
+        }
+        body_mode = 0;
+    }
+    int wait_stream()
+    {
+        if (!blocking_wait) {
+            HIP_TRY(hipStreamSynchronize(s));
+            return RGBD_OK;
+        }
+        if (!done_ev) HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventBlockingSync | hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(done_ev, s));
+        HIP_TRY(hipEventSynchronize(done_ev));
+        return RGBD_OK;
+    }
+    // pinned staging buffer of at least `bytes`; waits until the previous call's copies out of it have finished
+    int pin_take(size_t bytes, void** out)
+    {
+        if (pin_busy) {
+            HIP_TRY(hipEventSynchronize(pin_ev));
+            pin_busy = false;
+        }
+        if (bytes > pin_cap) {
+            std::unique_lock<std::shared_mutex> lk(g_capture_mu);
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr;
+            pin_cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            HIP_TRY(hipHostMalloc(&pin, want, hipHostMallocDefault));
+            pin_cap = want;
+        }
+        *out = pin;
+        return RGBD_OK;
+    }
+    int pin_release()
+    {
+        if (!pin_ev) HIP_TRY(hipEventCreateWithFlags(&pin_ev, hipEventBlockingSync | hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(pin_ev, s));
+        pin_busy = true;
+        return RGBD_OK;
+    }
     void fail(int code)
     {
         if (!rc) rc = code;
@@ -1309,8 +1459,10 @@ struct rgbd_elic {
 int rgbd_elic::ensure_arena(size_t bytes)
 {
     if (bytes <= arena.cap) return RGBD_OK;
+    graphs_invalidate();  // cached graphs have the old workspace addresses baked in
+    std::unique_lock<std::shared_mutex> lk(g_capture_mu);  // hipFree synchronises the device: not while anyone captures
     if (arena.base) {
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(s));  // only this instance's stream ever touches this workspace
         HIP_TRY(hipFree(arena.base));
         arena.base = nullptr;
         arena.cap = 0;
@@ -1333,7 +1485,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     arena.top = 0;
     rc = 0;
 
-    // ---- persistent buffers of this call
+    // ==== prologue (never captured): workspace of the call, upload of the stream geometry, input layout conversion ====
     int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(14 * B + 64));
     int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
     int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
@@ -1350,24 +1502,28 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
 
     // meta64 layout: [0,B) y stream_base inside a modality region (checkerboard kernels) ; [2B,3B) z base ;
     //   [3B,4B) z counts ; [6B,8B) z out_words ; from 8B: y encoder bases [2ny] (absolute), counts [2ny], out_words [2ny]
-    std::vector<int64_t> hmeta((size_t)14 * B + 64, 0);
-    for (int b = 0; b < B; ++b) {
-        hmeta[b] = per_image ? (int64_t)b * T : 0;
-        hmeta[2 * B + b] = (int64_t)b * Tz;
-        hmeta[3 * B + b] = Tz;
-    }
-    for (int m = 0; m < 2; ++m)
-        for (int i = 0; i < ny; ++i) {
-            hmeta[(size_t)8 * B + (size_t)m * ny + i] = (int64_t)m * B * T + (per_image ? (int64_t)i * T : 0);
-            hmeta[(size_t)8 * B + 2 * ny + (size_t)m * ny + i] = ycount;
-        }
     if (!dry()) {
-        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(err, 0, 256, s));
+        const size_t nmeta = (size_t)14 * B + 64;
+        void* pv = nullptr;
+        if (const int r = pin_take(nmeta * sizeof(int64_t), &pv)) return r;
+        int64_t* hmeta = (int64_t*)pv;
+        memset(hmeta, 0, nmeta * sizeof(int64_t));
+        for (int b = 0; b < B; ++b) {
+            hmeta[b] = per_image ? (int64_t)b * T : 0;
+            hmeta[2 * B + b] = (int64_t)b * Tz;
+            hmeta[3 * B + b] = Tz;
+        }
+        for (int m = 0; m < 2; ++m)
+            for (int i = 0; i < ny; ++i) {
+                hmeta[(size_t)8 * B + (size_t)m * ny + i] = (int64_t)m * B * T + (per_image ? (int64_t)i * T : 0);
+                hmeta[(size_t)8 * B + 2 * ny + (size_t)m * ny + i] = ycount;
+            }
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta, sizeof(int64_t) * nmeta, hipMemcpyHostToDevice, s));
+        if (const int r = pin_release()) return r;
     }
 
     Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
-    Act hyp_r, hyp_d;
+    Act hyp_r, hyp_d, rgb, depth;
     if (lat) {
         hyp_r = alloc(B, h, w, 2 * M);
         hyp_d = alloc(B, h, w, 2 * M);
@@ -1378,117 +1534,124 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
             if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s);
             if (r) return r;
         }
-        named["y_r"] = y_r;
-        named["y_d"] = y_d;
     } else {
-        // ---- analysis
-        Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
+        rgb = alloc(B, H, W, 3);
+        depth = alloc(B, H, W, 1);
         if (!dry()) {
             int r = launch_nchw_to_nhwc16(rgb_dev, B, 3, H, W, rgb.p, rgb.cs, s);
             if (!r) r = launch_nchw_to_nhwc16(depth_dev, B, 1, H, W, depth.p, depth.cs, s);
             if (r) return r;
         }
-        Act z_r, z_d;
-        {
-            const size_t mark = arena.top;
-            Act yr_t, yd_t;
-            if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
-            else if (variant == 3) g_a_r2d(rgb, depth, &yr_t, &yd_t);
-            else g_a(rgb, depth, &yr_t, &yd_t);
-            copy_ch(yr_t, y_r);
-            copy_ch(yd_t, y_d);
-            arena.top = mark;
-        }
-        h_a(y_r, y_d, &z_r, &z_d);
+    }
+
+    // ==== body: every kernel of the call, in stream order; captured into / replayed from a HIP graph per call shape ====
+    if (body_begin()) {
+        if (!dry()) HIP_TRY(hipMemsetAsync(err, 0, 256, s));
         named["y_r"] = y_r;
         named["y_d"] = y_d;
-        named["z_r"] = z_r;
-        named["z_d"] = z_d;
-
-        // ---- z: quantise, encode, dequantise (entropy_models.py:437-446)
-        Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
-        if (!dry() && !rc) {
-            const Act* zz[2] = {&z_r, &z_d};
-            const Act* zo[2] = {&zh_r, &zh_d};
-            const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
-            for (int m = 0; m < 2 && !rc; ++m) {
-                float* md = dense_of(med[m]);
-                if (!md) break;
-                int32_t* zs = zsym + (size_t)m * B * Tz;
-                int32_t* zi = zidx + (size_t)m * B * Tz;
-                int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
-                if (!r)
-                    r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
-                                           zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
-                if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
-                if (r) fail(r);
+        if (!lat) {
+            // ---- analysis
+            Act z_r, z_d;
+            {
+                const size_t mark = arena.top;
+                Act yr_t, yd_t;
+                if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
+                else if (variant == 3) g_a_r2d(rgb, depth, &yr_t, &yd_t);
+                else g_a(rgb, depth, &yr_t, &yd_t);
+                copy_ch(yr_t, y_r);
+                copy_ch(yd_t, y_d);
+                arena.top = mark;
             }
-        }
-        named["zhat_r"] = zh_r;
-        named["zhat_d"] = zh_d;
+            h_a(y_r, y_d, &z_r, &z_d);
+            named["z_r"] = z_r;
+            named["z_d"] = z_d;
 
-        // ---- hyper synthesis + Bi-CEE
-        if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
-        else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+            // ---- z: quantise, encode, dequantise (entropy_models.py:437-446)
+            Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+            if (!dry() && !rc) {
+                const Act* zz[2] = {&z_r, &z_d};
+                const Act* zo[2] = {&zh_r, &zh_d};
+                const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
+                for (int m = 0; m < 2 && !rc; ++m) {
+                    float* md = dense_of(med[m]);
+                    if (!md) break;
+                    int32_t* zs = zsym + (size_t)m * B * Tz;
+                    int32_t* zi = zidx + (size_t)m * B * Tz;
+                    int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
+                    if (!r)
+                        r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
+                                               zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
+                    if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+                    if (r) fail(r);
+                }
+            }
+            named["zhat_r"] = zh_r;
+            named["zhat_d"] = zh_d;
+
+            // ---- hyper synthesis
+            if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
+            else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        }
         named["hyper_r"] = hyp_r;
         named["hyper_d"] = hyp_d;
-    }
-    named["hyper_r"] = hyp_r;
-    named["hyper_d"] = hyp_d;
-    Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
-    if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
-        int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
-        if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
-        if (zr) fail(zr);
-    }
-    named["yhat_r"] = yhat_r;
-    named["yhat_d"] = yhat_d;
-    Coding cd;
-    cd.encode = true;
-    cd.per_image = per_image;
-    cd.per_image_total = T;
-    cd.sym = sym;
-    cd.idx = idx;
-    cd.stream_base = meta64;
-    if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
-    else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+        Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+        if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
+            int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
+            if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
+            if (zr) fail(zr);
+        }
+        named["yhat_r"] = yhat_r;
+        named["yhat_d"] = yhat_d;
+        Coding cd;
+        cd.encode = true;
+        cd.per_image = per_image;
+        cd.per_image_total = T;
+        cd.sym = sym;
+        cd.idx = idx;
+        cd.stream_base = meta64;
+        if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+        else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
 
-    if (!dry() && !rc) {
-        // both modalities in one launch: streams [0, ny) are rgb, [ny, 2ny) depth; bases are relative to `sym`
-        const int r = launch_rans_encode(sym, idx, meta64 + 8 * B, meta64 + 8 * B + 2 * ny, 2 * ny, ny, tables[0].d,
-                                         tables[1].d, ywords, ycap, meta64 + 8 * B + 4 * ny, err, s);
-        if (r) fail(r);
+        if (!dry() && !rc) {
+            // both modalities in one launch: streams [0, ny) are rgb, [ny, 2ny) depth; bases are relative to `sym`
+            const int r = launch_rans_encode(sym, idx, meta64 + 8 * B, meta64 + 8 * B + 2 * ny, 2 * ny, ny, tables[0].d,
+                                             tables[1].d, ywords, ycap, meta64 + 8 * B + 4 * ny, err, s);
+            if (r) fail(r);
+        }
     }
-    if (rc) return rc;
+    {
+        const int r = body_end();
+        if (rc) return rc;
+        if (r) return r;
+    }
     if (dry()) return RGBD_OK;
 
-    // ---- fetch the streams
+    // ==== epilogue (never captured): fetch the streams ================================================================
     std::vector<int64_t> ow((size_t)4 * B, 0);  // [y rgb | y depth | z rgb | z depth], B slots each
     int herr = 0;
     HIP_TRY(hipMemcpyAsync(ow.data(), meta64 + 8 * B + 4 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(ow.data() + B, meta64 + 8 * B + 5 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(ow.data() + 2 * B, meta64 + 6 * B, sizeof(int64_t) * 2 * B, hipMemcpyDeviceToHost, s));
+    if (!lat) HIP_TRY(hipMemcpyAsync(ow.data() + 2 * B, meta64 + 6 * B, sizeof(int64_t) * 2 * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (const int r = wait_stream()) return r;
     if (herr) return RGBD_ENOSPC;
     for (int m = 0; m < 2; ++m) {
         streams[m][0].assign(ny, {});
-        streams[m][1].assign(B, {});
+        streams[m][1].assign(lat ? 0 : B, {});
         for (int i = 0; i < ny; ++i) {
             const int64_t nw = ow[(size_t)m * B + i];
             streams[m][0][i].resize((size_t)nw * 4);
             const uint32_t* src = ywords + ((size_t)m * ny + i) * ycap + (ycap - nw);
             HIP_TRY(hipMemcpyAsync(streams[m][0][i].data(), src, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
         }
-        for (int i = 0; i < B; ++i) {
+        for (int i = 0; i < B && !lat; ++i) {
             const int64_t nw = ow[(size_t)2 * B + (size_t)m * B + i];
             streams[m][1][i].resize((size_t)nw * 4);
             const uint32_t* src = zwords + ((size_t)m * B + i) * zcap + (zcap - nw);
             HIP_TRY(hipMemcpyAsync(streams[m][1][i].data(), src, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
         }
     }
-    HIP_TRY(hipStreamSynchronize(s));
-    return RGBD_OK;
+    return wait_stream();
 }
 
 // eval-mode forward(): models/elic_united.py:234-263 with quant == "ste" (round in eval), likelihoods as in
@@ -1587,42 +1750,17 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     arena.top = 0;
     rc = 0;
 
-    // ---- upload streams: words region = [y rgb | y depth | z rgb | z depth]
+    // ==== prologue (never captured): upload the streams ================================================================
+    // words region = [y rgb | y depth | z rgb | z depth], every stream in a slot of the size the encoder may produce for
+    // this shape, so that the workspace layout (and with it a cached graph) does not depend on the stream lengths
     const int ns_y = n_y, ns_z = lat ? 0 : B;
-    std::vector<int64_t> hmeta;  // y: off[2][ns_y], len[2][ns_y]; z: off[2][B], len[2][B]; y base[B]; z base[B]
-    std::vector<uint32_t> hwords;
-    auto push_streams = [&](const uint8_t* const* arr, const int64_t* len, int n, std::vector<int64_t>& off,
-                            std::vector<int64_t>& ln) -> int {
-        for (int i = 0; i < n; ++i) {
-            if (len[i] < 8 || (len[i] & 3)) return RGBD_EINVAL;
-            off.push_back((int64_t)hwords.size());
-            ln.push_back(len[i] / 4);
-            const size_t o = hwords.size();
-            hwords.resize(o + (size_t)len[i] / 4);
-            memcpy(hwords.data() + o, arr[i], (size_t)len[i]);
-        }
-        return RGBD_OK;
-    };
-    std::vector<int64_t> yoff, ylen_w, zoff, zlen_w;
-    for (int m = 0; m < 2; ++m) {
-        const int r = push_streams(ys[m], ylen[m], ns_y, yoff, ylen_w);
-        if (r) return r;
-    }
-    for (int m = 0; m < 2 && ns_z; ++m) {
-        const int r = push_streams(zs[m], zlen[m], ns_z, zoff, zlen_w);
-        if (r) return r;
-    }
-    hmeta.insert(hmeta.end(), yoff.begin(), yoff.end());
-    hmeta.insert(hmeta.end(), ylen_w.begin(), ylen_w.end());
-    hmeta.insert(hmeta.end(), zoff.begin(), zoff.end());
-    hmeta.insert(hmeta.end(), zlen_w.begin(), zlen_w.end());
-    const size_t o_ybase = hmeta.size();
-    for (int b = 0; b < B; ++b) hmeta.push_back(per_image ? (int64_t)b * T : 0);
-    const size_t o_zbase = hmeta.size();
-    for (int b = 0; b < B; ++b) hmeta.push_back((int64_t)b * Tz);
-
-    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * hmeta.size());
-    uint32_t* words = (uint32_t*)arena.take(sizeof(uint32_t) * (hwords.size() + 4));
+    const int64_t ycount = per_image ? T : T * B;
+    const int64_t ycap = ((5 * ycount + 32 + 704) + 63) & ~(int64_t)63, zcap = ((5 * Tz + 32 + 704) + 63) & ~(int64_t)63;
+    // meta64: y off[2][ns_y], y len[2][ns_y], z off[2][ns_z], z len[2][ns_z], y base[B], z base[B]
+    const size_t nmeta = (size_t)4 * ns_y + (size_t)4 * ns_z + (size_t)2 * B;
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * nmeta);
+    const size_t nwords_cap = (size_t)2 * ns_y * ycap + (size_t)2 * ns_z * zcap;
+    uint32_t* words = (uint32_t*)arena.take(sizeof(uint32_t) * (nwords_cap + 4));
     uint64_t* state = (uint64_t*)arena.take(sizeof(uint64_t) * (size_t)(4 * (ns_y + ns_z)));
     int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
     int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
@@ -1631,17 +1769,56 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     dbg_sym = sym;
     dbg_idx = idx;
     dbg_per_mod = (int64_t)B * T;
+    for (int m = 0; m < 2; ++m) {
+        for (int i = 0; i < ns_y; ++i)
+            if (!ys[m] || !ys[m][i] || ylen[m][i] < 8 || (ylen[m][i] & 3) || ylen[m][i] / 4 > ycap) return RGBD_EINVAL;
+        for (int i = 0; i < ns_z; ++i)
+            if (!zs[m] || !zs[m][i] || zlen[m][i] < 8 || (zlen[m][i] & 3) || zlen[m][i] / 4 > zcap) return RGBD_EINVAL;
+    }
     if (!dry()) {
-        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(words, hwords.data(), sizeof(uint32_t) * hwords.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope at return; keep it simple
+        size_t total_words = 0;
+        for (int m = 0; m < 2; ++m) {
+            for (int i = 0; i < ns_y; ++i) total_words += (size_t)ylen[m][i] / 4;
+            for (int i = 0; i < ns_z; ++i) total_words += (size_t)zlen[m][i] / 4;
+        }
+        void* pv = nullptr;
+        if (const int r = pin_take(nmeta * sizeof(int64_t) + total_words * 4, &pv)) return r;
+        int64_t* hmeta = (int64_t*)pv;
+        uint32_t* hw = (uint32_t*)(hmeta + nmeta);
+        size_t used = 0;
+        auto put = [&](const uint8_t* src, int64_t len, size_t slot_off, size_t meta_off, size_t meta_len) -> int {
+            memcpy(hw + used, src, (size_t)len);
+            hmeta[meta_off] = (int64_t)slot_off;
+            hmeta[meta_len] = len / 4;
+            HIP_TRY(hipMemcpyAsync(words + slot_off, hw + used, (size_t)len, hipMemcpyHostToDevice, s));
+            used += (size_t)len / 4;
+            return RGBD_OK;
+        };
+        for (int m = 0; m < 2; ++m)
+            for (int i = 0; i < ns_y; ++i) {
+                const size_t k = (size_t)m * ns_y + i;
+                if (const int r = put(ys[m][i], ylen[m][i], k * (size_t)ycap, k, (size_t)2 * ns_y + k)) return r;
+            }
+        for (int m = 0; m < 2; ++m)
+            for (int i = 0; i < ns_z; ++i) {
+                const size_t k = (size_t)m * ns_z + i;
+                if (const int r = put(zs[m][i], zlen[m][i], (size_t)2 * ns_y * ycap + k * (size_t)zcap, (size_t)4 * ns_y + k,
+                                      (size_t)4 * ns_y + 2 * ns_z + k))
+                    return r;
+            }
+        for (int b = 0; b < B; ++b) {
+            hmeta[(size_t)4 * ns_y + 4 * ns_z + b] = per_image ? (int64_t)b * T : 0;
+            hmeta[(size_t)4 * ns_y + 4 * ns_z + B + b] = (int64_t)b * Tz;
+        }
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta, sizeof(int64_t) * nmeta, hipMemcpyHostToDevice, s));
+        if (const int r = pin_release()) return r;
     }
     const int64_t* d_yoff = meta64;
     const int64_t* d_ylen = meta64 + 2 * ns_y;
     const int64_t* d_zoff = meta64 + 4 * ns_y;
     const int64_t* d_zlen = meta64 + 4 * ns_y + 2 * ns_z;
-    const int64_t* d_ybase = meta64 + o_ybase;
-    const int64_t* d_zbase = meta64 + o_zbase;
+    const int64_t* d_ybase = meta64 + 4 * ns_y + 4 * ns_z;
+    const int64_t* d_zbase = d_ybase + B;
 
     Act hyp_r, hyp_d;
     if (lat) {
@@ -1652,76 +1829,94 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
             if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s);
             if (r) return r;
         }
-        named["hyper_r"] = hyp_r;
-        named["hyper_d"] = hyp_d;
-    } else {
-        // ---- z decode (entropy_models.py:442-446)
-        Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
-        if (!dry()) {
-            const Act* zo[2] = {&zh_r, &zh_d};
-            const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
-            for (int m = 0; m < 2 && !rc; ++m) {
-                float* md = dense_of(med[m]);
-                if (!md) break;
-                int32_t* zs_ = zsym + (size_t)m * B * Tz;
-                int32_t* zi_ = zidx + (size_t)m * B * Tz;
-                // indexes = channel id in (c, row, col) order: the quantiser's index writer on a zeroed tensor
-                int r = launch_fill_zero(zo[m]->p, zo[m]->elems(), s);
-                if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s);
-                if (!r)
-                    r = launch_rans_decode(words, d_zoff + (size_t)m * ns_z, d_zlen + (size_t)m * ns_z, ns_z,
-                                           state + (size_t)4 * ns_y + (size_t)m * ns_z * 2, 1, zi_, zs_, d_zbase, 0, Tz,
-                                           tables[2 + m].d, s);
-                if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
-                if (r) fail(r);
-            }
-        }
-        named["zhat_r"] = zh_r;
-        named["zhat_d"] = zh_d;
+    }
 
-        if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
-        else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+    // ==== body: captured into / replayed from a HIP graph per call shape ================================================
+    Act out0, out1;  // what the epilogue hands back: x_hat (or y_hat for decompress_united) per modality
+    if (body_begin()) {
+        if (!lat) {
+            // ---- z decode (entropy_models.py:442-446)
+            Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+            if (!dry()) {
+                const Act* zo[2] = {&zh_r, &zh_d};
+                const char* med[2] = {"rgb_entropy_bottleneck.medians", "depth_entropy_bottleneck.medians"};
+                for (int m = 0; m < 2 && !rc; ++m) {
+                    float* md = dense_of(med[m]);
+                    if (!md) break;
+                    int32_t* zs_ = zsym + (size_t)m * B * Tz;
+                    int32_t* zi_ = zidx + (size_t)m * B * Tz;
+                    // indexes = channel id in (c, row, col) order: the quantiser's index writer on a zeroed tensor
+                    int r = launch_fill_zero(zo[m]->p, zo[m]->elems(), s);
+                    if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s);
+                    if (!r)
+                        r = launch_rans_decode(words, d_zoff + (size_t)m * ns_z, d_zlen + (size_t)m * ns_z, ns_z,
+                                               state + (size_t)4 * ns_y + (size_t)m * ns_z * 2, 1, zi_, zs_, d_zbase, 0, Tz,
+                                               tables[2 + m].d, s);
+                    if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+                    if (r) fail(r);
+                }
+            }
+            named["zhat_r"] = zh_r;
+            named["zhat_d"] = zh_d;
+
+            if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
+            else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        }
         named["hyper_r"] = hyp_r;
         named["hyper_d"] = hyp_d;
+        Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+        if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
+            int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
+            if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
+            if (zr) fail(zr);
+        }
+        named["yhat_r"] = yhat_r;
+        named["yhat_d"] = yhat_d;
+        Coding cd;
+        cd.encode = false;
+        cd.per_image = per_image;
+        cd.per_image_total = T;
+        cd.sym = sym;
+        cd.idx = idx;
+        cd.stream_base = d_ybase;
+        cd.words = words;
+        cd.stream_off = d_yoff;
+        cd.stream_len = d_ylen;
+        cd.state = state;
+        cd.nstreams = ns_y;
+        if (variant == 3) bicee_r2d(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
+        else bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
+        if (lat) {  // decompress_united ends here: y_hat back to the caller
+            out0 = yhat_r;
+            out1 = yhat_d;
+        } else {
+            if (variant == 2) g_s_stf(yhat_r, yhat_d, &out0, &out1);
+            else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &out0, &out1);
+            else g_s(yhat_r, yhat_d, &out0, &out1);
+        }
+        if (cur_ge && !dry()) {
+            cur_ge->out[0] = out0;
+            cur_ge->out[1] = out1;
+        }
+    } else {
+        out0 = cur_ge->out[0];
+        out1 = cur_ge->out[1];
     }
-    Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
-    if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
-        int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
-        if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
-        if (zr) fail(zr);
-    }
-    named["yhat_r"] = yhat_r;
-    named["yhat_d"] = yhat_d;
-    Coding cd;
-    cd.encode = false;
-    cd.per_image = per_image;
-    cd.per_image_total = T;
-    cd.sym = sym;
-    cd.idx = idx;
-    cd.stream_base = d_ybase;
-    cd.words = words;
-    cd.stream_off = d_yoff;
-    cd.stream_len = d_ylen;
-    cd.state = state;
-    cd.nstreams = ns_y;
-    if (variant == 3) bicee_r2d(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
-    else bicee(cd, nullptr, nullptr, hyp_r, hyp_d, yhat_r, yhat_d);
-    if (lat) {  // decompress_united ends here: y_hat back to the caller (NCHW)
+    {
+        const int r = body_end();
         if (rc) return rc;
-        if (dry()) return RGBD_OK;
-        int r = launch_nhwc_to_nchw_clamp(yhat_r.p, B, M, h, w, yhat_r.cs, lat->yhat[0], 0, s);
-        if (!r) r = launch_nhwc_to_nchw_clamp(yhat_d.p, B, M, h, w, yhat_d.cs, lat->yhat[1], 0, s);
+        if (r) return r;
+    }
+    if (dry()) return RGBD_OK;
+
+    // ==== epilogue (never captured): results into the caller's NCHW tensors ==========================================
+    if (lat) {
+        int r = launch_nhwc_to_nchw_clamp(out0.p, B, M, h, w, out0.cs, lat->yhat[0], 0, s);
+        if (!r) r = launch_nhwc_to_nchw_clamp(out1.p, B, M, h, w, out1.cs, lat->yhat[1], 0, s);
         return r;
     }
-
-    Act xr, xd;
-    if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
-    else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &xr, &xd);
-    else g_s(yhat_r, yhat_d, &xr, &xd);
-    if (rc) return rc;
-    if (dry()) return RGBD_OK;
-    int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 1, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 1, s);
+    int r = launch_nhwc_to_nchw_clamp(out0.p, B, 3, H, W, out0.cs, xr_dev, 1, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(out1.p, B, 1, H, W, out1.cs, xd_dev, 1, s);
     return r;
 }
 
@@ -1919,6 +2114,30 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
     return launch_nhwc_to_nchw_clamp(xh.p, B, in_ch, H, W, xh.cs, x_out, 0, s);  // elic.py:318-325: not clamped
 }
 
+// One call = a sizing pass over the layer graph (workspace high-water mark; skipped when a cached HIP graph of this call
+// shape exists, which implies the workspace already fits) and the real pass.
+template <class F>
+static int run_sized(rgbd_elic* m, const std::string& key, F&& run)
+{
+    rgbd_elic::GraphEntry* ge = m->graph_entry(key);
+    if (!(ge && ge->exec)) {
+        m->cur_ge = nullptr;
+        m->arena.dry = true;
+        m->arena.top = m->arena.peak = 0;
+        int r = run();
+        m->arena.dry = false;
+        if (r) return r;
+        r = m->ensure_arena(m->arena.peak);  // a re-allocation drops every cached graph
+        if (r) return r;
+        ge = m->graph_entry(key);
+    }
+    m->cur_ge = ge;
+    const int r = run();
+    if (r) m->body_abort();
+    m->cur_ge = nullptr;
+    return r;
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -1965,6 +2184,7 @@ int rgbd_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, ui
 int rgbd_tables_create(const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
                        int32_t n_cdf, rgbd_tables** out)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!out) return RGBD_EINVAL;
     std::unique_ptr<rgbd_tables> t(new rgbd_tables());
     const int r = build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &t->ts);
@@ -1978,6 +2198,7 @@ int rgbd_tables_create(const int32_t* cdf, int32_t cdf_stride, const int32_t* cd
 
 void rgbd_tables_destroy(rgbd_tables* t)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!t) return;
     if (t->ts.blob) (void)hipFree(t->ts.blob);
     delete t;
@@ -1990,6 +2211,7 @@ int64_t rgbd_rans_max_bytes(int64_t n) { return 4 * enc_cap_words(n); }
 int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t* indexes, int64_t n, uint8_t* out,
                      int64_t cap, int64_t* out_len)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!t || !t->ts.ready || n < 0 || !out || !out_len || (n && (!symbols || !indexes))) return RGBD_EINVAL;
     for (int64_t i = 0; i < n; ++i)
         if (indexes[i] < 0 || indexes[i] >= t->ts.d.nrows) return RGBD_EINVAL;
@@ -2062,6 +2284,7 @@ int rgbd_rans_decoder_create(rgbd_rans_decoder** out)
 
 int rgbd_rans_decoder_set_stream(rgbd_rans_decoder* d, const uint8_t* stream, int64_t nbytes)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!d || !stream || nbytes < 8 || (nbytes & 3)) return RGBD_EINVAL;
     if (d->words) (void)hipFree(d->words);
     d->words = nullptr;
@@ -2077,6 +2300,7 @@ int rgbd_rans_decoder_set_stream(rgbd_rans_decoder* d, const uint8_t* stream, in
 int rgbd_rans_decoder_decode(rgbd_rans_decoder* d, const rgbd_tables* t, const int32_t* indexes, int64_t n,
                              int32_t* symbols_out)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!d || !d->words || !t || !t->ts.ready || n < 0 || (n && (!indexes || !symbols_out))) return RGBD_EINVAL;
     if (!n) return RGBD_OK;
     for (int64_t i = 0; i < n; ++i)
@@ -2099,6 +2323,7 @@ int rgbd_rans_decoder_decode(rgbd_rans_decoder* d, const rgbd_tables* t, const i
 
 void rgbd_rans_decoder_destroy(rgbd_rans_decoder* d)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!d) return;
     (void)hipFree(d->words);
     (void)hipFree(d->meta);
@@ -2110,6 +2335,7 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
                      const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
                      int32_t act, const float* residual_dev, float* y_dev, void* stream)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!x_dev || !weight || !y_dev || n <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k > 5 || stride < 1 || stride > 2)
         return RGBD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -2192,6 +2418,7 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
 int rgbd_debug_force_tile(const char* cfg)
 {
     snprintf(g_conv_force, sizeof(g_conv_force), "%s", cfg ? cfg : "");
+    ++g_cfg_epoch;
     return RGBD_OK;
 }
 
@@ -2216,12 +2443,14 @@ int rgbd_debug_force_ckbd(int32_t part)
 {
     if (part < 0 || part > 2) return RGBD_EINVAL;
     g_force_ckbd = part;
+    ++g_cfg_epoch;
     return RGBD_OK;
 }
 
 int rgbd_debug_force_splitk(int32_t s)
 {
     g_force_splitk = s;
+    ++g_cfg_epoch;
     return RGBD_OK;
 }
 
@@ -2229,6 +2458,7 @@ int rgbd_debug_force_splitk(int32_t s)
 int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                     int32_t transposed, int32_t with_residual, int32_t iters, float* ms_out)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!ms_out || n <= 0 || iters <= 0) return RGBD_EINVAL;
     HostTensor hw;
     hw.shape = transposed ? std::vector<int64_t>{cin, cout, k, k} : std::vector<int64_t>{cout, cin, k, k};
@@ -2454,9 +2684,14 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
 
 void rgbd_elic_destroy(rgbd_elic* m)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m) return;
     // weights, tables and the scale table belong to shared generations (DevGen) that go when their last user does
+    m->graphs_invalidate();
     if (m->arena.base) (void)hipFree(m->arena.base);
+    if (m->pin) (void)hipHostFree(m->pin);
+    if (m->pin_ev) (void)hipEventDestroy(m->pin_ev);
+    if (m->done_ev) (void)hipEventDestroy(m->done_ev);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
 }
@@ -2480,6 +2715,7 @@ int rgbd_elic_set_tensor(rgbd_elic* m, const char* name, const float* data, cons
 int rgbd_elic_set_tables(rgbd_elic* m, int32_t which, const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes,
                          const int32_t* offsets, int32_t n_cdf)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m || which < 0 || which > 3) return RGBD_EINVAL;
     TableSet fresh;
     const int r = build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &fresh);
@@ -2496,6 +2732,7 @@ int rgbd_elic_set_tables(rgbd_elic* m, int32_t which, const int32_t* cdf, int32_
 
 int rgbd_elic_set_scale_table(rgbd_elic* m, const float* table, int32_t n)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m || !table || n != 64) return RGBD_EINVAL;
     float* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, 64 * sizeof(float)));
@@ -2516,6 +2753,7 @@ static bool ends_with(const std::string& s, const char* suf)
 
 int rgbd_elic_finalize(rgbd_elic* m)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m) return RGBD_EINVAL;
     // a shared-weight clone has no host tensors of its own: re-finalising it would only drop the weights it borrows
     if (m->is_clone && m->raw.empty()) return RGBD_ESTATE;
@@ -2634,14 +2872,9 @@ int rgbd_elic_compress(rgbd_elic* m, const float* rgb_dev, const float* depth_de
     if (!rgb_dev || !depth_dev || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64) return RGBD_EINVAL;
     m->s = (hipStream_t)stream;
     const int per_image = (per_image_streams || B == 1) ? 1 : 0;
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    r = m->run_compress(rgb_dev, depth_dev, B, H, W, per_image);
+    char key[96];
+    snprintf(key, sizeof(key), "c|%d|%d|%d|%d", B, H, W, per_image);
+    r = run_sized(m, key, [&]() { return m->run_compress(rgb_dev, depth_dev, B, H, W, per_image); });
     if (m->profile) m->profile_collect();  // run_compress ends with a stream synchronise
     return r;
 }
@@ -2697,18 +2930,12 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
     const int64_t* yl[2] = {y_rgb_len, y_depth_len};
     const uint8_t* const* zs[2] = {z_rgb, z_depth};
     const int64_t* zl[2] = {z_rgb_len, z_depth_len};
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    r = m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev);
-    if (m->profile && !r) {
-        if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
-        m->profile_collect();
-    }
+    char key[96];
+    snprintf(key, sizeof(key), "d|%d|%d|%d|%d", B, zh, zw, n_y);
+    r = run_sized(m, key, [&]() { return m->run_decompress(ys, yl, n_y, zs, zl, B, zh, zw, xr_dev, xd_dev); });
+    // the caller's wait for x_hat happens here, on an event the host thread sleeps on (a pooled rank has 16 of them)
+    if (!r) r = m->wait_stream();
+    if (m->profile && !r) m->profile_collect();
     return r;
 }
 
@@ -2723,14 +2950,9 @@ int rgbd_elic_compress_united(rgbd_elic* m, const float* y_rgb_dev, const float*
     m->s = (hipStream_t)stream;
     const int per_image = (per_image_streams || B == 1) ? 1 : 0;
     rgbd_elic::Latents lat = {{y_rgb_dev, y_depth_dev}, {hyper_rgb_dev, hyper_depth_dev}, {nullptr, nullptr}};
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_compress(nullptr, nullptr, B, h * 16, w * 16, per_image, &lat);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    r = m->run_compress(nullptr, nullptr, B, h * 16, w * 16, per_image, &lat);
+    char key[96];
+    snprintf(key, sizeof(key), "cu|%d|%d|%d|%d", B, h, w, per_image);
+    r = run_sized(m, key, [&]() { return m->run_compress(nullptr, nullptr, B, h * 16, w * 16, per_image, &lat); });
     if (m->profile) m->profile_collect();
     return r;
 }
@@ -2752,18 +2974,11 @@ int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const
     const uint8_t* const* zs[2] = {nullptr, nullptr};
     const int64_t* zl[2] = {nullptr, nullptr};
     rgbd_elic::Latents lat = {{nullptr, nullptr}, {hyper_rgb_dev, hyper_depth_dev}, {yhat_rgb_dev, yhat_depth_dev}};
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_decompress_impl(ys, yl, n_y, zs, zl, B, h, w, nullptr, nullptr, &lat);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    r = m->run_decompress_impl(ys, yl, n_y, zs, zl, B, h, w, nullptr, nullptr, &lat);
-    if (m->profile && !r) {
-        if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
-        m->profile_collect();
-    }
+    char key[96];
+    snprintf(key, sizeof(key), "du|%d|%d|%d|%d", B, h, w, n_y);
+    r = run_sized(m, key, [&]() { return m->run_decompress_impl(ys, yl, n_y, zs, zl, B, h, w, nullptr, nullptr, &lat); });
+    if (!r) r = m->wait_stream();
+    if (m->profile && !r) m->profile_collect();
     return r;
 }
 
@@ -2805,6 +3020,7 @@ int rgbd_elic_profile_read(rgbd_elic* m, double* conv_ms, int64_t* launches, dou
 
 int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t cap_floats, int32_t* shape_out)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m || !name || !shape_out) return RGBD_EINVAL;
     auto it = m->named.find(name);
     if (it == m->named.end()) return RGBD_EINVAL;
@@ -2826,6 +3042,7 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
 
 int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m || !n || modality < 0 || modality > 1 || !m->dbg_sym) return RGBD_EINVAL;
     *n = m->dbg_per_mod;
     if (!symbols || !indexes) return RGBD_OK;
