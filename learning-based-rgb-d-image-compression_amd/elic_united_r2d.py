@@ -20,12 +20,6 @@ class ELIC_united_R2D(ELIC_united):
         check(lib().rgbd_elic_create_r2d(self.N, self.M, sl, len(self.slice_ch), ctypes.byref(h)), "elic_create_r2d")
         return h
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("eval-mode forward() is built for ELIC_united and STF_united")
-
-    __call__ = forward
-
-    def compress_united(self, *a, **k):
-        raise NotImplementedError("the stage-level entry points are built for ELIC_united")
-
-    decompress_united = compress_united
+    # forward(), compress_united() and decompress_united() are inherited, exactly as in the reference
+    # (models/elic_united_R2D.py overrides only the per-slice coders of models/elic_united.py): the engine created above
+    # (variant "r2d") runs the one-directional slice coder and the single-input hyper synthesis behind them.

@@ -1,8 +1,10 @@
 """Quality metrics of the reference harness (utils/metrics.py:8-30).
 
 PSNR follows the reference exactly (MSE of the clamped tensors).  MS-SSIM restates the published definition that
-pytorch_msssim implements (11-tap Gaussian, sigma 1.5, five scales, default weights); pytorch_msssim is not installed in
-the build image, so that number is NOT pinned against the reference.
+pytorch-msssim 1.0.0 (requirements.txt:48) implements (11-tap Gaussian, sigma 1.5, five scales, default weights); that
+package is not installable in the build image, so the number is not pinned against the package itself -- it is checked
+against an independent numpy fp64 statement of the definition (oracle/msssim_ref.py, tests/test_host_logic.py) and the
+harness log says so.
 """
 import numpy as np
 import torch

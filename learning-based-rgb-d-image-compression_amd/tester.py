@@ -234,6 +234,8 @@ class TesterUnited:
             f"Avg rPSNR: {meters['avg_rgb_psnr'].avg:.7f} | Avg dPSNR: {meters['avg_depth_psnr'].avg:.7f} | "
             f"Avg rMS-SSIM: {meters['avg_rgb_ms_ssim'].avg:.7f} | Avg dMS-SSIM: {meters['avg_depth_ms_ssim'].avg:.7f} | "
             f"Avg Encoding Latency: {meters['avg_encode_time'].avg:.6f} | Avg Decoding latency: {meters['avg_deocde_time'].avg:.6f}")
+        self.logger_test.info("MS-SSIM: pytorch-msssim 1.0.0's published definition restated (metrics.py; cross-checked in fp64 by "
+                              "oracle/msssim_ref.py) -- not part of the pinned parity set; bpp and PSNR are")
         if workers > 1:
             self.logger_test.info(f"Job throughput with {workers} images in flight: {self.job_mpx_per_s:.3f} Mpx/s (enc+dec+I/O)")
         return rows, meters

@@ -218,10 +218,20 @@ def stf_case(model_config, synth, name, B, H, W, config_id):
         y_r, y_d = net.g_a(r, d)
         out = net.compress(r, d)
         dec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+        fw = net(r, d)  # eval-mode forward (inherited models/elic_united.py:234-263 over the R2D slice coder)
+        # the Bi-CEE stage alone (inherited compress_united / decompress_united, elic_united.py:350-401,543-578)
+        lat = [torch.from_numpy(a) for a in synth.synthetic_latents(1, 8, 12, 320, 6)]
+        cu = net.compress_united(lat[0], lat[1], lat[2], lat[3])
+        du = net.decompress_united(cu[0][0], lat[1], cu[1][0], lat[3])
     g = {"B": B, "H": H, "W": W, "config_id": config_id, "shape": np.array(tuple(out["shape"]), np.int32),
          "r_y": np.frombuffer(out["r_strings"][0][0], np.uint8), "d_y": np.frombuffer(out["d_strings"][0][0], np.uint8),
          "r_z0": np.frombuffer(out["r_strings"][1][0], np.uint8), "d_z0": np.frombuffer(out["d_strings"][1][0], np.uint8),
          "y_r": y_r.numpy(), "y_d": y_d.numpy(),
+         "fw_xhat_r_sub": fw["x_hat"]["r"][:, :, ::4, ::4].numpy(), "fw_xhat_d_sub": fw["x_hat"]["d"][:, :, ::4, ::4].numpy(),
+         "lik_y_r": fw["r_likelihoods"]["y"].numpy(), "lik_y_d": fw["d_likelihoods"]["y"].numpy(),
+         "lik_z_r": fw["r_likelihoods"]["z"].numpy(), "lik_z_d": fw["d_likelihoods"]["z"].numpy(),
+         "cu_seed": 6, "cu_r_y": np.frombuffer(cu[0][0], np.uint8), "cu_d_y": np.frombuffer(cu[1][0], np.uint8),
+         "cu_yhat_r": du[0].numpy(), "cu_yhat_d": du[1].numpy(),
          "xhat_r_sub": dec["x_hat"]["r"][:, :, ::4, ::4].numpy(), "xhat_d_sub": dec["x_hat"]["d"][:, :, ::4, ::4].numpy(),
          "psnr": np.array([-10 * np.log10(torch.mean((dec["x_hat"]["r"] - r) ** 2).item()),
                            -10 * np.log10(torch.mean((dec["x_hat"]["d"] - d) ** 2).item())], np.float64)}
@@ -243,10 +253,20 @@ def r2d_case(model_config, synth, name, B, H, W, config_id):
         y_r, y_d = net.g_a(r, d)
         out = net.compress(r, d)
         dec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+        fw = net(r, d)  # eval-mode forward (inherited models/elic_united.py:234-263 over the R2D slice coder)
+        # the Bi-CEE stage alone (inherited compress_united / decompress_united, elic_united.py:350-401,543-578)
+        lat = [torch.from_numpy(a) for a in synth.synthetic_latents(1, 8, 12, 320, 6)]
+        cu = net.compress_united(lat[0], lat[1], lat[2], lat[3])
+        du = net.decompress_united(cu[0][0], lat[1], cu[1][0], lat[3])
     g = {"B": B, "H": H, "W": W, "config_id": config_id, "shape": np.array(tuple(out["shape"]), np.int32),
          "r_y": np.frombuffer(out["r_strings"][0][0], np.uint8), "d_y": np.frombuffer(out["d_strings"][0][0], np.uint8),
          "r_z0": np.frombuffer(out["r_strings"][1][0], np.uint8), "d_z0": np.frombuffer(out["d_strings"][1][0], np.uint8),
          "y_r": y_r.numpy(), "y_d": y_d.numpy(),
+         "fw_xhat_r_sub": fw["x_hat"]["r"][:, :, ::4, ::4].numpy(), "fw_xhat_d_sub": fw["x_hat"]["d"][:, :, ::4, ::4].numpy(),
+         "lik_y_r": fw["r_likelihoods"]["y"].numpy(), "lik_y_d": fw["d_likelihoods"]["y"].numpy(),
+         "lik_z_r": fw["r_likelihoods"]["z"].numpy(), "lik_z_d": fw["d_likelihoods"]["z"].numpy(),
+         "cu_seed": 6, "cu_r_y": np.frombuffer(cu[0][0], np.uint8), "cu_d_y": np.frombuffer(cu[1][0], np.uint8),
+         "cu_yhat_r": du[0].numpy(), "cu_yhat_d": du[1].numpy(),
          "xhat_r_sub": dec["x_hat"]["r"][:, :, ::4, ::4].numpy(), "xhat_d_sub": dec["x_hat"]["d"][:, :, ::4, ::4].numpy(),
          "psnr": np.array([-10 * np.log10(torch.mean((dec["x_hat"]["r"] - r) ** 2).item()),
                            -10 * np.log10(torch.mean((dec["x_hat"]["d"] - d) ** 2).item())], np.float64)}
@@ -259,6 +279,10 @@ def main():
     ELIC, model_config, ext = rl.load_reference()
     import rgbd_amd  # noqa: F401
     from rgbd_amd import synth
+
+    if "--only-r2d" in sys.argv:  # refresh one fixture without touching the others
+        r2d_case(model_config, synth, "128x192", 1, 128, 192, 4)
+        return
 
     net = ELIC(config=model_config(), channel=4).eval()
     sd = synth.synthetic_state_dict(0)

@@ -84,3 +84,33 @@ def test_r2d_128x192(net_r2d, sd_r2d):
     d2 = torch.from_numpy(synth.synthetic_batch(1, 128, 192, config_id=44)[1])
     out2 = net_r2d.compress(r.cuda(), d2.cuda())
     assert out2["r_strings"] == out["r_strings"] and out2["d_strings"] != out["d_strings"]
+
+
+def test_r2d_forward_and_stage_entry_points(net_r2d, sd_r2d):
+    """models/elic_united_R2D.py inherits forward() / compress_united() / decompress_united() from ELIC_united; here they
+    run on the R2D engine variant and are checked against the reference's golden outputs."""
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "r2d_128x192.npz"))
+    r, d = synth.synthetic_batch(1, 128, 192, config_id=4)
+    r, d = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+    fw = net_r2d(r, d)
+    out = net_r2d.compress(r, d)
+    rec = net_r2d.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    # eval forward == decompress(compress()) bit for bit (before the clamp), and both match the reference
+    assert torch.equal(fw["x_hat"]["r"].clamp(0, 1), rec["x_hat"]["r"]) and torch.equal(fw["x_hat"]["d"].clamp(0, 1), rec["x_hat"]["d"])
+    assert (fw["x_hat"]["r"].cpu()[:, :, ::4, ::4] - torch.from_numpy(g["fw_xhat_r_sub"])).abs().max() < 1e-4
+    assert (fw["x_hat"]["d"].cpu()[:, :, ::4, ::4] - torch.from_numpy(g["fw_xhat_d_sub"])).abs().max() < 1e-4
+    for mod in ("r", "d"):
+        np.testing.assert_allclose(fw[f"{mod}_likelihoods"]["z"].cpu().numpy(), g[f"lik_z_{mod}"], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(fw[f"{mod}_likelihoods"]["y"].cpu().numpy(), g[f"lik_y_{mod}"], rtol=2e-3, atol=1e-6)
+    # the Bi-CEE stage alone on given latents: streams identical to the reference's, y_hat within the float tolerance
+    lat = [torch.from_numpy(a).cuda() for a in synth.synthetic_latents(1, 8, 12, 320, int(g["cu_seed"]))]
+    sr, sdp = net_r2d.compress_united(lat[0], lat[1], lat[2], lat[3])
+    assert sr[0] == g["cu_r_y"].tobytes() and sdp[0] == g["cu_d_y"].tobytes()
+    yh_r, yh_d = net_r2d.decompress_united(sr[0], lat[1], sdp[0], lat[3])
+    assert _rel(yh_r.cpu().numpy(), g["cu_yhat_r"]) < 2e-5 and _rel(yh_d.cpu().numpy(), g["cu_yhat_d"]) < 2e-5
+    # the RGB stream of the stage does not depend on the depth latents
+    lat2 = [torch.from_numpy(a).cuda() for a in synth.synthetic_latents(1, 8, 12, 320, 77)]
+    sr2, _ = net_r2d.compress_united(lat[0], lat[1], lat2[2], lat2[3])
+    assert sr2[0] == sr[0]

@@ -176,3 +176,27 @@ def test_tile_table_is_well_formed(table):
         assert (wm, mt, nt) in tiles and kc in (16, 64) and dma in (0, 1, 2, 3) and not (dma and kc == 64), ln
         assert all(x > 0 for x in key) and key[3] % 16 == 0 and key[4] % 16 == 0 and key[7] in (1, 4, 11, 21), ln  # 11 / 21: checkerboard-output launches (nphase + 10 * ckbd)
     assert keys
+
+
+def test_ms_ssim_against_the_definition():
+    """utils/metrics.py:13 calls pytorch_msssim (1.0.0, not installable here): the product's torch restatement is checked
+    against an independent numpy fp64 statement of the published definition (oracle/msssim_ref.py) -- unpinned against the
+    package itself, which the harness log line says too."""
+    import torch
+
+    from oracle import msssim_ref
+    from rgbd_amd import metrics, synth
+
+    for (h, w, cid, noise) in ((176, 208, 3, 0.05), (161, 193, 4, 0.2), (256, 256, 5, 0.01)):
+        r, d = synth.synthetic_pair(cid, h, w, config_id=cid, smooth=True)
+        a = torch.from_numpy(r)[None].float()
+        rng = np.random.RandomState(cid)
+        b = (a + noise * torch.from_numpy(rng.standard_normal(a.shape).astype(np.float32))).clamp(0, 1)
+        got = metrics.ms_ssim(a, b, data_range=1.0)
+        want = msssim_ref.ms_ssim(a.numpy(), b.numpy(), 1.0)
+        assert abs(got - want) < 2e-5, (h, w, got, want)
+        assert 0.0 < got < 1.0
+        a1 = torch.from_numpy(d)[None].float()
+        assert abs(metrics.ms_ssim(a1, a1) - 1.0) < 1e-6
+    with pytest.raises(ValueError):
+        metrics.ms_ssim(torch.zeros(1, 1, 160, 300), torch.zeros(1, 1, 160, 300))
