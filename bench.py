@@ -221,45 +221,72 @@ def main():
     rgb, depth, padded = make_inputs(B, H, W, cid)
     elapsed, last = timed(rgb, depth, args.steps, args.warmup)
 
-    # ---- conv profile, separate pass (not in the timed region): one engine instance, nothing else on the chip --------
+    # ---- conv profile, separate passes (not in the timed region): one engine instance, nothing else on the chip.  Twice:
+    # with the tiles the timed region ran (throughput tiles when the chip is shared) and with the latency tiles, which
+    # is what a lone engine instance runs by default (tile choice never changes a result bit, only the speed).
     solo = net.nets[0]
-    solo.set_profile(True)
-    for _ in range(2):
-        o = solo.compress(rgb, depth)
-        solo.decompress(o["r_strings"], o["d_strings"], o["shape"])
-    prof1 = solo.profile_read()
-    solo.set_profile(False)
+
+    def conv_pass(mode):
+        solo.set_tile_mode(mode)
+        solo.set_profile(True)
+        for _ in range(2):
+            o = solo.compress(rgb, depth)
+            solo.decompress(o["r_strings"], o["d_strings"], o["shape"])
+        p = solo.profile_read()
+        solo.set_profile(False)
+        return p
+
+    prof1 = conv_pass(tile_mode)
+    prof_lat = prof1 if tile_mode == "latency" else conv_pass("latency")
+    solo.set_tile_mode(tile_mode)
     flops_step = prof1["flops"] / 2.0
     launches_step = prof1["launches"] // 2
 
     extras = world == 1 and not args.no_extras
-    latency = None
-    if extras:
-        # ---- the reference tester's calling pattern: one image per call, one engine instance, synchronised windows ------
-        solo.set_tile_mode("latency")
-        n_img = 8
+    latency = latency_tl = None
+
+    def tester_latency(one, n_img=8):
+        """The reference tester's calling pattern: one image per call, one engine instance, synchronised windows."""
         rl, dl, _ = make_inputs(n_img, H, W, cid + 100)
-        for i in range(2):  # size the workspace for B=1
-            o = solo.compress(rl[:1], dl[:1])
-            solo.decompress(o["r_strings"], o["d_strings"], o["shape"])
+        for i in range(2):  # size the workspace for B=1; the second call captures the HIP graphs
+            o = one.compress(rl[:1], dl[:1])
+            one.decompress(o["r_strings"], o["d_strings"], o["shape"])
         enc = dec = 0.0
+        nbytes = 0
         for i in range(n_img):
             torch.cuda.synchronize()
             t0 = time.time()
-            o = solo.compress(rl[i:i + 1], dl[i:i + 1])
+            o = one.compress(rl[i:i + 1], dl[i:i + 1])
             torch.cuda.synchronize()
             t1 = time.time()
-            solo.decompress(o["r_strings"], o["d_strings"], o["shape"])
+            one.decompress(o["r_strings"], o["d_strings"], o["shape"])
             torch.cuda.synchronize()
             t2 = time.time()
             enc += t1 - t0
             dec += t2 - t1
-        latency = {"value": round(n_img * H * W / (enc + dec) / 1e6, 4), "unit": "Mpx/s", "images": n_img, "batch": 1,
-                   "engine_instances": 1, "enc_ms_per_image": round(enc / n_img * 1e3, 2),
-                   "dec_ms_per_image": round(dec / n_img * 1e3, 2),
-                   "definition": "sum(H*W) / (sum(enc) + sum(dec)), torch.cuda.synchronize() around compress() and "
-                                 "decompress() as in testing/tester_united.py:142-147,180-186"}
+            nbytes += sum(len(s) for k in ("r_strings", "d_strings") for lst in o[k] for s in lst)
+        return {"value": round(n_img * H * W / (enc + dec) / 1e6, 4), "unit": "Mpx/s", "images": n_img, "batch": 1,
+                "engine_instances": 1, "enc_ms_per_image": round(enc / n_img * 1e3, 2),
+                "dec_ms_per_image": round(dec / n_img * 1e3, 2), "bpp_rgb_plus_depth": round(nbytes * 8.0 / (n_img * H * W), 3),
+                "definition": "sum(H*W) / (sum(enc) + sum(dec)), torch.cuda.synchronize() around compress() and "
+                              "decompress() as in testing/tester_united.py:142-147,180-186"}
+
+    if extras:
+        solo.set_tile_mode("latency")
+        latency = tester_latency(solo)
+        latency["weights"] = "synthetic seed 0 (stress recipe: ~22 bpp, wide CDF rows, 17 % escapes)"
         solo.set_tile_mode(tile_mode)
+        if model == "ELIC_united":
+            # the same pass at a trained model's operating point (rates of ~1.5 bpp per modality, narrow CDF rows): the serial
+            # entropy coder, which bounds a single image's latency, is much cheaper per symbol there
+            tl = rgbd_amd.modelZoo[model](config=rgbd_amd.model_config(), channel=4).eval()
+            tl.load_state_dict(synth.synthetic_state_dict(0, model=model, recipe="trained_like"))
+            tl.update(force=True)
+            tl = tl.to(dev)
+            tl.per_image_streams = True
+            latency_tl = tester_latency(tl)
+            latency_tl["weights"] = "synthetic seed 0 (trained_like recipe)"
+            del tl
 
     second = None
     if extras and args.workload == "c3_4x480x640":
@@ -282,7 +309,8 @@ def main():
         px = world * B * H * W * args.steps
         bytes_y = sum(len(s) for s in last["r_strings"][0] + last["d_strings"][0])
         job_tflops = flops_step * args.steps / elapsed / 1e12
-        iso_tflops = prof1["flops"] / (prof1["conv_ms"] / 1e3) / 1e12
+        iso_tflops = prof_lat["flops"] / (prof_lat["conv_ms"] / 1e3) / 1e12
+        iso_tp_tflops = prof1["flops"] / (prof1["conv_ms"] / 1e3) / 1e12
         res = {
             "metric": "RGB-D Mpixels/s encode+decode",
             "value": round(px / elapsed / 1e6, 4),
@@ -318,13 +346,20 @@ def main():
                              "note": "PMC HBM bytes of the conv launches of one step / step time: the path is MFMA-bound"},
                          "launches_per_step": launches_step, "gflop_per_step": round(flops_step / 1e9, 2),
                          "isolated": {"achieved": round(iso_tflops, 3), "frac": round(iso_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                                      "avg_launch_us": round(prof1["conv_ms"] * 1e3 / max(prof1["launches"], 1), 2),
-                                      "conv_ms_per_step": round(prof1["conv_ms"] / 2, 3),
+                                      "avg_launch_us": round(prof_lat["conv_ms"] * 1e3 / max(prof_lat["launches"], 1), 2),
+                                      "conv_ms_per_step": round(prof_lat["conv_ms"] / 2, 3), "conv_tiles": "latency",
                                       "note": "HIP events around every conv launch on its stream, single engine instance, "
-                                              "no concurrent kernels, separate pass after the timed region"}},
+                                              "no concurrent kernels, separate pass after the timed region, latency tiles "
+                                              "(what a lone instance runs); profiles/r02_bench_w1_summary.txt"},
+                         "isolated_timed_tiles": {"achieved": round(iso_tp_tflops, 3),
+                                                  "frac": round(iso_tp_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                                                  "conv_ms_per_step": round(prof1["conv_ms"] / 2, 3), "conv_tiles": tile_mode,
+                                                  "note": "the same pass with the tiles the timed region ran"}},
         }
         if latency is not None:
             res["latency"] = latency
+        if latency_tl is not None:
+            res["latency_trained_like"] = latency_tl
         if second is not None:
             res["workloads"] = [{"workload": args.workload, "value": res["value"], "unit": "Mpx/s",
                                  "ms_per_step": res["ms_per_step"], "images_per_gpu": B, "image": [H, W]}, second]
@@ -333,6 +368,7 @@ def main():
             res["cpu_baseline"] = cpu
             res["vs_cpu"] = {"throughput": round(res["value"] / cpu["value"], 2),
                              "latency_tester_semantics": None if latency is None else round(latency["value"] / cpu["value"], 2),
+                             "latency_tester_semantics_trained_like": None if latency_tl is None else round(latency_tl["value"] / cpu["value"], 2),
                              "note": "both over the CPU oracle at B=1 tester semantics (best pair); north-star target >= 40x"}
             if second is not None:
                 cpu2 = cpu_baseline(sd, 256, 256, 2, model, seconds_budget=8.0)

@@ -101,9 +101,16 @@ def make_tensor(name: str, e: Entry, seed: int) -> np.ndarray:
 
 
 def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_torch: bool = True,
-                         model: str = "ELIC_united", channel: int = 3):
+                         model: str = "ELIC_united", channel: int = 3, recipe: str = None):
     """Full state_dict (parameters + buffers) of ELIC_united (default) or the single-modal ELIC with deterministic
-    synthetic values."""
+    synthetic values.  `recipe`: "stress" (= stress=True, the default: ~22 bpp, wide CDF rows, 17 % escapes -- the worst
+    case for the entropy coder), "trained_like" (ELIC_united only: latents mostly inside the dead zone, scales near the
+    bottom of the scale table, ~1 bpp per modality like a trained q=2_2 model -- the coder's realistic operating point) or
+    "plain" (default initialisation, everything quantises to zero)."""
+    if recipe is not None:
+        if recipe not in ("stress", "trained_like", "plain"):
+            raise ValueError(f"unknown recipe {recipe}")
+        stress = recipe == "stress"
     if model == "STF_united":
         cfg = stf_config()
         entries = stf_united_entries()
@@ -122,6 +129,10 @@ def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_tor
             sd[f"g_a.{mod}_ana_layers.4.downsample.reduction.weight"] *= np.float32(STF_Y_GAIN)
     elif stress:
         _apply_stress_single(sd, cfg)
+    if recipe == "trained_like":
+        if model != "ELIC_united":
+            raise ValueError("the trained_like recipe is defined for ELIC_united")
+        _apply_trained_like(sd, cfg)
     if as_torch:
         import torch
 
@@ -146,6 +157,22 @@ def _apply_stress(sd, cfg, transforms=True):
         for i, c in enumerate(slice_ch):
             sd[f"{fam}.{i}.fusion.4.weight"] *= np.float32(6.0)
             sd[f"{fam}.{i}.fusion.4.bias"][:c] = np.float32(1.0)  # scale half
+
+
+def _apply_trained_like(sd, cfg):
+    """Rates of a trained low-rate model instead of the stress recipe's: |y| of a few tenths (most symbols round to zero,
+    some to +-1/+-2), predicted scales around 0.2-0.4 (scale-table rows of 7-9 entries), small |z|."""
+    slice_ch = list(cfg["slice_ch"])
+    for mod in ("rgb", "depth"):
+        sd[f"g_a.{mod}_analysis_transform.16.weight"] *= np.float32(6.0)
+        sd[f"h_a.{mod}_reduction.4.weight"] *= np.float32(6.0)
+    for m in ("r", "d"):
+        sd[f"h_s.{m}_h_s3.deconv.weight"] *= np.float32(8.0)
+    for fam in ("rgb_entropy_parameters_anchor", "depth_entropy_parameters_anchor",
+                "rgb_entropy_parameters_nonanchor", "depth_entropy_parameters_nonanchor"):
+        for i, c in enumerate(slice_ch):
+            sd[f"{fam}.{i}.fusion.4.weight"] *= np.float32(2.0)
+            sd[f"{fam}.{i}.fusion.4.bias"][:c] = np.float32(0.25)  # scale half
 
 
 def _apply_stress_single(sd, cfg):

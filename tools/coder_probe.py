@@ -19,9 +19,10 @@ cdf, sizes, offsets = gc.numpy_tables()
 t = ans.Tables(cdf, sizes, offsets)
 rng = np.random.default_rng(0)
 scales = np.exp(np.linspace(np.log(0.11), np.log(256), 64))
-for name, lo, hi in (("idx0-7", 0, 8), ("idx16-23", 16, 24), ("idx32-39", 32, 40), ("idx48-55", 48, 56), ("idx0-63", 0, 64)):
+for name, lo, hi, gain in (("idx0-7", 0, 8, 1.0), ("idx16-23", 16, 24, 1.0), ("idx32-39", 32, 40, 1.0), ("idx48-55", 48, 56, 1.0),
+                           ("idx0-63", 0, 64, 1.0), ("stress-like", 0, 40, 3.0), ("zeros", 0, 4, 0.0)):
     idx = rng.integers(lo, hi, N).astype(np.int32)
-    sym = np.rint(rng.normal(0.0, 1.0, N) * scales[idx]).astype(np.int32)
+    sym = np.rint(rng.normal(0.0, 1.0, N) * scales[idx] * gain).astype(np.int32)
     s = ans._encode(t, sym, idx)
     d = ans.RansDecoder()
     d.set_stream(s)
