@@ -199,6 +199,8 @@ def main():
             depth = torch.nn.functional.pad(depth, (0, pw, 0, ph), mode="replicate")
         return rgb.contiguous(), depth.contiguous(), (Hq + ph, Wq + pw)
 
+    host = {}
+
     def timed(rgb, depth, nsteps, nwarm):
         def run(k):
             # every step codes one full batch (compress + decompress); the W engine instances keep W steps in flight, so
@@ -212,14 +214,19 @@ def main():
             run(max(nwarm, min(args.workers, nsteps)))  # every engine instance sizes its workspace once
         distributed.barrier()
         torch.cuda.synchronize()
+        c0 = os.times()
         t0 = time.perf_counter()
         res = run(nsteps)
         torch.cuda.synchronize()
         distributed.barrier()
-        return distributed.max_over_ranks(time.perf_counter() - t0), res[-1][0]
+        dt = time.perf_counter() - t0
+        c1 = os.times()
+        host["cores_busy"] = round(((c1.user - c0.user) + (c1.system - c0.system)) / dt, 2)  # this rank's host threads
+        return distributed.max_over_ranks(dt), res[-1][0]
 
     rgb, depth, padded = make_inputs(B, H, W, cid)
     elapsed, last = timed(rgb, depth, args.steps, args.warmup)
+    host_cores = host.get("cores_busy")
 
     # ---- conv profile, separate passes (not in the timed region): one engine instance, nothing else on the chip.  Twice:
     # with the tiles the timed region ran (throughput tiles when the chip is shared) and with the latency tiles, which
@@ -328,7 +335,8 @@ def main():
                        "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)" if model == "ELIC_united" else "STF_united ch4 (N=192,M=384)",
                        "images_per_gpu": B, "image": [H, W], "padded": list(padded), "weights": "synthetic seed 0 (stress recipe)",
                        "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers,
-                       "conv_tiles": tile_mode},
+                       "conv_tiles": tile_mode, "host_cores_busy_per_rank": host_cores,
+                       "launch": "HIP graph per call shape" if not os.environ.get("RGBD_NO_GRAPH") else "eager"},
             # `achieved`: algorithmic conv FLOPs of the timed steps / wall time of the timed region (job level, a lower
             # bound on MFMA utilisation: the wall clock also holds every other kernel).  With several engine instances
             # sharing the chip a per-launch event bracket would also contain CU time-sharing, so the per-launch figure is

@@ -24,6 +24,11 @@ extern "C" {
 
 int rgbd_abi_version(void);
 
+/* Host-side wait policy of the current HIP device: 1 = host threads that wait for the GPU sleep (blocking sync) instead
+ * of spinning.  No reference counterpart (the reference drives one image at a time from one thread); a pooled rank
+ * keeps 16 host threads waiting on 16 streams, and 8 ranks share one host. */
+int rgbd_set_blocking_sync(int32_t on);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Table construction (host, one-off).
  * Replaces compressai._CXX.pmf_to_quantized_cdf -- CompressAI/compressai/cpp_exts/ops/ops.cpp:24-81, bound at

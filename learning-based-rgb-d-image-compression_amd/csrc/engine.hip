@@ -349,6 +349,8 @@ struct rgbd_elic {
     const bool blocking_wait = getenv("RGBD_SPIN_WAIT") == nullptr;
     hipEvent_t done_ev = nullptr;  // blocking-sync event: the host thread sleeps instead of spinning on the stream
     // pinned staging for the per-call uploads (stream bytes, offsets): truly asynchronous copies, no per-call pinning
+    int64_t* res_pin = nullptr;  // pinned landing buffer of the per-call result sizes
+    static constexpr size_t kResPinBytes = 64 * 1024;
     void* pin = nullptr;
     size_t pin_cap = 0;
     hipEvent_t pin_ev = nullptr;
@@ -1627,25 +1629,31 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     if (dry()) return RGBD_OK;
 
     // ==== epilogue (never captured): fetch the streams ================================================================
-    std::vector<int64_t> ow((size_t)4 * B, 0);  // [y rgb | y depth | z rgb | z depth], B slots each
-    int herr = 0;
-    HIP_TRY(hipMemcpyAsync(ow.data(), meta64 + 8 * B + 4 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(ow.data() + B, meta64 + 8 * B + 5 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
-    if (!lat) HIP_TRY(hipMemcpyAsync(ow.data() + 2 * B, meta64 + 6 * B, sizeof(int64_t) * 2 * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, s));
+    // stream sizes come back through a small pinned buffer: a device-to-host copy into pageable memory is synchronous in
+    // HIP, i.e. the host thread would spin inside it for the whole call; with pinned memory the thread sleeps on an event
+    if (!res_pin) HIP_TRY(hipHostMalloc((void**)&res_pin, kResPinBytes, hipHostMallocDefault));
+    if ((size_t)(4 * B + 2) * sizeof(int64_t) > kResPinBytes) return RGBD_EINVAL;
+    int64_t* ow = res_pin;  // [y rgb | y depth | z rgb | z depth], B slots each, then the error flag
+    memset(ow, 0, (size_t)(4 * B + 2) * sizeof(int64_t));
+    HIP_TRY(hipMemcpyAsync(ow, meta64 + 8 * B + 4 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ow + B, meta64 + 8 * B + 5 * ny, sizeof(int64_t) * ny, hipMemcpyDeviceToHost, s));
+    if (!lat) HIP_TRY(hipMemcpyAsync(ow + 2 * B, meta64 + 6 * B, sizeof(int64_t) * 2 * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ow + 4 * B, err, sizeof(int), hipMemcpyDeviceToHost, s));
     if (const int r = wait_stream()) return r;
-    if (herr) return RGBD_ENOSPC;
+    if ((int)ow[4 * B]) return RGBD_ENOSPC;
     for (int m = 0; m < 2; ++m) {
         streams[m][0].assign(ny, {});
         streams[m][1].assign(lat ? 0 : B, {});
         for (int i = 0; i < ny; ++i) {
             const int64_t nw = ow[(size_t)m * B + i];
+            if (nw < 0 || nw > ycap) return RGBD_EHIP;
             streams[m][0][i].resize((size_t)nw * 4);
             const uint32_t* src = ywords + ((size_t)m * ny + i) * ycap + (ycap - nw);
             HIP_TRY(hipMemcpyAsync(streams[m][0][i].data(), src, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
         }
         for (int i = 0; i < B && !lat; ++i) {
             const int64_t nw = ow[(size_t)2 * B + (size_t)m * B + i];
+            if (nw < 0 || nw > zcap) return RGBD_EHIP;
             streams[m][1][i].resize((size_t)nw * 4);
             const uint32_t* src = zwords + ((size_t)m * B + i) * zcap + (zcap - nw);
             HIP_TRY(hipMemcpyAsync(streams[m][1][i].data(), src, (size_t)nw * 4, hipMemcpyDeviceToHost, s));
@@ -2144,6 +2152,13 @@ static int run_sized(rgbd_elic* m, const std::string& key, F&& run)
 extern "C" {
 
 int rgbd_abi_version(void) { return RGBD_AMD_ABI_VERSION; }
+
+// Host threads that wait for the GPU sleep instead of spinning (hipDeviceScheduleBlockingSync for the current device).
+int rgbd_set_blocking_sync(int32_t on)
+{
+    HIP_TRY(hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto));
+    return RGBD_OK;
+}
 
 // ops.cpp:24-81 restated (host, one-off table construction)
 int rgbd_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, uint32_t* cdf_out)
@@ -2690,6 +2705,7 @@ void rgbd_elic_destroy(rgbd_elic* m)
     m->graphs_invalidate();
     if (m->arena.base) (void)hipFree(m->arena.base);
     if (m->pin) (void)hipHostFree(m->pin);
+    if (m->res_pin) (void)hipHostFree(m->res_pin);
     if (m->pin_ev) (void)hipEventDestroy(m->pin_ev);
     if (m->done_ev) (void)hipEventDestroy(m->done_ev);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);

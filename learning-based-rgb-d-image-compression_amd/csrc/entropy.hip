@@ -911,11 +911,12 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
             //   s[84:85] = x, s[86:87] = scratch pair, v[62:63] = bucket entry
             uint32_t a, start, freq, cum, more;
             {
-                uint32_t lb, t0, t1, e0, m0s;
+                uint32_t lb, t0, t1, e0, m0s, wn;
                 asm volatile(
                     "s_mov_b64 s[84:85], %[x]\n"
                     "s_mov_b32 %[m0s], m0\n"
                     "s_mov_b32 m0, %[j]\n"
+                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"
                     "s_cmp_ge_i32 m0, %[cnt]\n"
                     "s_cbranch_scc1 3f\n"
                     // First level: every lane holds one slot of the symbol's padded cm row (cm = cdf - 1, 0xFFFF
@@ -947,7 +948,29 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_sub_u32 %[freq], %[t1], %[t0]\n"
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
                     "s_sub_u32 %[t0], %[t0], 1\n"               // cum - start
-                    "s_branch 6f\n"
+                    "6:\n"
+                    "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
+                    "s_mul_i32 %[t1], s87, %[freq]\n"
+                    "s_mul_hi_u32 s85, s86, %[freq]\n"
+                    "s_mul_i32 s84, s86, %[freq]\n"
+                    "s_add_u32 %[t1], %[t1], s85\n"
+                    "s_add_u32 s84, s84, %[t0]\n"
+                    "s_addc_u32 s85, %[t1], 0\n"
+                    "v_writelane_b32 %[outv], %[a], m0\n"
+                    "s_lshr_b64 s[86:87], s[84:85], 31\n"      // renormalise when x < 2^31, branch-free: wn = next word
+                    "s_cmp_eq_u64 s[86:87], 0\n"
+                    "s_cselect_b32 s85, s84, s85\n"
+                    "s_cselect_b32 s84, %[wn], s84\n"
+                    "s_addc_u32 %[wi], %[wi], 0\n"             // consumed: advance
+                    "4:\n"
+                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"  // next unread word (lane 64 wraps: never used then)
+                    "s_add_u32 m0, m0, 1\n"
+                    "s_cmp_lt_i32 m0, %[cnt]\n"
+                    "s_cbranch_scc1 1b\n"
+                    "3:\n"
+                    "s_mov_b32 %[more], 0\n"
+                    "s_branch 5f\n"
+                    // out of line: the row's last slot (escape) and rows wider than the 64 lanes (bucket table)
                     "61:\n"
                     "s_sub_u32 %[freq], 0xffff, %[t0]\n"
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
@@ -967,28 +990,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_and_b32 %[a], %[e0], 0xffff\n"
                     "s_cmp_ge_u32 %[t0], %[freq]\n"
                     "s_cbranch_scc1 2f\n"
-                    "6:\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
-                    "s_mul_i32 %[t1], s87, %[freq]\n"
-                    "s_mul_hi_u32 s85, s86, %[freq]\n"
-                    "s_mul_i32 s84, s86, %[freq]\n"
-                    "s_add_u32 %[t1], %[t1], s85\n"
-                    "s_add_u32 s84, s84, %[t0]\n"
-                    "s_addc_u32 s85, %[t1], 0\n"
-                    "v_writelane_b32 %[outv], %[a], m0\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 31\n"      // renormalise when x < 2^31
-                    "s_cmp_lg_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 4f\n"
-                    "s_mov_b32 s85, s84\n"
-                    "v_readlane_b32 s84, %[wcur], %[wi]\n"
-                    "s_add_u32 %[wi], %[wi], 1\n"
-                    "4:\n"
-                    "s_add_u32 m0, m0, 1\n"
-                    "s_cmp_lt_i32 m0, %[cnt]\n"
-                    "s_cbranch_scc1 1b\n"
-                    "3:\n"
-                    "s_mov_b32 %[more], 0\n"
-                    "s_branch 5f\n"
+                    "s_branch 6b\n"
                     // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
                     // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
                     // path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot.
@@ -1104,7 +1106,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_mov_b32 m0, %[m0s]\n"
                     : [x] "+s"(x), [j] "+s"(j), [wi] "+s"(wi), [outv] "+v"(outv), [a] "=&s"(a), [start] "=&s"(start),
                       [freq] "=&s"(freq), [cum] "=&s"(cum), [more] "=&s"(more), [lb] "=&s"(lb), [t0] "=&s"(t0),
-                      [t1] "=&s"(t1), [e0] "=&s"(e0), [m0s] "=&s"(m0s)
+                      [t1] "=&s"(t1), [e0] "=&s"(e0), [m0s] "=&s"(m0s), [wn] "=&s"(wn)
                     : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
                       [lane2] "v"(lane2)
                     : "s84", "s85", "s86", "s87", "s88", "s89", "v58", "v59", "v60", "v62", "v63", "vcc", "scc", "memory");

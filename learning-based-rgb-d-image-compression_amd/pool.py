@@ -22,6 +22,16 @@ class CodecPool:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.nets: List[ELIC_united] = []
         self.streams = []
+        import os
+
+        # Host threads that wait for this GPU sleep instead of spinning (hipDeviceScheduleBlockingSync): a pool keeps W
+        # threads waiting on W streams.  Measured on c3 with 16 instances and HIP-graph launches: 15.1 -> 1.2 busy host
+        # cores per rank at the same throughput (tools/host_cost.sh); RGBD_BLOCKING_SYNC=0 restores the spinning default.
+        if workers > 1 and os.environ.get("RGBD_BLOCKING_SYNC", "1") != "0":
+            from ._lib import check, lib
+
+            torch.cuda.set_device(self.device)
+            check(lib().rgbd_set_blocking_sync(1), "set_blocking_sync")
         for i in range(workers):
             if i == 0:
                 net = model_cls(config=config, channel=4).eval()  # ELIC_united or its Swin variant STF_united

@@ -190,6 +190,10 @@ class TesterUnited:
 
             W = min(workers, n)
             nets = [self.net] + [self.net.clone_shared() for _ in range(W - 1)]
+            if os.environ.get("RGBD_BLOCKING_SYNC", "1") != "0":  # W host threads wait on W streams: sleep, do not spin
+                from ._lib import check, lib
+
+                check(lib().rgbd_set_blocking_sync(1), "set_blocking_sync")
             if W >= 4:
                 for nt in nets:
                     nt.set_tile_mode("throughput")
