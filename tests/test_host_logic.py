@@ -200,3 +200,40 @@ def test_ms_ssim_against_the_definition():
         assert abs(metrics.ms_ssim(a1, a1) - 1.0) < 1e-6
     with pytest.raises(ValueError):
         metrics.ms_ssim(torch.zeros(1, 1, 160, 300), torch.zeros(1, 1, 160, 300))
+
+
+def test_load_state_dict_diagnostics(caplog):
+    """models/elic_united.py:613-620 tries strict loading first and prints what did not match before falling back; here a
+    partial checkpoint is accepted but logged, a DDP 'module.' prefix is stripped, and a checkpoint that matches no
+    parameter at all is an error instead of a silent run on the synthetic initialisation."""
+    import logging
+
+    import rgbd_amd
+    from rgbd_amd import synth
+
+    sd = synth.synthetic_state_dict(0)
+    m = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    m.load_state_dict(sd, strict=True)  # the full reference key set loads strictly
+    # a DataParallel / DDP checkpoint
+    m2 = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    m2.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=True)
+    k0 = "g_a.rgb_analysis_transform.0.weight"
+    assert torch.equal(m2.state_dict()[k0], sd[k0])
+    # partial checkpoint: accepted, but not silently
+    part = {k: v for k, v in sd.items() if not k.startswith("h_s.")}
+    part["not.a.key"] = torch.zeros(1)
+    with caplog.at_level(logging.WARNING, logger="rgbd_amd"):
+        m3 = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+        m3.load_state_dict(part)
+    text = caplog.text
+    assert "missing keys" in text and "h_s." in text and "unexpected keys" in text and "not.a.key" in text
+    with pytest.raises(RuntimeError):
+        m3.load_state_dict(part, strict=True)
+    # nothing matches: an error, not a model that silently runs on its own initialisation
+    with pytest.raises(RuntimeError, match="none of the"):
+        rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).load_state_dict({"encoder.w": torch.zeros(3)})
+    # wrong shape
+    bad = dict(sd)
+    bad[k0] = torch.zeros(5, 5)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).load_state_dict(bad)
