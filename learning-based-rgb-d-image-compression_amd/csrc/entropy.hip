@@ -676,12 +676,20 @@ __global__ __launch_bounds__(64) void rans_encode_kernel2(const int32_t* __restr
     // of the decoder's order, rans_interface.cpp:147-162); padded to an even number with a no-op item.  Returns the count.
     auto expand = [&](const Half& hf) -> int {
         int incl = hf.c;  // inclusive prefix sum over the lanes
+        int total;
+        if (__builtin_amdgcn_ballot_w64(hf.c > 1) == 0) {
+            // no escape in this batch (the common case at a trained model's rates): one item per valid lane, and the
+            // valid lanes are a prefix of the wave
+            total = __builtin_popcountll(__builtin_amdgcn_ballot_w64(hf.c != 0));
+            incl = lane + 1;
+        } else {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            total = __builtin_amdgcn_readlane(incl, 63);
         }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
         if (hf.c) {
             const int o0 = incl - hf.c;  // first item index of this symbol; walk position = total - 1 - index
             auto put = [&](int index, uint32_t mlo, uint32_t mhi, uint32_t bias, uint32_t shift, uint32_t mult, uint32_t thr) {

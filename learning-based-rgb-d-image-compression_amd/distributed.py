@@ -44,11 +44,17 @@ def _comm_device():
 
 class RankStreams(Sequence):
     """One rank's gathered byte strings: a view on the gathered payload, split into `bytes` objects only on access (a
-    job that gathers hundreds of MB per step batch should not pay for thousands of copies it may never look at)."""
+    job that gathers hundreds of MB per step batch should not pay for thousands of copies it may never look at).  The
+    payload may still live in this rank's HBM (where RCCL delivered it); it is copied to the host on first access."""
 
-    def __init__(self, payload: np.ndarray, lens: np.ndarray):
-        self._p = payload
+    def __init__(self, payload, lens: np.ndarray):
+        self._p = payload  # numpy uint8 array, or a torch uint8 tensor (CPU or GPU)
         self._off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+    def _host(self) -> np.ndarray:
+        if not isinstance(self._p, np.ndarray):
+            self._p = self._p.cpu().numpy()
+        return self._p
 
     def __len__(self):
         return len(self._off) - 1
@@ -60,7 +66,7 @@ class RankStreams(Sequence):
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError(i)
-        return self._p[self._off[i]:self._off[i + 1]].tobytes()
+        return self._host()[self._off[i]:self._off[i + 1]].tobytes()
 
     def __eq__(self, other):
         return list(self) == list(other)
@@ -69,32 +75,42 @@ class RankStreams(Sequence):
 def gather_streams(streams: Sequence[bytes]) -> List[Sequence[bytes]]:
     """All ranks receive every rank's list of byte strings (ranks may hold different numbers of strings): two small
     all_gathers (counts, lengths) and one all_gather of the zero-padded payload.  Element r of the result behaves like
-    rank r's list of `bytes`."""
+    rank r's list of `bytes`.  With RCCL the payload is packed once into pinned host memory, uploaded asynchronously and
+    gathered HBM to HBM over xGMI; the gathered bytes stay in HBM until somebody reads them (`RankStreams`)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [list(streams)]
     world = dist.get_world_size()
     dev = _comm_device()
-    count = torch.tensor([len(streams), sum(len(s) for s in streams)], dtype=torch.int64, device=dev)
+    on_gpu = dev.type == "cuda"
+    total = sum(len(s) for s in streams)
+    count = torch.tensor([len(streams), total], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count)
-    counts = [c.cpu() for c in counts]
-    max_n = max(int(c[0]) for c in counts)
-    max_b = max(int(c[1]) for c in counts)
-    lens = torch.zeros(max(max_n, 1), dtype=torch.int64)
-    lens[: len(streams)] = torch.tensor([len(s) for s in streams], dtype=torch.int64)
-    payload = torch.zeros(max(max_b, 1), dtype=torch.uint8)
+    counts = torch.stack(counts).cpu()
+    max_n = max(int(counts[:, 0].max()), 1)
+    max_b = max(int(counts[:, 1].max()), 1)
+    lens = torch.zeros(max_n, dtype=torch.int64)
     if streams:
-        flat = np.frombuffer(b"".join(streams), dtype=np.uint8)
-        payload[: flat.shape[0]] = torch.from_numpy(flat.copy())
-    lens, payload = lens.to(dev), payload.to(dev)
-    all_lens = [torch.zeros_like(lens) for _ in range(world)]
-    all_payload = [torch.zeros_like(payload) for _ in range(world)]
+        lens[: len(streams)] = torch.tensor([len(s) for s in streams], dtype=torch.int64)
+    payload = torch.empty(max_b, dtype=torch.uint8, pin_memory=on_gpu)  # one packing pass, straight into pinned memory
+    view = payload.numpy()
+    o = 0
+    for s in streams:
+        n = len(s)
+        view[o:o + n] = np.frombuffer(s, dtype=np.uint8)
+        o += n
+    view[o:] = 0
+    lens, payload = lens.to(dev, non_blocking=on_gpu), payload.to(dev, non_blocking=on_gpu)
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
+    all_payload = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(all_lens, lens)
     dist.all_gather(all_payload, payload)
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()  # the gather has landed in this rank's HBM
     out = []
     for r in range(world):
         n = int(counts[r][0])
-        out.append(RankStreams(all_payload[r].cpu().numpy(), all_lens[r][:n].cpu().numpy()))
+        out.append(RankStreams(all_payload[r][: int(counts[r][1])], all_lens[r][:n].cpu().numpy()))
     return out
 
 
