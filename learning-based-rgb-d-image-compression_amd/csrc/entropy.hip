@@ -935,13 +935,15 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "1:\n"
                     "s_waitcnt lgkmcnt(0)\n"
                     "v_mov_b32 v58, v59\n"                      // this symbol's row slots
-                    "s_add_u32 %[t1], m0, 1\n"                  // prefetch the next symbol's row (clamped: the
-                    "s_min_u32 %[t1], %[t1], 63\n"              // last lane re-reads itself, value unused)
+                    "s_and_b32 %[cum], s84, 0xffff\n"
+                    "v_cmp_gt_u32 vcc, %[cum], v58\n"           // lanes with cdf[i+1] <= cum
+                    // issued in the shadow of the VALU -> SALU hand-over of vcc (an in-order wave would otherwise sit
+                    // out ~7 ns there): prefetch of the next symbol's row (clamped: the last lane re-reads itself)
+                    "s_add_u32 %[t1], m0, 1\n"
+                    "s_min_u32 %[t1], %[t1], 63\n"
                     "v_readlane_b32 %[lb], %[rowbase], %[t1]\n"
                     "v_add_u32 v60, %[lb], %[lane2]\n"
                     "ds_read_u16 v59, v60 offset:2\n"
-                    "s_and_b32 %[cum], s84, 0xffff\n"
-                    "v_cmp_gt_u32 vcc, %[cum], v58\n"           // lanes with cdf[i+1] <= cum
                     "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index when it is < 64
                     "s_cmp_eq_u32 %[a], 64\n"
                     "s_cbranch_scc1 60f\n"                      // beyond the first 64 slots: bucket table

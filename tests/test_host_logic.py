@@ -237,3 +237,32 @@ def test_load_state_dict_diagnostics(caplog):
     bad[k0] = torch.zeros(5, 5)
     with pytest.raises(RuntimeError, match="size mismatch"):
         rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).load_state_dict(bad)
+
+
+def test_image_read_semantics_like_the_reference_dataset(tmp_path):
+    """dataset/testDataset.py:36-61 (cv2.imread UNCHANGED + BGR->RGB, /255; depth divided by 10000 / 100000 / 255 by its
+    maximum, with the reference's strict inequalities) restated over PIL: PNG decoding is lossless, so the tensors are the
+    reference's for 8-bit RGB and 8/16-bit depth files."""
+    from PIL import Image
+
+    from rgbd_amd import tester
+
+    rng = np.random.RandomState(3)
+    rgb = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "c.png")
+    t = tester.load_image(tmp_path / "c.png", "RGB")
+    assert t.shape == (3, 37, 53) and t.dtype == torch.float32
+    assert torch.equal(t, torch.from_numpy(rgb.transpose(2, 0, 1)).float() / 255.0)  # R, G, B order, exact
+    for mx, div in ((200, 255.0), (255, 255.0), (256, 10000.0), (9999, 10000.0), (10000, 255.0), (10001, 100000.0),
+                    (65535, 100000.0)):
+        d = rng.randint(0, mx + 1, (21, 34)).astype(np.uint16)
+        d[0, 0] = mx
+        Image.fromarray(d).save(tmp_path / "d.png")
+        td = tester.load_image(tmp_path / "d.png", "L")
+        assert td.shape == (1, 21, 34)
+        assert torch.equal(td, torch.from_numpy(d.astype("float32"))[None] / div), mx
+    # the harness writes depth reconstructions as 16-bit PNGs (tester_united.py:101-109)
+    x = torch.rand(1, 1, 8, 9)
+    tester.save_depth16(x, tmp_path / "r.png", 10000)
+    back = np.array(Image.open(tmp_path / "r.png"))
+    assert back.dtype == np.uint16 and np.array_equal(back, (x * 10000).squeeze().numpy().astype("uint16"))
