@@ -27,7 +27,7 @@ cd "$root"
 # every run executes warm-up steps, the timed steps and two conv-profile passes of two steps each: divide by all of them
 steps=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1]);print(j['steps']+max(j['warmup'],min(j['config']['engine_instances'],j['steps']))+4)")
 { python3 profiles/summarize.py "$out/stats" "$steps"; python3 profiles/timeline.py "$out/stats"; grep '^{' "$out/stats.log"; } > "$out/${tag}_bench_default_summary.txt"
-{ python3 profiles/summarize.py "$out/stats_w1" 10; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
+{ python3 profiles/summarize.py "$out/stats_w1" 12; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_default_kernel_stats.csv"
 # 4 x 512x640 padded pixels x 30.28 KB + 1.01 GB weights per step over 594 launches = 68.5 MB algorithmic per launch
 python3 profiles/pmc_traffic.py "$out/fetch_c3" "$out/write_c3" "$out/${tag}_c3" 68516164 "--workload c3_4x480x640 (RGBD_NO_GRAPH=1)"
