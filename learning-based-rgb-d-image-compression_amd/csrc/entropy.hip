@@ -931,26 +931,19 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     // pad), loaded one symbol AHEAD so the LDS hop overlaps the previous symbol's update.
                     "v_readlane_b32 %[lb], %[rowbase], m0\n"
                     "v_add_u32 v60, %[lb], %[lane2]\n"
-                    "ds_read_u16 v59, v60 offset:2\n"
+                    "ds_read_u16 v58, v60 offset:2\n"
+                    // The loop is bound by the issue rate of the one wave (~3 ns per instruction, measured: every
+                    // instruction removed takes 3 ns off a symbol), so it is kept as short as it gets.
                     "1:\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_mov_b32 v58, v59\n"                      // this symbol's row slots
+                    "s_waitcnt lgkmcnt(0)\n"                    // v58: this symbol's row slots (prefetched at 6: below)
                     "s_and_b32 %[cum], s84, 0xffff\n"
                     "v_cmp_gt_u32 vcc, %[cum], v58\n"           // lanes with cdf[i+1] <= cum
-                    // issued in the shadow of the VALU -> SALU hand-over of vcc (an in-order wave would otherwise sit
-                    // out ~7 ns there): prefetch of the next symbol's row (clamped: the last lane re-reads itself)
-                    "s_add_u32 %[t1], m0, 1\n"
-                    "s_min_u32 %[t1], %[t1], 63\n"
-                    "v_readlane_b32 %[lb], %[rowbase], %[t1]\n"
-                    "v_add_u32 v60, %[lb], %[lane2]\n"
-                    "ds_read_u16 v59, v60 offset:2\n"
                     "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index when it is < 64
                     "s_cmp_eq_u32 %[a], 64\n"
                     "s_cbranch_scc1 60f\n"                      // beyond the first 64 slots: bucket table
                     "s_sub_u32 %[t0], %[a], 1\n"
                     "v_readlane_b32 %[t1], v58, %[a]\n"         // cdf[a+1]-1
-                    "s_and_b32 %[t0], %[t0], 63\n"
-                    "v_readlane_b32 %[t0], v58, %[t0]\n"        // cdf[a]-1 (a == 0: -1 below)
+                    "v_readlane_b32 %[t0], v58, %[t0]\n"        // cdf[a]-1 (a == 0: lane select -1 reads some lane; -1 below)
                     "s_cmp_eq_u32 %[a], 0\n"
                     "s_cselect_b32 %[t0], -1, %[t0]\n"
                     "s_cmp_eq_u32 %[t1], 0xffff\n"              // cdf[a+1] == 65536: last slot = escape
@@ -959,6 +952,12 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
                     "s_sub_u32 %[t0], %[t0], 1\n"               // cum - start
                     "6:\n"
+                    // the row slots are dead from here on: the next symbol's row goes straight into v58 (lane 64 wraps
+                    // to lane 0: a valid row, value unused), its LDS hop overlaps the state update below
+                    "s_add_u32 %[t1], m0, 1\n"
+                    "v_readlane_b32 %[lb], %[rowbase], %[t1]\n"
+                    "v_add_u32 v60, %[lb], %[lane2]\n"
+                    "ds_read_u16 v58, v60 offset:2\n"
                     "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
                     "s_mul_i32 %[t1], s87, %[freq]\n"
                     "s_mul_hi_u32 s85, s86, %[freq]\n"
@@ -1100,6 +1099,10 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "v_writelane_b32 %[outv], %[t1], m0\n"
                     "s_mov_b64 s[84:85], s[88:89]\n"           // commit
                     "s_mov_b32 %[wi], %[lb]\n"
+                    "s_add_u32 %[lb], m0, 1\n"                 // (this path does not pass 6: -- prefetch the next row here)
+                    "v_readlane_b32 %[lb], %[rowbase], %[lb]\n"
+                    "v_add_u32 v60, %[lb], %[lane2]\n"
+                    "ds_read_u16 v58, v60 offset:2\n"
                     "s_sub_u32 %[t0], %[cnt], m0\n"           // rest of the batch still inside the word window?
                     "s_add_u32 %[t0], %[t0], %[wi]\n"
                     "s_cmp_le_u32 %[t0], 65\n"
