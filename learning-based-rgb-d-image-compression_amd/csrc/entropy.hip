@@ -1070,6 +1070,28 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_cbranch_scc1 8f\n"
                     "s_mov_b32 %[start], 0\n"
                     "s_mov_b32 %[cum], 0\n"
+                    // All payload nibbles at once when the state is large enough that none of the first nn - 1 steps can
+                    // drop it below 2^31 (x >= 2^(27 + 4 nn): three escapes in four): the payload is then simply the low
+                    // 4 nn bits of x, and only the last step can ask for a word -- the reference's nibble-by-nibble loop
+                    // (rans_interface.cpp:80-96, 323-345) consumes exactly the same words in that case.
+                    "s_sub_u32 %[t1], %[e0], 1\n"             // nn in 1..7 ?
+                    "s_cmp_gt_u32 %[t1], 6\n"
+                    "s_cbranch_scc1 74f\n"
+                    "s_lshl_b32 %[t1], %[e0], 2\n"            // bits = 4 nn
+                    "s_add_u32 %[t0], %[t1], 27\n"
+                    "s_lshr_b64 s[86:87], s[88:89], %[t0]\n"
+                    "s_cmp_eq_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 74f\n"                    // too small: step by step
+                    "s_bfm_b32 %[t0], %[t1], 0\n"
+                    "s_and_b32 %[start], s88, %[t0]\n"        // raw
+                    "s_lshr_b64 s[88:89], s[88:89], %[t1]\n"
+                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
+                    "s_cmp_lg_u64 s[86:87], 0\n"
+                    "s_cbranch_scc1 75f\n"
+                    "s_mov_b32 s89, s88\n"
+                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
+                    "s_add_u32 %[lb], %[lb], 1\n"
+                    "s_branch 75f\n"
                     "74:\n"
                     "s_cmp_eq_u32 %[e0], 0\n"
                     "s_cbranch_scc1 75f\n"
