@@ -161,8 +161,21 @@ __global__ void channel_mean_kernel(const float* __restrict__ x, int HW, int cs,
     const size_t n = blockIdx.y;
     float s = 0.f;
     if (c < C) {
+        // same summation order as ever (each of the 4 chains adds its pixels r, r+4, r+8, ... one after the other: the
+        // SE gate feeds the entropy parameters, so the order is part of the bitstream contract); the loads of 8 steps are
+        // issued together so that a chain is bound by bandwidth, not by one memory round trip per pixel
         const float* b = x + n * (size_t)HW * cs + c;
-        for (int p = r; p < HW; p += 4) s += b[(size_t)p * cs];
+        const size_t step = (size_t)4 * cs;
+        const float* q = b + (size_t)r * cs;
+        int p = r;
+        for (; p + 28 < HW; p += 32, q += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q[k * step];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; p < HW; p += 4, q += step) s += *q;
     }
     part[r][threadIdx.x & 63] = s;
     __syncthreads();
