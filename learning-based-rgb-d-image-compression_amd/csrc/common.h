@@ -103,6 +103,9 @@ int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int 
 int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s);
 int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s);
 int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s);
+int launch_channel_mean_strided(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s);
+int launch_channel_scale_to_strided(const float* x, int N, int HW, int xcs, int C, const float* scale, int sstride, int mode,
+                                    float* y, int ycs, hipStream_t s);
 // w1t is fc.2.weight transposed to [hidden][C]; hid is a [N][hidden] scratch buffer
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
                  float* scale, hipStream_t s);

@@ -903,14 +903,31 @@ struct rgbd_elic {
         }
     }
 
-    // synthesis.py:345-362
+    // synthesis.py:345-362.  cat(own, other) -> SE -> deconv without materialising the unscaled concatenation: the channel
+    // means of the two inputs land side by side (what the mean of the concatenation would be, channel by channel), the
+    // gate is computed from them, and each input is scaled straight into its half of the deconv's input buffer
     Act hs_block(const std::string& p, const Act& own, const Act& other, bool last)
     {
-        Act f = alloc(own.n, own.h, own.w, own.c + other.c);
-        copy_ch(own, view(f, 0, own.c));
-        copy_ch(other, view(f, own.c, other.c));
-        float* sc = se_weights(p + ".se", f);
-        scale_inplace(f, sc, 0);
+        const int C = own.c + other.c;
+        Act f = alloc(own.n, own.h, own.w, C);
+        float* w0 = dense_of(p + ".se.fc.0.weight");
+        float* w1 = dense_of(p + ".se.fc.2.weight");
+        float* mean = (float*)arena.take((size_t)own.n * C * sizeof(float));
+        float* sc = (float*)arena.take((size_t)own.n * C * sizeof(float));
+        float* hid = (float*)arena.take((size_t)own.n * (C / 16 + 1) * sizeof(float));
+        if (C % 16 || own.c % 4) {
+            fail(RGBD_EINVAL);
+            return f;
+        }
+        if (!dry() && !rc && w0 && w1) {
+            const int HW = own.h * own.w;
+            int r = launch_channel_mean_strided(own.p, own.n, HW, own.cs, own.c, mean, C, s);
+            if (!r) r = launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
+            if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s);
+            if (!r) r = launch_channel_scale_to_strided(own.p, own.n, HW, own.cs, own.c, sc, C, 0, f.p, f.cs, s);
+            if (!r) r = launch_channel_scale_to_strided(other.p, other.n, HW, other.cs, other.c, sc + own.c, C, 0, f.p + own.c, f.cs, s);
+            if (r) fail(r);
+        }
         Epi e;
         e.act = last ? ACT_NONE : ACT_LEAKY;
         return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);

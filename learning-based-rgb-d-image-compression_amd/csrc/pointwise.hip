@@ -153,7 +153,7 @@ int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H
 // ---------------------------------------------------------------------------------------------
 // Global average pool per (n, c): fixed reduction order (per-thread strided partial sums, then a fixed LDS tree),
 // so the result does not depend on scheduling.  grid = (ceil(C/64), N), block = 256 = 64 channels x 4 pixel lanes.
-__global__ void channel_mean_kernel(const float* __restrict__ x, int HW, int cs, int C, float* __restrict__ mean)
+__global__ void channel_mean_kernel(const float* __restrict__ x, int HW, int cs, int C, float* __restrict__ mean, int mstride)
 {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -181,13 +181,19 @@ __global__ void channel_mean_kernel(const float* __restrict__ x, int HW, int cs,
     __syncthreads();
     if (r == 0 && c < C) {
         const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        mean[n * C + c] = t / (float)HW;
+        mean[n * mstride + c] = t / (float)HW;
     }
 }
 
 int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s)
 {
-    hipLaunchKernelGGL(channel_mean_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, x, HW, cs, C, mean);
+    return launch_channel_mean_strided(x, N, HW, cs, C, mean, C, s);
+}
+
+// mean[n * mstride + c]: the means of two tensors can land side by side, as if they had been concatenated first
+int launch_channel_mean_strided(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s)
+{
+    hipLaunchKernelGGL(channel_mean_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, x, HW, cs, C, mean, mstride);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
@@ -223,6 +229,9 @@ __global__ void se_gate_kernel(const float* __restrict__ hid, int C, int hidden,
     scale[n * C + c] = 1.0f / (1.0f + expf(-s));
 }
 
+// (A single-launch variant -- every workgroup recomputing the hidden layer into LDS, then gating its channels -- was built
+// and measured: at B = 1 the 4 waves of a workgroup walk 44 hidden units each, one memory round trip after the other, and
+// an SE gate took ~100 us instead of 2 x 14 us; the two-launch form below stays.)
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
                  float* scale, hipStream_t s)
 {
@@ -274,15 +283,16 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int scs, flo
     }
 }
 
-__global__ void channel_scale_to_kernel(const float* __restrict__ x, int HW, int xcs, int C, const float* __restrict__ scale,
-                                        int mode, float* __restrict__ y, int ycs, size_t total4, int c4n)
+__global__ void channel_scale_to_kernel(const float* __restrict__ x, int HW, int xcs, int sstride,
+                                        const float* __restrict__ scale, int mode, float* __restrict__ y, int ycs,
+                                        size_t total4, int c4n)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const size_t pix = i / c4n;
         const size_t n = pix / HW;
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * xcs + c4 * 4);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n * C + c4 * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n * sstride + c4 * 4);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -297,10 +307,17 @@ __global__ void channel_scale_to_kernel(const float* __restrict__ x, int HW, int
 int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const float* scale, int mode, float* y, int ycs,
                             hipStream_t s)
 {
-    if (C % 4) return RGBD_EINVAL;
+    return launch_channel_scale_to_strided(x, N, HW, xcs, C, scale, C, mode, y, ycs, s);
+}
+
+// scale[n * sstride + c]: the gate of a channel slice of a wider (virtually concatenated) tensor
+int launch_channel_scale_to_strided(const float* x, int N, int HW, int xcs, int C, const float* scale, int sstride, int mode,
+                                    float* y, int ycs, hipStream_t s)
+{
+    if (C % 4 || sstride % 4) return RGBD_EINVAL;
     const size_t total4 = (size_t)N * HW * (C / 4);
-    hipLaunchKernelGGL(channel_scale_to_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, HW, xcs, C, scale, mode, y, ycs,
-                       total4, C / 4);
+    hipLaunchKernelGGL(channel_scale_to_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, HW, xcs, sstride, scale, mode, y,
+                       ycs, total4, C / 4);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
