@@ -197,6 +197,8 @@ int rgbd_elic_profile_dump(rgbd_elic* m, const char* path);
 /* Measurement hook (bench.py): when on, every convolution launch is bracketed by HIP events on the launch stream.
  * profile_read returns the summed kernel time (ms), the launch count and the algorithmic FLOPs (2*MACs, unpadded)
  * accumulated since set_profile(). */
+/* Number of call shapes whose kernel sequence is currently cached as a HIP graph (tests / diagnostics). */
+int rgbd_elic_graph_count(const rgbd_elic* m);
 int rgbd_elic_set_profile(rgbd_elic* m, int32_t on);
 int rgbd_elic_profile_read(rgbd_elic* m, double* conv_ms, int64_t* launches, double* flops);
 

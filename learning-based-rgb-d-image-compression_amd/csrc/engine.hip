@@ -348,6 +348,26 @@ struct rgbd_elic {
     const bool use_graphs = getenv("RGBD_NO_GRAPH") == nullptr;
     const bool blocking_wait = getenv("RGBD_SPIN_WAIT") == nullptr;
     hipEvent_t done_ev = nullptr;  // blocking-sync event: the host thread sleeps instead of spinning on the stream
+    // A caller that passes the NULL (legacy default) stream gets an engine-owned stream instead: the legacy stream cannot
+    // be captured into a graph.  Order is kept by events: the engine's stream first waits for what the caller had queued
+    // on the NULL stream, and every entry point returns only after its own work has finished (wait_stream()).
+    hipStream_t own_s = nullptr;
+    hipEvent_t null_ev = nullptr;
+    int use_stream(void* stream)
+    {
+        if (stream) {
+            s = (hipStream_t)stream;
+            return RGBD_OK;
+        }
+        if (!own_s) {
+            HIP_TRY(hipStreamCreateWithFlags(&own_s, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&null_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(null_ev, nullptr));
+        HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
+        s = own_s;
+        return RGBD_OK;
+    }
     // pinned staging for the per-call uploads (stream bytes, offsets): truly asynchronous copies, no per-call pinning
     int64_t* res_pin = nullptr;  // pinned landing buffer of the per-call result sizes
     static constexpr size_t kResPinBytes = 64 * 1024;
@@ -368,7 +388,10 @@ struct rgbd_elic {
     GraphEntry* graph_entry(const std::string& key)
     {
         if (!use_graphs || profile) return nullptr;
-        return &graphs[key + "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch)];
+        // (the stream is part of the key: a graph is replayed on the stream it was captured on)
+        char sk[32];
+        snprintf(sk, sizeof(sk), "|%p", (void*)s);
+        return &graphs[key + "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch) + sk];
     }
     // Start of the capturable part of a call.  Returns true when the caller has to run the body code (eagerly, into a
     // capture, or as a sizing pass), false when a cached graph stands in for it.
@@ -1565,7 +1588,10 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
 
     // ==== body: every kernel of the call, in stream order; captured into / replayed from a HIP graph per call shape ====
     if (body_begin()) {
-        if (!dry()) HIP_TRY(hipMemsetAsync(err, 0, 256, s));
+        if (!dry()) {
+            const int zr = launch_fill_zero((float*)err, 64, s);  // (a kernel, not a memset node: see launch_fill_zero)
+            if (zr) fail(zr);
+        }
         named["y_r"] = y_r;
         named["y_d"] = y_d;
         if (!lat) {
@@ -2655,7 +2681,7 @@ int rgbd_elic_compress_single(rgbd_elic* m, const float* x_dev, int32_t B, int32
     int r = check_ready(m);
     if (r) return r;
     if (m->variant != 1 || !x_dev || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64) return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     const int per_image = (per_image_streams || B == 1) ? 1 : 0;
     m->arena.dry = true;
     m->arena.top = m->arena.peak = 0;
@@ -2677,7 +2703,7 @@ int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int
     if (r) return r;
     if (m->variant != 1 || !y || !y_len || !z || !z_len || !x_dev || B <= 0 || zh <= 0 || zw <= 0) return RGBD_EINVAL;
     if (n_y != 1 && n_y != B) return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     m->arena.dry = true;
     m->arena.top = m->arena.peak = 0;
     r = m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev);
@@ -2686,10 +2712,8 @@ int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int
     r = m->ensure_arena(m->arena.peak);
     if (r) return r;
     r = m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev);
-    if (m->profile && !r) {
-        if (hipStreamSynchronize(m->s) != hipSuccess) return RGBD_EHIP;
-        m->profile_collect();
-    }
+    if (!r) r = m->wait_stream();  // (the work may sit on the engine's own stream: return when x_hat is there)
+    if (m->profile && !r) m->profile_collect();
     return r;
 }
 
@@ -2725,6 +2749,8 @@ void rgbd_elic_destroy(rgbd_elic* m)
     if (m->res_pin) (void)hipHostFree(m->res_pin);
     if (m->pin_ev) (void)hipEventDestroy(m->pin_ev);
     if (m->done_ev) (void)hipEventDestroy(m->done_ev);
+    if (m->null_ev) (void)hipEventDestroy(m->null_ev);
+    if (m->own_s) (void)hipStreamDestroy(m->own_s);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
 }
@@ -2903,7 +2929,7 @@ int rgbd_elic_compress(rgbd_elic* m, const float* rgb_dev, const float* depth_de
     int r = check_ready(m);
     if (r) return r;
     if (!rgb_dev || !depth_dev || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64) return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     const int per_image = (per_image_streams || B == 1) ? 1 : 0;
     char key[96];
     snprintf(key, sizeof(key), "c|%d|%d|%d|%d", B, H, W, per_image);
@@ -2921,7 +2947,7 @@ int rgbd_elic_forward(rgbd_elic* m, const float* rgb_dev, const float* depth_dev
     if (!rgb_dev || !depth_dev || !xr_dev || !xd_dev || !lik_y_rgb || !lik_y_depth || !lik_z_rgb || !lik_z_depth || B <= 0 ||
         H <= 0 || W <= 0 || H % 64 || W % 64)
         return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     m->arena.dry = true;
     m->arena.top = m->arena.peak = 0;
     r = m->run_forward(rgb_dev, depth_dev, B, H, W, xr_dev, xd_dev, lik_y_rgb, lik_y_depth, lik_z_rgb, lik_z_depth);
@@ -2958,7 +2984,7 @@ int rgbd_elic_decompress(rgbd_elic* m, const uint8_t* const* y_rgb, const int64_
     if (r) return r;
     if (!y_rgb || !y_depth || !z_rgb || !z_depth || !xr_dev || !xd_dev || B <= 0 || zh <= 0 || zw <= 0) return RGBD_EINVAL;
     if (n_y != 1 && n_y != B) return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     const uint8_t* const* ys[2] = {y_rgb, y_depth};
     const int64_t* yl[2] = {y_rgb_len, y_depth_len};
     const uint8_t* const* zs[2] = {z_rgb, z_depth};
@@ -2980,7 +3006,7 @@ int rgbd_elic_compress_united(rgbd_elic* m, const float* y_rgb_dev, const float*
     if (r) return r;
     if (!y_rgb_dev || !hyper_rgb_dev || !y_depth_dev || !hyper_depth_dev || B <= 0 || h <= 0 || w <= 0 || (w & 1))
         return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     const int per_image = (per_image_streams || B == 1) ? 1 : 0;
     rgbd_elic::Latents lat = {{y_rgb_dev, y_depth_dev}, {hyper_rgb_dev, hyper_depth_dev}, {nullptr, nullptr}};
     char key[96];
@@ -3001,7 +3027,7 @@ int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const
         w <= 0 || (w & 1))
         return RGBD_EINVAL;
     if (n_y != 1 && n_y != B) return RGBD_EINVAL;
-    m->s = (hipStream_t)stream;
+    if (const int ur = m->use_stream(stream)) return ur;
     const uint8_t* const* ys[2] = {y_rgb, y_depth};
     const int64_t* yl[2] = {y_rgb_len, y_depth_len};
     const uint8_t* const* zs[2] = {nullptr, nullptr};
@@ -3013,6 +3039,14 @@ int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const
     if (!r) r = m->wait_stream();
     if (m->profile && !r) m->profile_collect();
     return r;
+}
+
+int rgbd_elic_graph_count(const rgbd_elic* m)
+{
+    if (!m) return RGBD_EINVAL;
+    int n = 0;
+    for (const auto& kv : m->graphs) n += kv.second.exec ? 1 : 0;
+    return n;
 }
 
 int rgbd_elic_set_profile(rgbd_elic* m, int32_t on)
@@ -3068,6 +3102,7 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
     float* tmp = nullptr;
     HIP_TRY(hipMalloc((void**)&tmp, (size_t)need * sizeof(float)));
     int r = launch_nhwc_to_nchw_clamp(a.p, a.n, a.c, a.h, a.w, a.cs, tmp, 0, m->s);
+    if (!r && hipStreamSynchronize(m->s) != hipSuccess) r = RGBD_EHIP;  // (the stream may be non-blocking: hipMemcpy would not wait for it)
     if (!r && hipMemcpy(data, tmp, (size_t)need * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) r = RGBD_EHIP;
     (void)hipFree(tmp);
     return r;

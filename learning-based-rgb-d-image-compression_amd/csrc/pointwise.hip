@@ -332,8 +332,18 @@ int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npi
     return RGBD_OK;
 }
 
+// A kernel rather than hipMemsetAsync: these fills sit inside the bodies that are captured into HIP graphs, and a memset
+// node of a replayed graph was observed not to clear its buffer (the encoder's error flag came back set with whatever the
+// workspace held before) -- a kernel node behaves.
+__global__ void fill_zero_kernel(float* __restrict__ p, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 int launch_fill_zero(float* p, size_t n, hipStream_t s)
 {
-    HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(float), s));
+    if (!n) return RGBD_OK;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, p, n);
+    HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }

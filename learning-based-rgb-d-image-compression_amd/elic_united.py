@@ -419,6 +419,10 @@ class ELIC_united:
         self._tile_mode = mode
         check(lib().rgbd_elic_set_tile_mode(self._h, {"latency": 0, "throughput": 1}[mode]), "set_tile_mode")
 
+    def graph_count(self) -> int:
+        """Call shapes whose launch sequence is cached as a HIP graph on this engine instance."""
+        return int(lib().rgbd_elic_graph_count(self._h))
+
     def set_profile(self, on: bool):
         check(lib().rgbd_elic_set_profile(self._h, 1 if on else 0), "set_profile")
 

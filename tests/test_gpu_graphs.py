@@ -36,13 +36,27 @@ def _round(net, r, d):
     return out, rec["x_hat"]["r"].clone(), rec["x_hat"]["d"].clone()
 
 
-def test_eager_capture_replay_agree(net):
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_eager_capture_replay_agree(net, side_stream):
+    """On the caller's NULL stream (the engine then works on a stream of its own, which can be captured) and on a torch
+    side stream alike."""
+    if side_stream:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            _eager_capture_replay(net)
+        torch.cuda.synchronize()
+    else:
+        _eager_capture_replay(net)
+
+
+def _eager_capture_replay(net):
     net.per_image_streams = True
     try:
         a = _pair(2, 128, 192, 31)
         b = _pair(2, 128, 192, 32)  # same shape, other pixels: a replayed graph must read the NEW inputs
-        ref_a = _round(net, *a)     # eager
-        cap_a = _round(net, *a)     # captured + launched
+        ref_a = _round(net, *a)     # eager (and sizes the workspace: a re-allocation drops cached graphs)
+        cap_a = _round(net, *a)     # eager or captured + launched, depending on when the workspace last grew
+        _round(net, *a)
+        assert net.graph_count() >= 2  # compress and decompress of this shape are cached graphs now
         rep_a = _round(net, *a)     # replayed
         rep_b = _round(net, *b)     # replayed on other inputs
         for other in (cap_a, rep_a):
