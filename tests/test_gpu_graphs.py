@@ -99,3 +99,31 @@ def test_bicee_alone_replay(net):
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[1] == outs[0][1]
         assert torch.equal(o[2], outs[0][2]) and torch.equal(o[3], outs[0][3])
+
+
+def test_stf_replay_and_varying_shapes():
+    """STF_united zero-fills y_hat inside the captured body (its 24-wide slices make a 16-channel read straddle into a slice
+    that is not coded yet): a replayed graph must do that fill too.  Shapes alternate so that the workspace holds another
+    call's leftovers whenever a graph is replayed."""
+    import rgbd_amd
+    from rgbd_amd import synth
+
+    require_gpu()
+    m = rgbd_amd.modelZoo["STF_united"](config=rgbd_amd.model_config(), channel=4).eval()
+    m.load_state_dict(synth.synthetic_state_dict(0, model="STF_united"))
+    m.update(force=True)
+    m = m.to("cuda")
+    shapes = [(1, 256, 256, 41), (1, 256, 320, 42)]
+    ref = {}
+    for rnd in range(4):  # eager, capture, replay, replay -- interleaved over two shapes
+        for shp in shapes:
+            r, d = _pair(*shp)
+            out = m.compress(r, d)
+            rec = m.decompress(out["r_strings"], out["d_strings"], out["shape"])
+            got = (out["r_strings"], out["d_strings"], rec["x_hat"]["r"].clone(), rec["x_hat"]["d"].clone())
+            if shp not in ref:
+                ref[shp] = got
+            else:
+                assert got[0] == ref[shp][0] and got[1] == ref[shp][1], (rnd, shp)
+                assert torch.equal(got[2], ref[shp][2]) and torch.equal(got[3], ref[shp][3]), (rnd, shp)
+    assert m.graph_count() >= 4
