@@ -348,24 +348,14 @@ struct rgbd_elic {
     const bool use_graphs = getenv("RGBD_NO_GRAPH") == nullptr;
     const bool blocking_wait = getenv("RGBD_SPIN_WAIT") == nullptr;
     hipEvent_t done_ev = nullptr;  // blocking-sync event: the host thread sleeps instead of spinning on the stream
-    // A caller that passes the NULL (legacy default) stream gets an engine-owned stream instead: the legacy stream cannot
-    // be captured into a graph.  Order is kept by events: the engine's stream first waits for what the caller had queued
-    // on the NULL stream, and every entry point returns only after its own work has finished (wait_stream()).
-    hipStream_t own_s = nullptr;
-    hipEvent_t null_ev = nullptr;
+    // The legacy NULL stream cannot be captured: a caller that passes it runs the eager launch path (same results, no
+    // graph).  Substituting an engine-owned stream for it (ordered behind the NULL stream by an event) was built and
+    // taken out again: with it, a later hipFree -- an implicit device synchronise -- never returned in a process that had
+    // also replayed graphs on torch side streams (tests/test_gpu_harness.py run as a whole; the stage is logged by
+    // RGBD_DEBUG_DESTROY=1).  Throughput users drive their own streams (CodecPool), which do capture.
     int use_stream(void* stream)
     {
-        if (stream) {
-            s = (hipStream_t)stream;
-            return RGBD_OK;
-        }
-        if (!own_s) {
-            HIP_TRY(hipStreamCreateWithFlags(&own_s, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&null_ev, hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(null_ev, nullptr));
-        HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
-        s = own_s;
+        s = (hipStream_t)stream;
         return RGBD_OK;
     }
     // pinned staging for the per-call uploads (stream bytes, offsets): truly asynchronous copies, no per-call pinning
@@ -387,7 +377,7 @@ struct rgbd_elic {
     }
     GraphEntry* graph_entry(const std::string& key)
     {
-        if (!use_graphs || profile) return nullptr;
+        if (!use_graphs || profile || !s) return nullptr;  // (the NULL stream cannot be captured)
         // (the stream is part of the key: a graph is replayed on the stream it was captured on)
         char sk[32];
         snprintf(sk, sizeof(sk), "|%p", (void*)s);
@@ -2740,19 +2730,24 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
 
 void rgbd_elic_destroy(rgbd_elic* m)
 {
+    static const bool dbg = getenv("RGBD_DEBUG_DESTROY") != nullptr;
+    if (dbg) fprintf(stderr, "[destroy %p] wait lock\n", (void*)m);
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m) return;
+    if (dbg) fprintf(stderr, "[destroy %p] locked, graphs %zu\n", (void*)m, m->graphs.size());
     // weights, tables and the scale table belong to shared generations (DevGen) that go when their last user does
     m->graphs_invalidate();
+    if (dbg) fprintf(stderr, "[destroy %p] graphs gone\n", (void*)m);
     if (m->arena.base) (void)hipFree(m->arena.base);
+    if (dbg) fprintf(stderr, "[destroy %p] arena freed\n", (void*)m);
     if (m->pin) (void)hipHostFree(m->pin);
     if (m->res_pin) (void)hipHostFree(m->res_pin);
     if (m->pin_ev) (void)hipEventDestroy(m->pin_ev);
     if (m->done_ev) (void)hipEventDestroy(m->done_ev);
-    if (m->null_ev) (void)hipEventDestroy(m->null_ev);
-    if (m->own_s) (void)hipStreamDestroy(m->own_s);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    if (dbg) fprintf(stderr, "[destroy %p] events/streams gone\n", (void*)m);
     delete m;
+    if (dbg) fprintf(stderr, "[destroy] done\n");
 }
 
 int rgbd_elic_set_tensor(rgbd_elic* m, const char* name, const float* data, const int64_t* shape, int32_t ndim)

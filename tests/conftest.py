@@ -45,3 +45,11 @@ def synth_sd():
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, f"model_{name}.npz")))
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress must fail, not sit on the GPU box: every `gpu` test without its own timeout gets
+    one (method "thread": a wait inside the HIP runtime never returns to the interpreter, so a signal would not fire)."""
+    for it in items:
+        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(420, method="thread"))

@@ -129,6 +129,22 @@ def test_pool_matches_single_instance(net, synth_sd):
     for out, mxr, mxd in many:
         assert out["r_strings"] == ref["r_strings"] and out["d_strings"] == ref["d_strings"]
         assert torch.equal(mxr, ref_rec["x_hat"]["r"])
+    # the pooled instances replay HIP graphs from their third call of a shape on: two shapes alternating, six batches per
+    # worker, every result against the single-instance call (whose workspace never saw the other shape in between)
+    r2, d2 = synth.synthetic_batch(2, 128, 192, config_id=12)
+    rgb2, depth2 = torch.from_numpy(r2).cuda(), torch.from_numpy(d2).cuda()
+    net.per_image_streams = True
+    try:
+        ref2 = net.compress(rgb2, depth2)
+        ref2_rec = net.decompress(ref2["r_strings"], ref2["d_strings"], ref2["shape"])
+    finally:
+        net.per_image_streams = False
+    seq = [(rgb, depth), (rgb2, depth2)] * 6
+    for k, (out, mxr, mxd) in enumerate(pool.roundtrip_many(seq)):
+        want, want_rec = (ref, ref_rec) if k % 2 == 0 else (ref2, ref2_rec)
+        assert out["r_strings"] == want["r_strings"] and out["d_strings"] == want["d_strings"], k
+        assert torch.equal(mxr, want_rec["x_hat"]["r"]) and torch.equal(mxd, want_rec["x_hat"]["d"]), k
+    assert all(n.graph_count() >= 2 for n in pool.nets)
 
 
 def test_tester_single_on_files(tmp_path, monkeypatch):
