@@ -1,3 +1,6 @@
+"""Step-logged probe of the pooled HIP-graph replay path (two engine instances, two alternating call shapes, every result
+against a single-instance reference), with a faulthandler watchdog: writes gpurun_out/hang_probe.log.  Used to localise a
+hang in the runtime; see DESIGN.md 3.5."""
 import faulthandler, sys, os, time
 sys.path.insert(0, "/root/repo")
 log = open("/root/repo/gpurun_out/hang_probe.log", "w")
