@@ -266,3 +266,23 @@ def test_image_read_semantics_like_the_reference_dataset(tmp_path):
     tester.save_depth16(x, tmp_path / "r.png", 10000)
     back = np.array(Image.open(tmp_path / "r.png"))
     assert back.dtype == np.uint16 and np.array_equal(back, (x * 10000).squeeze().numpy().astype("uint16"))
+
+
+def test_trained_like_recipe_is_defined_and_reproducible():
+    """The second synthetic weight recipe (bench.py `latency_trained_like`): same generator, other gains; ELIC_united only."""
+    from rgbd_amd import synth
+
+    a = synth.synthetic_state_dict(0, recipe="trained_like", as_torch=False)
+    b = synth.synthetic_state_dict(0, recipe="trained_like", as_torch=False)
+    s = synth.synthetic_state_dict(0, as_torch=False)  # stress recipe (default)
+    k = "g_a.rgb_analysis_transform.16.weight"
+    assert np.array_equal(a[k], b[k]) and not np.array_equal(a[k], s[k])
+    assert np.allclose(a[k] * 8.0, s[k])  # gains 6 vs 48 on the last analysis conv
+    kb = "rgb_entropy_parameters_anchor.0.fusion.4.bias"
+    assert np.allclose(a[kb][:16], 0.25) and np.allclose(s[kb][:16], 1.0)
+    untouched = "g_s.rgb_synthesis_transform.3.branch.2.weight"
+    assert np.array_equal(a[untouched], s[untouched])
+    with pytest.raises(ValueError):
+        synth.synthetic_state_dict(0, recipe="trained_like", model="STF_united")
+    with pytest.raises(ValueError):
+        synth.synthetic_state_dict(0, recipe="nope")

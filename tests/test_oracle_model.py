@@ -210,3 +210,43 @@ def test_elic_united_r2d():
     dec = orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
     assert np.array_equal(dec["x_hat"]["r"][:, :, ::4, ::4].numpy(), g["xhat_r_sub"])
     assert np.array_equal(dec["x_hat"]["d"][:, :, ::4, ::4].numpy(), g["xhat_d_sub"])
+
+
+def test_golden_part_walker_on_the_oracle(codec, kat):
+    """tests/parity_utils.golden_parts_identical (what the GPU parity floors are measured with) checked here, on the CPU,
+    with the oracle standing in for the GPU: symbols / indexes that ARE the reference's walk all 20 parts of the golden
+    stream; one perturbed symbol or index stops the count at its part (coding order: rgb anchor, depth anchor, rgb
+    non-anchor, depth non-anchor per slice)."""
+    from oracle import coder
+    from parity_utils import golden_parts_identical, part_sizes
+
+    g = load_golden("a_128x192")
+    r, d, rp, dp = _inputs(g)
+    codec.trace = {}
+    out = codec.compress(rp, dp)
+    tr, codec.trace = codec.trace, None
+    if out["r_strings"][0][0] != g["r_y"].tobytes() or out["d_strings"][0][0] != g["d_y"].tobytes():
+        pytest.skip("this CPU's conv kernels differ in the last bits from the golden machine")
+    gc = coder.Tables(kat["gc_cdf"], kat["gc_sizes"], kat["gc_offsets"])
+    sym = {0: [], 1: []}
+    idx = {0: [], 1: []}
+    for p in tr["parts"]:
+        m = 0 if p["mod"] == "rgb" else 1
+        sym[m].append(p["symbols"].reshape(-1).numpy().astype(np.int32))
+        idx[m].append(p["indexes"].reshape(-1).numpy().astype(np.int32))
+    sym = {m: np.concatenate(v) for m, v in sym.items()}
+    idx = {m: np.concatenate(v) for m, v in idx.items()}
+    golden = {0: g["r_y"].tobytes(), 1: g["d_y"].tobytes()}
+    sizes = part_sizes(codec.slice_ch, 8, 12)
+    assert sum(sizes) == sym[0].shape[0] == 320 * 8 * 12
+    assert golden_parts_identical(sym, idx, golden, gc, sizes) == (20, 20)
+    # a symbol flipped in the depth stream's 3rd part (slice 1, anchor) = coding-order part 5: parts 0..4 stay clean
+    bad = {0: sym[0], 1: sym[1].copy()}
+    pos = sizes[0] + sizes[1] + 7
+    bad[1][pos] += 1
+    assert golden_parts_identical(bad, idx, golden, gc, sizes) == (5, 20)
+    # an index moved in the rgb stream's first part: nothing is clean
+    badi = {0: idx[0].copy(), 1: idx[1]}
+    badi[0][3] = (badi[0][3] + 9) % 64
+    clean, total = golden_parts_identical(sym, badi, golden, gc, sizes)
+    assert total == 20 and clean == 0
