@@ -179,6 +179,10 @@ int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, in
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
 int rgbd_debug_force_splitk(int32_t s);
+/* ResidualBottleneck / ResidualUnit tails (3x3 + ReLU -> 1x1 + residual; res_blk.py:7-27, layers.py:177-196) run as one
+ * launch where that is faster.  -1 = automatic (default), 0 = never, 1 / 2 / 4 = always, with 64 / 128 / 256-pixel tiles.
+ * Results are bit-identical in every mode. */
+int rgbd_debug_force_fuse(int32_t mode);
 /* Convolution tile tables: mode 0 (default) = the winners of isolated launches (lowest latency of one compress / decompress),
  * mode 1 = the winners with the chip shared between several engine instances (highest job throughput; CodecPool sets it).
  * Results are bit-identical in both modes -- tile choice never changes an output. */

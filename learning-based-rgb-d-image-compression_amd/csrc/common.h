@@ -68,12 +68,21 @@ struct ConvArgs {
     int loaded;      // tile-table flavour: 0 = winners of isolated launches (latency), 1 = winners with the chip shared (throughput)
     int ckbd;        // checkerboard output: 0 = every position, 1 = anchor positions only ((row + col) odd, ckbd.py:37-48),
                      // 2 = non-anchor positions only; the other half of y is left untouched (stride-1, single-phase convs)
+    // Fused trailing 1x1 (launch_conv_fused; ResidualBottleneck branch.2 -> branch.4, ResidualUnit conv.2 -> conv.4):
+    // t = act_mid(conv(x) + bias) stays in the accumulator registers and is the B operand of a second GEMM
+    // y = act(w2 * t + bias2 + res1).  cout_pad / w / bias describe the first layer, y / ycs / cout_store / res1 / act the
+    // second; the fma chain of every y element is the one the stand-alone 1x1 launch runs (chunk -> channel).
+    const float* w2;     // packed [cout2_pad][1][cout_pad]; nullptr = no fused layer
+    const float* bias2;  // [cout2_pad]
+    int cout2_pad;
+    int act_mid;
     TapTable taps;
 };
 
 // split factor of a layer: a function of the layer and of the per-image output grid only -- never of the batch size -- so
 // the summation order of every output is the same in the encoder, the decoder and for any batching of the same images
 extern char g_conv_force[64];
+extern int g_fuse_force;  // rgbd_debug_force_fuse (conv_mfma.hip)
 static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_per_image, int nphase)
 {
     const long K = (long)cin_pad * taps_per_phase;
@@ -93,6 +102,10 @@ static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_p
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s);
+// conv + fused trailing 1x1 (ConvArgs::w2).  conv_fused_plan returns the pixel-tile class the launch would use
+// (1 / 2 / 4 = 64 / 128 / 256 pixels per workgroup) or 0 when this pair of layers on this grid is not worth fusing.
+int conv_fused_plan(int cout_pad, int cout2_pad, int ntaps, int N, int GH, int GW, int loaded);
+int launch_conv_fused(const ConvArgs& a, hipStream_t s);
 int conv_log_enable(int on);            // shape log for tools/tune_tiles.py
 long conv_log_read(char* buf, long cap);  // CSV text; returns the size needed
 

@@ -38,9 +38,9 @@ __device__ __forceinline__ float sigmoid_f32(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
-                                                         int taps_per_stage, int tab_f)
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, int tiles_x, int tiles_y, int taps_per_stage,
+                                               int tab_f)
 {
     constexpr int TM = 16 * MT * WM;
     constexpr int TP = 16 * NT * WN;
@@ -308,6 +308,137 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
         }
     }
 
+    if constexpr (G2 > 0) {
+        // ---- fused trailing 1x1 (ConvArgs::w2) ---------------------------------------------------------------------
+        // WM == 1 and TM == cout_pad: this wave's accumulators hold every channel of t for its 16*NT pixels.  In the
+        // MFMA result layout lane group q holds channels 4q..4q+3 of a 16-channel tile in the four accumulator
+        // registers -- exactly what the B operand of k-step e (register e) of the next GEMM needs, and exactly the
+        // channel order (e, 4+e, 8+e, 12+e; e = 0..3) the stand-alone kernel's ds_read_b128 fragments produce.  So t
+        // never leaves the registers, and each y element is the same fma chain as in the unfused pair of launches.
+        // The second layer's weights come through LDS in groups of G2 cout tiles (double-buffered, register-staged);
+        // each group's outputs leave through the same LDS transpose as the ordinary epilogue.
+        static_assert(WM == 1 && KC == 16, "fused tail: one wave row, 16-channel stages");
+        constexpr int SLAB4 = MT * G2 * 64;  // 16-byte slots of one weight group: [MT chunks][16*G2 rows][4]
+        constexpr int WU = (SLAB4 + 255) / 256;
+        constexpr int SW2 = 16 * G2 + 4;  // staging row stride (floats)
+        constexpr int S42 = 4 * G2;       // float4 per staged pixel row
+        constexpr int EU2 = TP * S42 / 256;
+        static_assert(TP * S42 % 256 == 0, "fused epilogue tiling");
+        float* w2l = smem;                  // [2][SLAB4 * 4]
+        float* est = smem + 2 * SLAB4 * 4;  // [TP][SW2]
+        const int K2 = a.cout_pad;          // reduction length of the second layer (= TM)
+        const int ng2 = a.cout2_pad / (16 * G2);
+        unsigned w2_off[WU];
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int f = tid + u * 256;
+            const int c = f / (G2 * 64), row = (f >> 2) % (G2 * 16), c4 = f & 3;
+            w2_off[u] = (unsigned)(row * K2 + c * 16 + c4 * 4) * 4u;
+        }
+        f32x4 pw2[WU];
+        auto issue_w2 = [&](int g) {
+            const char* base = reinterpret_cast<const char*>(a.w2) + (size_t)g * (G2 * 16) * K2 * 4;  // wave-uniform
+#pragma unroll
+            for (int u = 0; u < WU; ++u)
+                if (tid + u * 256 < SLAB4) pw2[u] = *reinterpret_cast<const f32x4*>(base + w2_off[u]);
+        };
+        auto commit_w2 = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < WU; ++u)
+                if (tid + u * 256 < SLAB4)
+                    *reinterpret_cast<f32x4*>(w2l + buf * (SLAB4 * 4) + (tid + u * 256) * 4) = pw2[u];
+        };
+        issue_w2(0);
+        // t = act_mid(acc + bias): the float operations of the stand-alone launch's epilogue
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + i * 16 + q * 4);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                f32x4 t = acc[i][k] + b4;
+                if (a.act_mid == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+                }
+                acc[i][k] = t;
+            }
+        }
+        __syncthreads();  // every wave has left the main loop: the stage buffers are free
+        commit_w2(0);
+        __syncthreads();
+        const size_t img_px2 = (size_t)n * a.OH * a.OW;
+        char* yn2 = reinterpret_cast<char*>(a.y + img_px2 * a.ycs);
+        const char* r1n2 = reinterpret_cast<const char*>(a.res1 + img_px2 * a.r1cs);
+        for (int g = 0; g < ng2; ++g) {
+            if (g + 1 < ng2) issue_w2(g + 1);
+            f32x4 acc2[G2][NT];
+#pragma unroll
+            for (int i = 0; i < G2; ++i)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) acc2[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* cw = w2l + (g & 1) * (SLAB4 * 4);
+#pragma unroll
+            for (int c = 0; c < MT; ++c) {
+                f32x4 af2[G2];
+#pragma unroll
+                for (int i = 0; i < G2; ++i)
+                    af2[i] = *reinterpret_cast<const f32x4*>(cw + ((c * G2 + i) * 16 + l15) * 16 + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < G2; ++i)
+#pragma unroll
+                        for (int k = 0; k < NT; ++k)
+                            acc2[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[i][e], acc[c][k][e], acc2[i][k], 0, 0, 0);
+            }
+            if (g > 0) __syncthreads();  // everyone has read the previous group out of the staging tile
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int p = (wn * NT + k) * 16 + l15;
+#pragma unroll
+                for (int i = 0; i < G2; ++i) *reinterpret_cast<f32x4*>(est + p * SW2 + i * 16 + q * 4) = acc2[i][k];
+            }
+            if (g + 1 < ng2) commit_w2((g + 1) & 1);  // that buffer was last read two barriers ago
+            __syncthreads();
+            constexpr int UB2 = EU2 % 4 == 0 ? 4 : (EU2 % 3 == 0 ? 3 : (EU2 % 2 == 0 ? 2 : 1));
+            for (int u0 = 0; u0 < EU2; u0 += UB2) {
+                f32x4 r1[UB2], v[UB2];
+                unsigned pixs[UB2];
+                int cbs[UB2];
+                bool ok[UB2];
+#pragma unroll
+                for (int u = 0; u < UB2; ++u) {
+                    const int f = tid + (u0 + u) * 256;
+                    const int p = f / S42, c4 = f - p * S42;
+                    const int cb = g * (G2 * 16) + c4 * 4;
+                    const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+                    ok[u] = cb < a.cout_store && gy < a.GH && gx < a.GW;
+                    cbs[u] = cb;
+                    pixs[u] = (unsigned)(gy * a.OW + gx);
+                    v[u] = *reinterpret_cast<const f32x4*>(est + p * SW2 + c4 * 4);
+                    r1[u] = (ok[u] && a.res1)
+                                ? *reinterpret_cast<const f32x4*>(r1n2 + (size_t)((pixs[u] * (unsigned)a.r1cs + cb) * 4u))
+                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < UB2; ++u) {
+                    if (!ok[u]) continue;
+                    f32x4 w = v[u] + *reinterpret_cast<const f32x4*>(a.bias2 + cbs[u]);
+                    if (a.res1) w += r1[u];
+                    if (a.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = fmaxf(w[e], 0.f);
+                    } else if (a.act == ACT_LEAKY) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = w[e] > 0.f ? w[e] : w[e] * 0.01f;
+                    }
+                    *reinterpret_cast<f32x4*>(yn2 + (size_t)((pixs[u] * (unsigned)a.ycs + cbs[u]) * 4u)) = w;
+                }
+            }
+        }
+        return;
+    }
+
     // Epilogue.  The MFMA result layout gives each lane 4 consecutive couts of one pixel (64-byte segments per pixel
     // and store instruction); writing that straight to HBM wastes half of every 128-byte line transaction.  The tile is
     // therefore staged through LDS as [pixel][cout] and written back by all 256 threads with consecutive lanes on
@@ -386,11 +517,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
     }
 }
 
+template <int WM, int WN, int MT, int NT, int KC, bool DMA>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
+                                                         int taps_per_stage, int tab_f)
+{
+    conv_mfma_body<WM, WN, MT, NT, KC, DMA, 0>(a, tw_log2, tiles_x, tiles_y, taps_per_stage, tab_f);
+}
+
+// The fused variants are compiled for two workgroups per CU (256 registers per lane): left alone, the allocator parks the
+// first layer's accumulators in AGPRs and copies them into VGPRs for the second GEMM (302 registers, one workgroup per CU).
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_mfma_kernel_fused(
+    ConvArgs a, int tw_log2, int tiles_x, int tiles_y, int taps_per_stage, int tab_f)
+{
+    conv_mfma_body<WM, WN, MT, NT, KC, DMA, G2>(a, tw_log2, tiles_x, tiles_y, taps_per_stage, tab_f);
+}
+
 namespace {
 
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2 = 0>
 int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
 {
     const long budget = lds_cap > 0 ? lds_cap : LDS_BUDGET;
@@ -418,9 +565,15 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;
     const size_t epi_bytes = (size_t)TP * (16 * WM * EMT + 4) * sizeof(float);
     const size_t stage_bytes = (patch_bytes + (size_t)tps * tap_bytes) * (DMA ? 2 : 1);
-    const size_t buf_bytes = ((stage_bytes > epi_bytes ? stage_bytes : epi_bytes) + 15) & ~(size_t)15;
+    // fused tail: two weight-group slabs + the output staging tile (it replaces the ordinary epilogue)
+    const size_t fuse_bytes = G2 > 0 ? (size_t)2 * MT * G2 * 1024 + (size_t)TP * (16 * G2 + 4) * sizeof(float) : 0;
+    const size_t tail_bytes = G2 > 0 ? fuse_bytes : epi_bytes;
+    const size_t buf_bytes = ((stage_bytes > tail_bytes ? stage_bytes : tail_bytes) + 15) & ~(size_t)15;
     const size_t lds = buf_bytes + 256;  // + the workgroup's expanded tap table (2 x 32 ints)
-    auto kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
+    if (G2 > 0 && (lds > (size_t)LDS_BUDGET + 256 || a.cout_pad != TM || a.cout2_pad % (16 * (G2 > 0 ? G2 : 1)))) return RGBD_ENOSPC;
+    void (*kern)(ConvArgs, int, int, int, int, int);
+    if constexpr (G2 > 0) kern = conv_mfma_kernel_fused<WM, WN, MT, NT, KC, DMA, G2>;
+    else kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
     if (lds > 64 * 1024) {  // the attribute is per device: one flag per (instantiation, device), set under a lock
         static std::mutex mu;
         static bool configured[64] = {false};
@@ -730,5 +883,55 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     RGBD_CASE(2, 2, 5, 1) RGBD_CASE(2, 2, 4, 1) RGBD_CASE(2, 2, 3, 1) RGBD_CASE(2, 2, 2, 1) RGBD_CASE(2, 2, 1, 1)
     RGBD_CASE(1, 4, 3, 2) RGBD_CASE(1, 4, 2, 2) RGBD_CASE(1, 4, 1, 2)
     RGBD_CASE(1, 4, 3, 1) RGBD_CASE(1, 4, 2, 1) RGBD_CASE(1, 4, 1, 1)
+    return RGBD_EINVAL;
+}
+
+// ---- conv + fused trailing 1x1 ---------------------------------------------------------------------------------------
+// The pair (3x3 C->C, 1x1 C->C2) of a ResidualBottleneck / ResidualUnit as one launch: the first layer's whole cout range
+// is one workgroup tile (TM = cout_pad = 96), pixel tiles of 64 / 128 / 256.  Results are bit-identical to the two
+// stand-alone launches (tests/test_gpu_conv.py::test_fused_tail_bit_identical), so fusing is a speed decision only.
+static const bool g_fuse_off = getenv("RGBD_NO_FUSE") != nullptr;
+int g_fuse_force = -1;  // rgbd_debug_force_fuse: -1 = plan, 0 = never, 1 / 2 / 4 = always with that pixel-tile class
+
+int conv_fused_plan(int cout_pad, int cout2_pad, int ntaps, int N, int GH, int GW, int loaded)
+{
+    if (g_fuse_off || g_fuse_force == 0) return 0;
+    if (cout_pad != 96 || cout2_pad % 96 || ntaps > 9) return 0;  // instantiated: MT = 6; groups of 2 or 3 cout tiles
+    if (g_fuse_force > 0) return g_fuse_force;
+    static const char* nt_env = getenv("RGBD_FUSE_NT");
+    if (nt_env) return atoi(nt_env);
+    const long px = (long)N * GH * GW;
+    // enough workgroups to fill 256 CUs twice with the widest tile that still does; a launch that cannot fill the chip
+    // once with 64-pixel tiles stays unfused (the stand-alone kernels tile the couts as well)
+    if (px / 256 >= (loaded ? 320 : 480)) return 4;
+    if (px / 128 >= 320) return 2;
+    if (px / 64 >= 256) return 1;
+    return 0;
+}
+
+int launch_conv_fused(const ConvArgs& a_in, hipStream_t s)
+{
+    ConvArgs a = a_in;
+    if (!a.w2 || !a.bias2 || a.cout2_pad <= 0) return RGBD_EINVAL;
+    if (a.cout_store <= 0 || a.cout_store > a.cout2_pad) a.cout_store = a.cout2_pad;
+    if (a.cout_store % 4) return RGBD_EINVAL;
+    if (a.nphase != 1 || a.IS != 1 || a.OS != 1 || a.splitk > 1 || a.partial || a.mul || a.res2 || a.ckbd) return RGBD_EINVAL;
+    if (a.act != ACT_NONE && a.act != ACT_RELU && a.act != ACT_LEAKY) return RGBD_EINVAL;
+    if (a.act_mid != ACT_NONE && a.act_mid != ACT_RELU) return RGBD_EINVAL;
+    if (a.cin_pad % 16 || a.cout_pad % 16 || a.xcs % 4 || a.ycs % 4 || a.N <= 0 || a.GH <= 0 || a.GW <= 0) return RGBD_EINVAL;
+    if (a.OH != a.GH || a.OW != a.GW) return RGBD_EINVAL;
+    a.splitk = 1;
+    {
+        const size_t lim = (size_t)1 << 32;
+        const size_t opx = (size_t)a.OH * a.OW * 4;
+        const int ocs = std::max(std::max(a.ycs, a.cout2_pad), a.r1cs);
+        if ((size_t)a.H * a.W * a.xcs * 4 >= lim || opx * ocs >= lim || (size_t)a.cout_pad * a.ntaps_total * a.cin_pad * 4 >= lim)
+            return RGBD_EINVAL;
+    }
+    const int cls = conv_fused_plan(a.cout_pad, a.cout2_pad, a.ntaps_total, a.N, a.GH, a.GW, a.loaded);
+    if (a.cout_pad != 96) return RGBD_EINVAL;
+    if (cls == 4) return launch_cfg<1, 4, 6, 4, 16, true, 2>(a, pick_tw_log2(a.GW, a.GH, 256), s);
+    if (cls == 2) return launch_cfg<1, 4, 6, 2, 16, true, 3>(a, pick_tw_log2(a.GW, a.GH, 128), s);
+    if (cls == 1) return launch_cfg<1, 4, 6, 1, 16, true, 3>(a, pick_tw_log2(a.GW, a.GH, 64), s);
     return RGBD_EINVAL;
 }

@@ -529,10 +529,15 @@ struct rgbd_elic {
     }
 
     // --- operators -----------------------------------------------------------------------------
-    Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr)
+    // fuse1x1: name of a 1x1 layer applied to relu(conv(x)) inside the same launch (launch_conv_fused); ep / dst / the
+    // returned tensor then describe that second layer's output.  Callers ask fusable() first.
+    Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
+             const std::string* fuse1x1 = nullptr)
     {
         const PackedConv* pc = conv_of(name + ".weight");
         if (!pc) return Act();
+        const PackedConv* pc2 = fuse1x1 ? conv_of(*fuse1x1 + ".weight") : nullptr;
+        if (fuse1x1 && !pc2) return Act();
         const int k = pc->k;
         int OH, OW;
         if (!pc->transposed) {
@@ -542,8 +547,10 @@ struct rgbd_elic {
             OH = (x.h - 1) * stride - 2 * pad + k + (stride - 1);
             OW = (x.w - 1) * stride - 2 * pad + k + (stride - 1);
         }
-        Act y = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
-        if (round_up(x.c, 16) != pc->cin_pad || y.h != OH || y.w != OW || y.n != x.n || y.c != pc->cout) {
+        const PackedConv* pcy = pc2 ? pc2 : pc;  // the layer that produces y
+        Act y = dst ? *dst : alloc(x.n, OH, OW, pcy->cout);
+        if (round_up(x.c, 16) != pc->cin_pad || y.h != OH || y.w != OW || y.n != x.n || y.c != pcy->cout ||
+            (pc2 && (pc2->k != 1 || pc2->cin_pad != pc->cout_pad || pc2->transposed))) {
             fprintf(stderr, "[rgbd_amd] shape mismatch at %s: x.c=%d cin=%d y=(%d,%d,%d) expect (%d,%d,%d)\n", name.c_str(),
                     x.c, pc->cin, y.h, y.w, y.c, OH, OW, pc->cout);
             fail(RGBD_EINVAL);
@@ -573,7 +580,13 @@ struct rgbd_elic {
         a.cout_pad = pc->cout_pad;
         // a channel slice narrower than its 16-padded width inside a wider buffer (STF_united: 24 of 48): stop at the
         // slice end; a buffer of its own gets its pad channels zeroed as usual
-        a.cout_store = (pc->cout % 16 && y.cs != round_up(pc->cout, 16)) ? round_up(pc->cout, 4) : pc->cout_pad;
+        a.cout_store = (pcy->cout % 16 && y.cs != round_up(pcy->cout, 16)) ? round_up(pcy->cout, 4) : pcy->cout_pad;
+        if (pc2) {
+            a.w2 = pc2->w;
+            a.bias2 = pc2->bias;
+            a.cout2_pad = pc2->cout_pad;
+            a.act_mid = ACT_RELU;
+        }
         make_taps(*pc, stride, pad, &a);
         a.GH = pc->transposed ? x.h : OH;
         a.GW = pc->transposed ? x.w : OW;
@@ -624,11 +637,12 @@ struct rgbd_elic {
             e1 = ev_pool[ev_used++];
             (void)hipEventRecord(e0, s);
         }
-        const int r = launch_conv(a, s);
+        const int r = pc2 ? launch_conv_fused(a, s) : launch_conv(a, s);
         if (profile) {
             (void)hipEventRecord(e1, s);
             const double fl = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
-                              (pc->transposed ? (double)(stride * stride) : 1.0);
+                                  (pc->transposed ? (double)(stride * stride) : 1.0) +
+                              (pc2 ? 2.0 * (double)x.n * OH * OW * (double)pc2->cout * pc2->cin : 0.0);
             prof_flops += fl;
             ++prof_launches;
             ev_names.emplace_back(name, fl);
@@ -667,6 +681,16 @@ struct rgbd_elic {
         if (r) fail(r);
     }
 
+    // the pair (mid: 3x3 + ReLU, last: 1x1 + residual) as one launch?  (a speed decision: the results are bit-identical)
+    bool fusable(const std::string& mid, const std::string& last, const Act& x)
+    {
+        auto a = convs.find(mid + ".weight"), b = convs.find(last + ".weight");
+        if (a == convs.end() || b == convs.end()) return false;
+        const PackedConv &p3 = a->second, &p1 = b->second;
+        if (p3.transposed || p1.transposed || p1.k != 1 || p3.k != 3 || p1.cin_pad != p3.cout_pad || p1.cout % 16) return false;
+        return conv_fused_plan(p3.cout_pad, p1.cout_pad, p3.k * p3.k, x.n, x.h, x.w, tile_mode) > 0;
+    }
+
     // modules/layers/res_blk.py:7-27
     Act bottleneck(const std::string& p, const Act& x, const Act* dst = nullptr)
     {
@@ -677,12 +701,17 @@ struct rgbd_elic {
         Epi relu;
         relu.act = ACT_RELU;
         Act t1 = conv(p + ".branch.0", x, 1, 0, relu);
-        Act t2 = conv(p + ".branch.2", t1, 1, 1, relu);
         Epi e;
         Act idn = x;
         if (convs.count(p + ".skip.weight")) idn = conv(p + ".skip", x, 1, 0);
         e.res1 = &idn;
-        conv(p + ".branch.4", t2, 1, 0, e, &out);
+        const std::string last_name = p + ".branch.4";
+        if (fusable(p + ".branch.2", last_name, t1)) {
+            conv(p + ".branch.2", t1, 1, 1, e, &out, &last_name);
+        } else {
+            Act t2 = conv(p + ".branch.2", t1, 1, 1, relu);
+            conv(last_name, t2, 1, 0, e, &out);
+        }
         arena.top = mark;
         return out;
     }
@@ -695,11 +724,16 @@ struct rgbd_elic {
         Epi relu;
         relu.act = ACT_RELU;
         Act t1 = conv(p + ".conv.0", x, 1, 0, relu);
-        Act t2 = conv(p + ".conv.2", t1, 1, 1, relu);
         Epi e;
         e.act = ACT_RELU;
         e.res1 = &x;
-        conv(p + ".conv.4", t2, 1, 0, e, &out);
+        const std::string last_name = p + ".conv.4";
+        if (fusable(p + ".conv.2", last_name, t1)) {
+            conv(p + ".conv.2", t1, 1, 1, e, &out, &last_name);
+        } else {
+            Act t2 = conv(p + ".conv.2", t1, 1, 1, relu);
+            conv(last_name, t2, 1, 0, e, &out);
+        }
         arena.top = mark;
         return out;
     }
@@ -2491,6 +2525,15 @@ int rgbd_debug_force_ckbd(int32_t part)
 {
     if (part < 0 || part > 2) return RGBD_EINVAL;
     g_force_ckbd = part;
+    ++g_cfg_epoch;
+    return RGBD_OK;
+}
+
+// -1: fuse where the plan says so (default), 0: never, 1 / 2 / 4: always, with 64 / 128 / 256-pixel tiles
+int rgbd_debug_force_fuse(int32_t mode)
+{
+    if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 4) return RGBD_EINVAL;
+    g_fuse_force = mode;
     ++g_cfg_epoch;
     return RGBD_OK;
 }
