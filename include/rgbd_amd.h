@@ -180,8 +180,9 @@ int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, in
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
 int rgbd_debug_force_splitk(int32_t s);
 /* ResidualBottleneck / ResidualUnit tails (3x3 + ReLU -> 1x1 + residual; res_blk.py:7-27, layers.py:177-196) run as one
- * launch where that is faster.  -1 = automatic (default), 0 = never, 1 / 2 / 4 = always, with 64 / 128 / 256-pixel tiles.
- * Results are bit-identical in every mode. */
+ * launch where that is faster, together with the leading 1x1 + ReLU of the block that follows.  -1 = automatic (default),
+ * 0 = never, 1 / 2 / 4 = always, with 64 / 128 / 256-pixel tiles; + 16 (15, 17, 18, 20) = the same without the following
+ * block's leading layer.  Results are bit-identical in every mode. */
 int rgbd_debug_force_fuse(int32_t mode);
 /* Convolution tile tables: mode 0 (default) = the winners of isolated launches (lowest latency of one compress / decompress),
  * mode 1 = the winners with the chip shared between several engine instances (highest job throughput; CodecPool sets it).

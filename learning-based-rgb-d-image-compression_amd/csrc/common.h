@@ -76,13 +76,19 @@ struct ConvArgs {
     const float* bias2;  // [cout2_pad]
     int cout2_pad;
     int act_mid;
+    // ... and, optionally, the leading 1x1 of the block that follows: u = relu(w3 * y + bias3) -> y3 (cout3_pad = cout_pad)
+    const float* w3;     // packed [cout3_pad][1][cout2_pad]; nullptr = none
+    const float* bias3;
+    float* y3;
+    int y3cs;
+    int cout3_pad;
     TapTable taps;
 };
 
 // split factor of a layer: a function of the layer and of the per-image output grid only -- never of the batch size -- so
 // the summation order of every output is the same in the encoder, the decoder and for any batching of the same images
 extern char g_conv_force[64];
-extern int g_fuse_force;  // rgbd_debug_force_fuse (conv_mfma.hip)
+extern int g_fuse_force, g_fuse_lead_off;  // rgbd_debug_force_fuse (conv_mfma.hip)
 static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_per_image, int nphase)
 {
     const long K = (long)cin_pad * taps_per_phase;

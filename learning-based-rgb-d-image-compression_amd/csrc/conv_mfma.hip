@@ -38,7 +38,7 @@ __device__ __forceinline__ float sigmoid_f32(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2, bool LEAD = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, int tiles_x, int tiles_y, int taps_per_stage,
                                                int tab_f)
 {
@@ -328,6 +328,44 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
         float* est = smem + 2 * SLAB4 * 4;  // [TP][SW2]
         const int K2 = a.cout_pad;          // reduction length of the second layer (= TM)
         const int ng2 = a.cout2_pad / (16 * G2);
+        // LEAD: a third GEMM u = relu(w3 * y + bias3) (the next block's leading 1x1, TM couts again) rides along: each
+        // finished group of y (16*G2 channels, final values, read back from the staging tile in B-fragment layout) is one
+        // slice of its reduction, so u accumulates group by group in the order the stand-alone launch walks its chunks.
+        constexpr int SLAB3 = G2 * MT * 64;  // 16-byte slots of one w3 slice: [G2 chunks][TM rows][4]
+        constexpr int WU3 = (SLAB3 + 255) / 256;
+        float* w3l = est + TP * SW2;         // [2][SLAB3 * 4]
+        const int K3 = a.cout2_pad;
+        unsigned w3_off[LEAD ? WU3 : 1];
+        f32x4 pw3[LEAD ? WU3 : 1];
+        f32x4 uacc[LEAD ? MT : 1][LEAD ? NT : 1];
+        if constexpr (LEAD) {
+#pragma unroll
+            for (int u = 0; u < WU3; ++u) {
+                const int f = tid + u * 256;
+                const int c = f / (TM * 4), row = (f >> 2) % TM, c4 = f & 3;
+                w3_off[u] = (unsigned)(row * K3 + c * 16 + c4 * 4) * 4u;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) uacc[i][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        auto issue_w3 = [&](int g) {
+            if constexpr (LEAD) {
+                const char* base = reinterpret_cast<const char*>(a.w3) + (size_t)g * (G2 * 16) * 4;  // column slice g
+#pragma unroll
+                for (int u = 0; u < WU3; ++u)
+                    if (tid + u * 256 < SLAB3) pw3[u] = *reinterpret_cast<const f32x4*>(base + w3_off[u]);
+            }
+        };
+        auto commit_w3 = [&](int buf) {
+            if constexpr (LEAD) {
+#pragma unroll
+                for (int u = 0; u < WU3; ++u)
+                    if (tid + u * 256 < SLAB3)
+                        *reinterpret_cast<f32x4*>(w3l + buf * (SLAB3 * 4) + (tid + u * 256) * 4) = pw3[u];
+            }
+        };
         unsigned w2_off[WU];
 #pragma unroll
         for (int u = 0; u < WU; ++u) {
@@ -349,6 +387,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                     *reinterpret_cast<f32x4*>(w2l + buf * (SLAB4 * 4) + (tid + u * 256) * 4) = pw2[u];
         };
         issue_w2(0);
+        issue_w3(0);
         // t = act_mid(acc + bias): the float operations of the stand-alone launch's epilogue
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -365,12 +404,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
         }
         __syncthreads();  // every wave has left the main loop: the stage buffers are free
         commit_w2(0);
+        commit_w3(0);
         __syncthreads();
         const size_t img_px2 = (size_t)n * a.OH * a.OW;
         char* yn2 = reinterpret_cast<char*>(a.y + img_px2 * a.ycs);
         const char* r1n2 = reinterpret_cast<const char*>(a.res1 + img_px2 * a.r1cs);
         for (int g = 0; g < ng2; ++g) {
-            if (g + 1 < ng2) issue_w2(g + 1);
+            if (g + 1 < ng2) {
+                issue_w2(g + 1);
+                issue_w3(g + 1);
+            }
             f32x4 acc2[G2][NT];
 #pragma unroll
             for (int i = 0; i < G2; ++i)
@@ -398,7 +441,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                 for (int i = 0; i < G2; ++i) *reinterpret_cast<f32x4*>(est + p * SW2 + i * 16 + q * 4) = acc2[i][k];
             }
-            if (g + 1 < ng2) commit_w2((g + 1) & 1);  // that buffer was last read two barriers ago
+            if (g + 1 < ng2) {  // those buffers were last read two barriers ago
+                commit_w2((g + 1) & 1);
+                commit_w3((g + 1) & 1);
+            }
             __syncthreads();
             constexpr int UB2 = EU2 % 4 == 0 ? 4 : (EU2 % 3 == 0 ? 3 : (EU2 % 2 == 0 ? 2 : 1));
             for (int u0 = 0; u0 < EU2; u0 += UB2) {
@@ -433,7 +479,64 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                         for (int e = 0; e < 4; ++e) w[e] = w[e] > 0.f ? w[e] : w[e] * 0.01f;
                     }
                     *reinterpret_cast<f32x4*>(yn2 + (size_t)((pixs[u] * (unsigned)a.ycs + cbs[u]) * 4u)) = w;
+                    if constexpr (LEAD) v[u] = w;
                 }
+                if constexpr (LEAD) {  // the final y values go back into the slots they came from (same thread)
+#pragma unroll
+                    for (int u = 0; u < UB2; ++u) {
+                        const int f = tid + (u0 + u) * 256;
+                        const int p = f / S42, c4 = f - p * S42;
+                        *reinterpret_cast<f32x4*>(est + p * SW2 + c4 * 4) = v[u];
+                    }
+                }
+            }
+            if constexpr (LEAD) {
+                __syncthreads();
+                const float* cw3 = w3l + (g & 1) * (SLAB3 * 4);
+#pragma unroll
+                for (int c = 0; c < G2; ++c) {
+                    f32x4 af3[MT], bf3[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) af3[i] = *reinterpret_cast<const f32x4*>(cw3 + ((c * MT + i) * 16 + l15) * 16 + q * 4);
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        bf3[k] = *reinterpret_cast<const f32x4*>(est + ((wn * NT + k) * 16 + l15) * SW2 + c * 16 + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+                                uacc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af3[i][e], bf3[k][e], uacc[i][k], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (LEAD) {
+            // u = relu(uacc + bias3) leaves through an LDS transpose like any other output tile
+            constexpr int SW3 = 16 * MT + 4, S43 = 4 * MT, EU3 = TP * S43 / 256;
+            static_assert(TP * S43 % 256 == 0, "lead epilogue tiling");
+            __syncthreads();  // the last group's fragments have been read
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias3 + i * 16 + q * 4);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    f32x4 t = uacc[i][k] + b4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+                    *reinterpret_cast<f32x4*>(smem + ((wn * NT + k) * 16 + l15) * SW3 + i * 16 + q * 4) = t;
+                }
+            }
+            __syncthreads();
+            char* y3n = reinterpret_cast<char*>(a.y3 + img_px2 * a.y3cs);
+#pragma unroll
+            for (int u = 0; u < EU3; ++u) {
+                const int f = tid + u * 256;
+                const int p = f / S43, c4 = f - p * S43;
+                const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+                if (gy < a.GH && gx < a.GW)
+                    *reinterpret_cast<f32x4*>(y3n + (size_t)(((unsigned)(gy * a.OW + gx) * (unsigned)a.y3cs + c4 * 4) * 4u)) =
+                        *reinterpret_cast<const f32x4*>(smem + p * SW3 + c4 * 4);
             }
         }
         return;
@@ -526,18 +629,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2,
 
 // The fused variants are compiled for two workgroups per CU (256 registers per lane): left alone, the allocator parks the
 // first layer's accumulators in AGPRs and copies them into VGPRs for the second GEMM (302 registers, one workgroup per CU).
-template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2, bool LEAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_mfma_kernel_fused(
     ConvArgs a, int tw_log2, int tiles_x, int tiles_y, int taps_per_stage, int tab_f)
 {
-    conv_mfma_body<WM, WN, MT, NT, KC, DMA, G2>(a, tw_log2, tiles_x, tiles_y, taps_per_stage, tab_f);
+    conv_mfma_body<WM, WN, MT, NT, KC, DMA, G2, LEAD>(a, tw_log2, tiles_x, tiles_y, taps_per_stage, tab_f);
 }
 
 namespace {
 
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2 = 0>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2 = 0, bool LEAD = false>
 int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
 {
     const long budget = lds_cap > 0 ? lds_cap : LDS_BUDGET;
@@ -566,13 +669,19 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     const size_t epi_bytes = (size_t)TP * (16 * WM * EMT + 4) * sizeof(float);
     const size_t stage_bytes = (patch_bytes + (size_t)tps * tap_bytes) * (DMA ? 2 : 1);
     // fused tail: two weight-group slabs + the output staging tile (it replaces the ordinary epilogue)
-    const size_t fuse_bytes = G2 > 0 ? (size_t)2 * MT * G2 * 1024 + (size_t)TP * (16 * G2 + 4) * sizeof(float) : 0;
+    size_t fuse_bytes = G2 > 0 ? (size_t)2 * MT * G2 * 1024 + (size_t)TP * (16 * G2 + 4) * sizeof(float) : 0;
+    if (LEAD) {  // + two slices of the third layer's weights; the u tile is staged over everything at the end
+        fuse_bytes += (size_t)2 * G2 * MT * 1024;
+        const size_t u_bytes = (size_t)TP * (16 * MT + 4) * sizeof(float);
+        fuse_bytes = fuse_bytes > u_bytes ? fuse_bytes : u_bytes;
+        if (!a.w3 || !a.bias3 || !a.y3 || a.cout3_pad != TM || a.y3cs % 4) return RGBD_EINVAL;
+    }
     const size_t tail_bytes = G2 > 0 ? fuse_bytes : epi_bytes;
     const size_t buf_bytes = ((stage_bytes > tail_bytes ? stage_bytes : tail_bytes) + 15) & ~(size_t)15;
     const size_t lds = buf_bytes + 256;  // + the workgroup's expanded tap table (2 x 32 ints)
     if (G2 > 0 && (lds > (size_t)LDS_BUDGET + 256 || a.cout_pad != TM || a.cout2_pad % (16 * (G2 > 0 ? G2 : 1)))) return RGBD_ENOSPC;
     void (*kern)(ConvArgs, int, int, int, int, int);
-    if constexpr (G2 > 0) kern = conv_mfma_kernel_fused<WM, WN, MT, NT, KC, DMA, G2>;
+    if constexpr (G2 > 0) kern = conv_mfma_kernel_fused<WM, WN, MT, NT, KC, DMA, G2, LEAD>;
     else kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
     if (lds > 64 * 1024) {  // the attribute is per device: one flag per (instantiation, device), set under a lock
         static std::mutex mu;
@@ -892,6 +1001,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
 // stand-alone launches (tests/test_gpu_conv.py::test_fused_tail_bit_identical), so fusing is a speed decision only.
 static const bool g_fuse_off = getenv("RGBD_NO_FUSE") != nullptr;
 int g_fuse_force = -1;  // rgbd_debug_force_fuse: -1 = plan, 0 = never, 1 / 2 / 4 = always with that pixel-tile class
+int g_fuse_lead_off = 0;  // ... + 16: without the next block's leading 1x1
 
 int conv_fused_plan(int cout_pad, int cout2_pad, int ntaps, int N, int GH, int GW, int loaded)
 {
@@ -930,6 +1040,12 @@ int launch_conv_fused(const ConvArgs& a_in, hipStream_t s)
     }
     const int cls = conv_fused_plan(a.cout_pad, a.cout2_pad, a.ntaps_total, a.N, a.GH, a.GW, a.loaded);
     if (a.cout_pad != 96) return RGBD_EINVAL;
+    if (a.w3) {  // + the next block's leading 1x1: 128- and 64-pixel tiles only (u needs TM x TP accumulators as well)
+        if (a.cout2_pad % 32) return RGBD_EINVAL;
+        if (cls >= 2) return launch_cfg<1, 4, 6, 2, 16, true, 2, true>(a, pick_tw_log2(a.GW, a.GH, 128), s);
+        if (cls == 1) return launch_cfg<1, 4, 6, 1, 16, true, 2, true>(a, pick_tw_log2(a.GW, a.GH, 64), s);
+        return RGBD_EINVAL;
+    }
     if (cls == 4) return launch_cfg<1, 4, 6, 4, 16, true, 2>(a, pick_tw_log2(a.GW, a.GH, 256), s);
     if (cls == 2) return launch_cfg<1, 4, 6, 2, 16, true, 3>(a, pick_tw_log2(a.GW, a.GH, 128), s);
     if (cls == 1) return launch_cfg<1, 4, 6, 1, 16, true, 3>(a, pick_tw_log2(a.GW, a.GH, 64), s);

@@ -531,13 +531,20 @@ struct rgbd_elic {
     // --- operators -----------------------------------------------------------------------------
     // fuse1x1: name of a 1x1 layer applied to relu(conv(x)) inside the same launch (launch_conv_fused); ep / dst / the
     // returned tensor then describe that second layer's output.  Callers ask fusable() first.
+    // lead1x1 / lead_dst (only with fuse1x1): a further 1x1 + ReLU applied to that output inside the same launch -- the
+    // leading layer of the block that follows -- written to *lead_dst.
     Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
-             const std::string* fuse1x1 = nullptr)
+             const std::string* fuse1x1 = nullptr, const std::string* lead1x1 = nullptr, const Act* lead_dst = nullptr)
     {
         const PackedConv* pc = conv_of(name + ".weight");
         if (!pc) return Act();
         const PackedConv* pc2 = fuse1x1 ? conv_of(*fuse1x1 + ".weight") : nullptr;
         if (fuse1x1 && !pc2) return Act();
+        const PackedConv* pc3 = (pc2 && lead1x1 && lead_dst) ? conv_of(*lead1x1 + ".weight") : nullptr;
+        if (lead1x1 && !pc3) {
+            fail(RGBD_EINVAL);
+            return Act();
+        }
         const int k = pc->k;
         int OH, OW;
         if (!pc->transposed) {
@@ -550,7 +557,9 @@ struct rgbd_elic {
         const PackedConv* pcy = pc2 ? pc2 : pc;  // the layer that produces y
         Act y = dst ? *dst : alloc(x.n, OH, OW, pcy->cout);
         if (round_up(x.c, 16) != pc->cin_pad || y.h != OH || y.w != OW || y.n != x.n || y.c != pcy->cout ||
-            (pc2 && (pc2->k != 1 || pc2->cin_pad != pc->cout_pad || pc2->transposed))) {
+            (pc2 && (pc2->k != 1 || pc2->cin_pad != pc->cout_pad || pc2->transposed)) ||
+            (pc3 && (pc3->k != 1 || pc3->cin_pad != pc2->cout_pad || pc3->transposed || lead_dst->c != pc3->cout ||
+                     lead_dst->h != OH || lead_dst->w != OW || lead_dst->n != x.n))) {
             fprintf(stderr, "[rgbd_amd] shape mismatch at %s: x.c=%d cin=%d y=(%d,%d,%d) expect (%d,%d,%d)\n", name.c_str(),
                     x.c, pc->cin, y.h, y.w, y.c, OH, OW, pc->cout);
             fail(RGBD_EINVAL);
@@ -586,6 +595,13 @@ struct rgbd_elic {
             a.bias2 = pc2->bias;
             a.cout2_pad = pc2->cout_pad;
             a.act_mid = ACT_RELU;
+        }
+        if (pc3) {
+            a.w3 = pc3->w;
+            a.bias3 = pc3->bias;
+            a.y3 = lead_dst->p;
+            a.y3cs = lead_dst->cs;
+            a.cout3_pad = pc3->cout_pad;
         }
         make_taps(*pc, stride, pad, &a);
         a.GH = pc->transposed ? x.h : OH;
@@ -642,7 +658,8 @@ struct rgbd_elic {
             (void)hipEventRecord(e1, s);
             const double fl = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
                                   (pc->transposed ? (double)(stride * stride) : 1.0) +
-                              (pc2 ? 2.0 * (double)x.n * OH * OW * (double)pc2->cout * pc2->cin : 0.0);
+                              (pc2 ? 2.0 * (double)x.n * OH * OW * (double)pc2->cout * pc2->cin : 0.0) +
+                              (pc3 ? 2.0 * (double)x.n * OH * OW * (double)pc3->cout * pc3->cin : 0.0);
             prof_flops += fl;
             ++prof_launches;
             ev_names.emplace_back(name, fl);
@@ -691,22 +708,55 @@ struct rgbd_elic {
         return conv_fused_plan(p3.cout_pad, p1.cout_pad, p3.k * p3.k, x.n, x.h, x.w, tile_mode) > 0;
     }
 
-    // modules/layers/res_blk.py:7-27
-    Act bottleneck(const std::string& p, const Act& x, const Act* dst = nullptr)
+    // ... and can the leading 1x1 + ReLU of the block after it ride along?  (its input is this block's output)
+    bool lead_fusable(const std::string& last, const std::string& lead)
+    {
+        static const bool off = getenv("RGBD_NO_FUSE_LEAD") != nullptr;
+        if (off || g_fuse_lead_off || lead.empty()) return false;
+        auto b = convs.find(last + ".weight"), c = convs.find(lead + ".weight");
+        if (b == convs.end() || c == convs.end()) return false;
+        const PackedConv &p1 = b->second, &p0 = c->second;
+        return !p0.transposed && p0.k == 1 && p0.cin_pad == p1.cout_pad && p0.cout_pad == p1.cin_pad && p0.cout % 16 == 0 &&
+               p1.cout_pad % 32 == 0;
+    }
+    // outputs of leading layers that a previous block's launch has already produced, by layer name
+    std::map<std::string, Act> pre_leads;
+    Act take_lead(const std::string& name, const Act& x)
+    {
+        auto it = pre_leads.find(name);
+        if (it != pre_leads.end()) {
+            Act t = it->second;
+            pre_leads.erase(it);
+            return t;
+        }
+        Epi relu;
+        relu.act = ACT_RELU;
+        return conv(name, x, 1, 0, relu);
+    }
+
+    // modules/layers/res_blk.py:7-27.  next_lead: the leading layer of the block that consumes this block's output ("" = none)
+    Act bottleneck(const std::string& p, const Act& x, const Act* dst = nullptr, const std::string& next_lead = std::string())
     {
         const PackedConv* last = conv_of(p + ".branch.4.weight");
         if (!last) return Act();
         Act out = dst ? *dst : alloc(x.n, x.h, x.w, last->cout);
+        const std::string last_name = p + ".branch.4";
+        const bool fuse = fusable(p + ".branch.2", last_name, x);
+        const bool lead = fuse && lead_fusable(last_name, next_lead);
+        Act lead_out;
+        if (lead) lead_out = alloc(x.n, x.h, x.w, convs.find(next_lead + ".weight")->second.cout);  // outlives this block
         const size_t mark = arena.top;
         Epi relu;
         relu.act = ACT_RELU;
-        Act t1 = conv(p + ".branch.0", x, 1, 0, relu);
+        Act t1 = take_lead(p + ".branch.0", x);
         Epi e;
         Act idn = x;
         if (convs.count(p + ".skip.weight")) idn = conv(p + ".skip", x, 1, 0);
         e.res1 = &idn;
-        const std::string last_name = p + ".branch.4";
-        if (fusable(p + ".branch.2", last_name, t1)) {
+        if (lead) {
+            conv(p + ".branch.2", t1, 1, 1, e, &out, &last_name, &next_lead, &lead_out);
+            pre_leads[next_lead] = lead_out;
+        } else if (fuse) {
             conv(p + ".branch.2", t1, 1, 1, e, &out, &last_name);
         } else {
             Act t2 = conv(p + ".branch.2", t1, 1, 1, relu);
@@ -717,18 +767,25 @@ struct rgbd_elic {
     }
 
     // CompressAI/compressai/layers/layers.py:177-196
-    Act res_unit(const std::string& p, const Act& x)
+    Act res_unit(const std::string& p, const Act& x, const std::string& next_lead = std::string())
     {
         Act out = alloc(x.n, x.h, x.w, x.c);
+        const std::string last_name = p + ".conv.4";
+        const bool fuse = fusable(p + ".conv.2", last_name, x);
+        const bool lead = fuse && lead_fusable(last_name, next_lead);
+        Act lead_out;
+        if (lead) lead_out = alloc(x.n, x.h, x.w, convs.find(next_lead + ".weight")->second.cout);
         const size_t mark = arena.top;
         Epi relu;
         relu.act = ACT_RELU;
-        Act t1 = conv(p + ".conv.0", x, 1, 0, relu);
+        Act t1 = take_lead(p + ".conv.0", x);
         Epi e;
         e.act = ACT_RELU;
         e.res1 = &x;
-        const std::string last_name = p + ".conv.4";
-        if (fusable(p + ".conv.2", last_name, t1)) {
+        if (lead) {
+            conv(p + ".conv.2", t1, 1, 1, e, &out, &last_name, &next_lead, &lead_out);
+            pre_leads[next_lead] = lead_out;
+        } else if (fuse) {
             conv(p + ".conv.2", t1, 1, 1, e, &out, &last_name);
         } else {
             Act t2 = conv(p + ".conv.2", t1, 1, 1, relu);
@@ -744,9 +801,13 @@ struct rgbd_elic {
         Act out = dst ? *dst : alloc(x.n, x.h, x.w, x.c);
         const size_t mark = arena.top;
         Act a = x;
-        for (int u = 0; u < 3; ++u) a = res_unit(p + ".conv_a." + std::to_string(u), a);
+        for (int u = 0; u < 3; ++u)
+            a = res_unit(p + ".conv_a." + std::to_string(u), a,
+                         u < 2 ? p + ".conv_a." + std::to_string(u + 1) + ".conv.0" : std::string());
         Act b = x;
-        for (int u = 0; u < 3; ++u) b = res_unit(p + ".conv_b." + std::to_string(u), b);
+        for (int u = 0; u < 3; ++u)
+            b = res_unit(p + ".conv_b." + std::to_string(u), b,
+                         u < 2 ? p + ".conv_b." + std::to_string(u + 1) + ".conv.0" : std::string());
         Epi e;
         e.act = ACT_SIGMOID;
         e.mul = &a;
@@ -869,8 +930,10 @@ struct rgbd_elic {
                 r = conv(pr + si, r, 2, 2);
                 d = conv(pd + si, d, 2, 2);
             } else if (k == "rb") {
-                r = bottleneck(pr + si, r, pr_dst);
-                d = bottleneck(pd + si, d, pd_dst);
+                const bool next_rb = (i + 1 < 18) && std::string(kinds[i + 1]) == "rb";
+                const std::string sn = std::to_string(i + 1) + ".branch.0";
+                r = bottleneck(pr + si, r, pr_dst, next_rb ? pr + sn : std::string());
+                d = bottleneck(pd + si, d, pd_dst, next_rb ? pd + sn : std::string());
                 if (next_spf) {
                     r = rcat;
                     d = dcat;
@@ -919,8 +982,10 @@ struct rgbd_elic {
                 r = conv(pr + si, r, 2, 2, Epi(), pr_dst);
                 d = conv(pd + si, d, 2, 2, Epi(), pd_dst);
             } else if (k == "rb") {
-                r = bottleneck(pr + si, r, pr_dst);
-                d = bottleneck(pd + si, d, pd_dst);
+                const bool next_rb = (i + 1 < 18) && std::string(kinds[i + 1]) == "rb";
+                const std::string sn = std::to_string(i + 1) + ".branch.0";
+                r = bottleneck(pr + si, r, pr_dst, next_rb ? pr + sn : std::string());
+                d = bottleneck(pd + si, d, pd_dst, next_rb ? pd + sn : std::string());
             } else {
                 r = attention(pr + si, r, pr_dst);
                 d = attention(pd + si, d, pd_dst);
@@ -1548,6 +1613,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     const int64_t Tz = (int64_t)N * zh * zw;
     const int ny = per_image ? B : 1;
     named.clear();
+    pre_leads.clear();
     arena.top = 0;
     rc = 0;
 
@@ -1736,6 +1802,7 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
 {
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
     named.clear();
+    pre_leads.clear();
     arena.top = 0;
     rc = 0;
     Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
@@ -1822,6 +1889,7 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     const int per_image = (n_y == B && !(B == 1)) ? 1 : (n_y == 1 ? (B == 1 ? 1 : 0) : -1);
     if (per_image < 0) return RGBD_EINVAL;
     named.clear();
+    pre_leads.clear();
     arena.top = 0;
     rc = 0;
 
@@ -2002,6 +2070,7 @@ int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_im
     const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
     const int ny = per_image ? B : 1;
     named.clear();
+    pre_leads.clear();
     arena.top = 0;
     rc = 0;
     int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(8 * B + 64));
@@ -2111,6 +2180,7 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
     const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
     const int per_image = (n_y == B) ? 1 : 0;
     named.clear();
+    pre_leads.clear();
     arena.top = 0;
     rc = 0;
     std::vector<uint32_t> hwords;
@@ -2532,8 +2602,11 @@ int rgbd_debug_force_ckbd(int32_t part)
 // -1: fuse where the plan says so (default), 0: never, 1 / 2 / 4: always, with 64 / 128 / 256-pixel tiles
 int rgbd_debug_force_fuse(int32_t mode)
 {
+    const int lead_off = mode >= 15 ? 1 : 0;  // + 16: tails only, the next block's leading 1x1 stays a launch of its own
+    if (lead_off) mode -= 16;
     if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 4) return RGBD_EINVAL;
     g_fuse_force = mode;
+    g_fuse_lead_off = lead_off;
     ++g_cfg_epoch;
     return RGBD_OK;
 }

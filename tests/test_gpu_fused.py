@@ -1,6 +1,7 @@
 """Fused ResidualBottleneck / ResidualUnit tails (3x3 + ReLU -> 1x1 + residual in one launch, csrc/conv_mfma.hip): the
 intermediate stays in the accumulator registers and feeds the second GEMM in the channel order the stand-alone 1x1
-kernel uses, so every mode -- never fused, fused with 64 / 128 / 256-pixel tiles, automatic -- must give the same bits:
+kernel uses, and the next block's leading 1x1 can ride along as a third GEMM fed from the finished output groups; every
+mode -- never fused, fused with 64 / 128 / 256-pixel tiles, with or without the leading layer -- must give the same bits:
 latents, streams and reconstructions are compared with array_equal, on a ragged map (24 columns under 16-wide tiles) and
 on a batch."""
 import numpy as np
@@ -42,7 +43,7 @@ def test_fused_tail_bit_identical(net, shape):
     try:
         check(lib().rgbd_debug_force_fuse(0), "force_fuse")
         ref = _run(net, r, d)
-        for mode in (1, 2, 4, -1):
+        for mode in (1, 2, 4, -1, 15, 17, 18, 20):
             check(lib().rgbd_debug_force_fuse(mode), "force_fuse")
             got = _run(net, r, d)
             for k in ref[1]:
@@ -55,7 +56,8 @@ def test_fused_tail_bit_identical(net, shape):
 
 
 def test_fused_tail_is_taken(net):
-    """The automatic plan fuses the large maps of a 4 x 256 x 320 batch (fewer conv launches than with fusing off)."""
+    """The automatic plan fuses the large maps of a 2 x 256 x 320 batch: fewer stand-alone conv launches with the tails
+    fused, fewer again with the following blocks' leading layers riding along."""
     from rgbd_amd import synth
     from rgbd_amd._lib import check, lib
 
@@ -63,7 +65,7 @@ def test_fused_tail_is_taken(net):
     r, d = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
     counts = {}
     try:
-        for mode in (0, -1):
+        for mode in (0, 15, -1):
             check(lib().rgbd_debug_force_fuse(mode), "force_fuse")
             check(lib().rgbd_debug_conv_log(1), "conv_log")
             net.compress(r, d)
@@ -78,4 +80,4 @@ def test_fused_tail_is_taken(net):
     finally:
         lib().rgbd_debug_force_fuse(-1)
         lib().rgbd_debug_conv_log(0)
-    assert counts[-1] < counts[0], counts
+    assert counts[-1] < counts[15] < counts[0], counts
