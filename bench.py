@@ -142,7 +142,9 @@ def main():
     ap.add_argument("--workload", default="c3_4x480x640", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload and the B=1 latency pass")
-    ap.add_argument("--workers", type=int, default=16, help="engine instances (HIP streams) per GPU; 1 = no overlap")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="engine instances (HIP streams) per GPU; 1 = no overlap; 0 = as few full rounds of at most 24 "
+                         "instances as --steps allows (20 steps -> 20 instances, 48 -> 24)")
     ap.add_argument("--tile-mode", default="auto", choices=["auto", "latency", "throughput"],
                     help="conv tile tables: auto = throughput tiles when >= 4 engine instances share the GPU (CodecPool's rule)")
     ap.add_argument("--rehearse", action="store_true", help=argparse.SUPPRESS)  # CPU test of the N-rank plumbing
@@ -166,6 +168,9 @@ def main():
         sys.exit(2)
     if args.rehearse:
         sys.exit(rehearse(args))
+    if args.workers <= 0:  # rgbd_amd.pool.balanced_workers, restated here because nothing may load HIP before the line below
+        rounds = -(-max(1, args.steps) // 24)
+        args.workers = -(-max(1, args.steps) // rounds)
     if not _USER_QUEUES:
         os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))
 
@@ -211,7 +216,11 @@ def main():
             return res
 
         if nwarm:
-            run(max(nwarm, min(args.workers, nsteps)))  # every engine instance sizes its workspace once
+            # every engine instance sizes its workspace on its first batch and captures its HIP graphs on the second: the
+            # timed steps then run the way a long job runs (RGBD_BENCH_WARM_ROUNDS=1: time the capturing calls instead)
+            w = min(args.workers, nsteps)
+            host["warmup_steps_run"] = max(nwarm, int(os.environ.get("RGBD_BENCH_WARM_ROUNDS", "2")) * w)
+            run(host["warmup_steps_run"])
         distributed.barrier()
         torch.cuda.synchronize()
         c0 = os.times()
@@ -336,6 +345,7 @@ def main():
                        "images_per_gpu": B, "image": [H, W], "padded": list(padded), "weights": "synthetic seed 0 (stress recipe)",
                        "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers,
                        "conv_tiles": tile_mode, "host_cores_busy_per_rank": host_cores,
+                       "warmup_steps_run": host.get("warmup_steps_run", 0),
                        "launch": "HIP graph per call shape" if not os.environ.get("RGBD_NO_GRAPH") else "eager"},
             # `achieved`: algorithmic conv FLOPs of the timed steps / wall time of the timed region (job level, a lower
             # bound on MFMA utilisation: the wall clock also holds every other kernel).  With several engine instances

@@ -14,6 +14,14 @@ import torch
 from .elic_united import ELIC_united
 
 
+def balanced_workers(n_batches: int, max_workers: int = 24) -> int:
+    """Engine instances for a job of n_batches: as few rounds as max_workers allows, every round full
+    (20 batches -> 20 instances, one round; 48 -> 24, two rounds; 16 instances would leave 4 batches for a second round)."""
+    n = max(1, int(n_batches))
+    rounds = -(-n // max(1, max_workers))
+    return -(-n // rounds)
+
+
 class CodecPool:
     def __init__(self, state_dict, config=None, workers: int = 2, device="cuda", per_image_streams: bool = True,
                  model_cls=ELIC_united):
@@ -99,20 +107,33 @@ class CodecPool:
         return [r[0] for r in res], xr, xd
 
     def roundtrip_many(self, batches):
-        """Software pipeline over whole batches: worker w codes batches[w::W], so one batch's serial coder phases overlap
-        the other workers' convolutions.  batches: list of (rgb, depth).  Returns [(compress_out, x_hat_r, x_hat_d)]."""
+        """Software pipeline over whole batches: the workers pull batches off a shared counter, so one batch's serial
+        coder phases overlap the other workers' convolutions.  batches: list of (rgb, depth).  Returns
+        [(compress_out, x_hat_r, x_hat_d)] in batch order.
+
+        Workers that start together stay in lock-step (same work, symmetric contention), so a job of K batches takes
+        ceil(K / W) rounds and a last round with few workers leaves the chip idle: pick W so that the rounds are full
+        (`balanced_workers`).  Breaking the lock-step with staggered starts or a cap on concurrent compress() calls was
+        measured (tools/pool_sched_probe.py, c3, K = 20) and gains nothing: fewer instances in their transforms at a
+        time lower the convolution throughput by as much as the overlap wins."""
         n = len(batches)
         torch.cuda.current_stream().synchronize()
         W = min(self.workers, n)
+        nxt, lock = [W], threading.Lock()
 
         def fn(i):
             outs = []
-            for k in range(i, n, W):
+            k = i  # worker i starts with batch i (so W batches touch every instance once), then takes what is next
+            while True:
+                if k >= n:
+                    return outs
                 rgb, depth = batches[k]
                 out = self.nets[i].compress(rgb, depth)
                 rec = self.nets[i].decompress(out["r_strings"], out["d_strings"], out["shape"])
                 outs.append((k, out, rec["x_hat"]["r"], rec["x_hat"]["d"]))
-            return outs
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
 
         res = [None] * n
         for lst in self._run(fn, W):
