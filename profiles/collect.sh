@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the profiles committed under profiles/ (run on the GPU box from the repo root):
-#   1. kernel trace + stats of the default bench command (c3, 16 engine instances) -> <tag>_bench_default_{kernel_stats.csv,summary.txt}
+#   1. kernel trace + stats of the bench command the driver runs (c3, --steps 20 --warmup 5: 20 engine instances) -> <tag>_bench_default_{kernel_stats.csv,summary.txt}
 #   2. kernel trace + stats of a single engine instance with its own (latency) tiles  -> <tag>_bench_w1_summary.txt (= roofline.isolated)
 #   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)                              -> <tag>_c3_pmc_*.{csv,json}
 #   4. PMC pass for MFMA utilisation (own run, kernel trace only for the durations)  -> <tag>_mfma_by_kernel.csv
@@ -8,11 +8,12 @@
 # Usage: bash profiles/collect.sh r02
 set -e -o pipefail
 tag=${1:-r02}
+bench_args=${BENCH_ARGS:---steps 20 --warmup 5}  # the command line the round-end driver uses (BENCH_r01.json)
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" --no-cpu-baseline --no-extras > "$out/stats.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 "$root/bench.py" $bench_args --no-cpu-baseline --no-extras > "$out/stats.log" 2>&1
 echo "[collect] default done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_w1" -o run -- python3 "$root/bench.py" --workers 1 --steps 6 --warmup 2 --no-cpu-baseline --no-extras > "$out/stats_w1.log" 2>&1
 echo "[collect] w1 done"
@@ -25,11 +26,14 @@ echo "[collect] mfma done"
 unset RGBD_NO_GRAPH
 cd "$root"
 # every run executes warm-up steps, the timed steps and two conv-profile passes of two steps each: divide by all of them
-steps=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1]);print(j['steps']+max(j['warmup'],min(j['config']['engine_instances'],j['steps']))+4)")
+steps=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1]);print(j['steps']+j['config']['warmup_steps_run']+4)")
+steps_w1=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats_w1.log') if l.startswith('{')][-1]);print(j['steps']+j['config']['warmup_steps_run']+4)")
+# 4 x 512x640 padded pixels x 30.28 KB of layer-boundary bytes + 1.01 GB of weights per step, over the conv
+# launches one step makes now that block tails are fused
+algo=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.log') if l.startswith('{')][-1]);print(int((4*512*640*30.28e3+1.01e9)/j['roofline']['launches_per_step']))")
 { python3 profiles/summarize.py "$out/stats" "$steps"; python3 profiles/timeline.py "$out/stats"; grep '^{' "$out/stats.log"; } > "$out/${tag}_bench_default_summary.txt"
-{ python3 profiles/summarize.py "$out/stats_w1" 12; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
+{ python3 profiles/summarize.py "$out/stats_w1" "$steps_w1"; grep '^{' "$out/stats_w1.log"; } > "$out/${tag}_bench_w1_summary.txt"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_default_kernel_stats.csv"
-# 4 x 512x640 padded pixels x 30.28 KB + 1.01 GB weights per step over 594 launches = 68.5 MB algorithmic per launch
-python3 profiles/pmc_traffic.py "$out/fetch_c3" "$out/write_c3" "$out/${tag}_c3" 68516164 "--workload c3_4x480x640 (RGBD_NO_GRAPH=1)"
+python3 profiles/pmc_traffic.py "$out/fetch_c3" "$out/write_c3" "$out/${tag}_c3" "$algo" "--workload c3_4x480x640 (RGBD_NO_GRAPH=1)"
 python3 profiles/mfma_util.py "$out/mfma" "$out/${tag}_mfma_by_kernel.csv"
 ls "$out"

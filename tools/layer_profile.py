@@ -54,3 +54,8 @@ tot = sum(g[1] for g in groups.values())
 print(f"total conv ms/step {tot/N:.2f}")
 for k, g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{k:62s} n={g[0]//N:4d} {g[1]/N:7.3f} ms/step {g[2]/max(g[1],1e-9):7.1f} TF/s {100*g[1]/tot:5.1f}%")
+if os.environ.get("LAYER_RAW"):  # LAYER_RAW=<regex>: the individual layers behind the groups
+    pat = re.compile(os.environ["LAYER_RAW"])
+    for name, cnt, ms, gf, tf in sorted(rows, key=lambda r: r[0]):
+        if pat.search(name):
+            print(f"  {name:70s} n={int(cnt)//N:3d} {float(ms)/N*1e3:8.1f} us/step {float(gf)/max(float(ms),1e-9):7.1f} TF/s")
