@@ -184,6 +184,10 @@ int rgbd_debug_force_splitk(int32_t s);
  * 0 = never, 1 / 2 / 4 = always, with 64 / 128 / 256-pixel tiles; + 16 (15, 17, 18, 20) = the same without the following
  * block's leading layer.  Results are bit-identical in every mode. */
 int rgbd_debug_force_fuse(int32_t mode);
+/* The image-producing ConvTranspose2d (N -> 3 / 1, k 5, stride 2; synthesis.py:147,168) runs as one 9-tap sub-pixel conv
+ * over the input grid (16 channels = 4 output phases x 4) instead of four phases with the couts padded to 16 each:
+ * 0 = per-phase form, 1 = sub-pixel form inside the codec (default), 2 = also in rgbd_conv2d_nchw.  Same bits. */
+int rgbd_debug_force_subpix(int32_t mode);
 /* Convolution tile tables: mode 0 (default) = the winners of isolated launches (lowest latency of one compress / decompress),
  * mode 1 = the winners with the chip shared between several engine instances (highest job throughput; CodecPool sets it).
  * Results are bit-identical in both modes -- tile choice never changes an output. */

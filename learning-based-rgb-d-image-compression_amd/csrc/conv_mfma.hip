@@ -583,7 +583,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                 const int gx = tx0 + (ck ? 2 * (p & (TW - 1)) + ((gy & 1) ^ (a.ckbd == 1 ? 1 : 0)) : (p & (TW - 1)));
                 ok[u] = ip + ii < MT && cb < a.cout_store && gy < a.GH && gx < a.GW;
                 cbs[u] = cb;
-                pixs[u] = (unsigned)((gy * a.OS + oy_off) * a.OW + (gx * a.OS + ox_off));
+                // sub-pixel form of a stride-2 transposed conv with <= 4 couts (ConvArgs::subpix): the 16 computed channels
+                // are 4 output phases x 4 channels, so this float4 belongs to output pixel (2gy + py, 2gx + px), channels 0..3
+                const int oy = a.subpix ? ((cb >> 3) & 1) : oy_off, ox = a.subpix ? ((cb >> 2) & 1) : ox_off;
+                pixs[u] = (unsigned)((gy * a.OS + oy) * a.OW + (gx * a.OS + ox));
                 v[u] = *reinterpret_cast<const f32x4*>(smem + p * SW + c4 * 4);
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 r1[u] = (ok[u] && a.res1) ? *reinterpret_cast<const f32x4*>(r1n + (size_t)((pixs[u] * (unsigned)a.r1cs + cb) * 4u)) : z;
@@ -614,7 +617,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                    // expansion, unrolled for every output slot, used to be 2/3 of this kernel's code)
                 if (a.mul) w *= ml[u];
                 if (a.res2) w += r2[u];
-                *reinterpret_cast<f32x4*>(yn + (size_t)((pixs[u] * (unsigned)a.ycs + cb) * 4u)) = w;
+                *reinterpret_cast<f32x4*>(yn + (size_t)((pixs[u] * (unsigned)a.ycs + (a.subpix ? 0 : cb)) * 4u)) = w;
             }
         }
     }
@@ -934,6 +937,9 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
             return RGBD_EINVAL;
     }
     if (a.act == ACT_GELU && !a.partial) return RGBD_EINVAL;  // GELU is applied by the reducer: needs one partial plane
+    if (a.subpix && (a.cout_pad != 16 || a.nphase != 1 || a.IS != 1 || a.OS != 2 || a.splitk > 1 || a.res1 || a.mul || a.res2 ||
+                     a.ckbd || a.ycs < 4))
+        return RGBD_EINVAL;
     if (a.ckbd && (a.ckbd > 2 || a.ckbd < 0 || a.nphase != 1 || a.IS != 1 || a.OS != 1)) return RGBD_EINVAL;
     const int rc = launch_conv_main(a, s);
     if (rc || !a.partial) return rc;

@@ -157,6 +157,7 @@ struct PackedConv {
     float* bias = nullptr;
     int cin = 0, cout = 0, cin_pad = 0, cout_pad = 0, k = 0;
     bool transposed = false;
+    bool subpix = false;  // pack_subpix(): [16 = phase * 4 + cout][9 taps][cin_pad] of a k = 5, stride-2 transposed conv
 };
 
 int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedConv* pc, DevGen* gen = nullptr)
@@ -191,6 +192,63 @@ int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedC
     HIP_TRY(hipMemcpy(pc->w, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pc->bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
     return RGBD_OK;
+}
+
+// ConvTranspose2d(cin -> cout <= 4, k = 5, stride 2, pad 2, output_padding 1) as ONE stride-1 3x3 conv over the input grid
+// with 16 output channels = 4 output phases x 4: the per-phase form pads the couts to 16 for each of its 25 taps, this one
+// runs 9 taps for all phases together (2.8x fewer MFMAs).  Output phase (ry, rx) at input offset (dy, dx) uses kernel
+// element ky = ry + 2 - 2 dy, kx = rx + 2 - 2 dx when that is inside the kernel, else a zero weight; the taps run dy, dx =
+// 1, 0, -1, which keeps every phase's real taps in the order make_taps() gives them -- with fma(0, x, acc) == acc the
+// value of every output is the same chain as in the per-phase form (tests/test_gpu_conv.py::test_subpixel_deconv).
+int pack_subpix(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen* gen)
+{
+    if (w.shape.size() != 4 || w.shape[2] != 5 || w.shape[3] != 5 || w.shape[1] > 4) return RGBD_EINVAL;
+    const int cin = (int)w.shape[0], cout = (int)w.shape[1];
+    pc->cin = cin;
+    pc->cout = cout;
+    pc->k = 5;
+    pc->transposed = true;
+    pc->subpix = true;
+    pc->cin_pad = round_up(cin, 16);
+    pc->cout_pad = 16;
+    std::vector<float> h((size_t)16 * 9 * pc->cin_pad, 0.f), hb(16, 0.f);
+    for (int ry = 0; ry < 2; ++ry)
+        for (int rx = 0; rx < 2; ++rx)
+            for (int co = 0; co < cout; ++co) {
+                const int row = (ry * 2 + rx) * 4 + co;
+                if (b) hb[row] = b->v[co];
+                for (int u = 0; u < 9; ++u) {
+                    const int dy = 1 - u / 3, dx = 1 - u % 3;
+                    const int ky = ry + 2 - 2 * dy, kx = rx + 2 - 2 * dx;
+                    if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
+                    for (int ci = 0; ci < cin; ++ci)
+                        h[((size_t)row * 9 + u) * pc->cin_pad + ci] = w.v[(((size_t)ci * cout + co) * 5 + ky) * 5 + kx];
+                }
+            }
+    HIP_TRY(hipMalloc((void**)&pc->w, h.size() * sizeof(float)));
+    if (gen) gen->p.push_back(pc->w);
+    HIP_TRY(hipMalloc((void**)&pc->bias, hb.size() * sizeof(float)));
+    if (gen) gen->p.push_back(pc->bias);
+    HIP_TRY(hipMemcpy(pc->w, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pc->bias, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RGBD_OK;
+}
+
+void make_taps_subpix(ConvArgs* a)
+{
+    memset(&a->taps, 0, sizeof(a->taps));
+    a->nphase = 1;
+    a->IS = 1;
+    a->OS = 2;
+    a->subpix = 1;
+    for (int u = 0; u < 9; ++u) {
+        a->taps.dy[0][u] = (int8_t)(1 - u / 3);
+        a->taps.dx[0][u] = (int8_t)(1 - u % 3);
+        a->taps.wt[0][u] = (int8_t)u;
+    }
+    a->taps.n[0] = 9;
+    a->min_dy = a->min_dx = -1;
+    a->span_y = a->span_x = 3;
 }
 
 void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
@@ -250,6 +308,7 @@ std::shared_mutex g_capture_mu;
 int g_cfg_epoch = 0;     // bumped by every debug switch that changes kernel choices: cached HIP graphs of older epochs are not reused
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 int g_bench_streams = 1;  // rgbd_debug_bench_streams: rgbd_conv_bench issues every launch on this many streams at once
+int g_subpix = getenv("RGBD_NO_SUBPIX") ? 0 : 1;  // rgbd_debug_force_subpix: sub-pixel form of the last transposed conv
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
 const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
 
@@ -587,6 +646,18 @@ struct rgbd_elic {
         a.OW = OW;
         a.ycs = y.cs;
         a.cout_pad = pc->cout_pad;
+        // the last transposed conv (N -> 3 / 1): one 9-tap sub-pixel conv instead of four phases of padded couts
+        const PackedConv* sp = nullptr;
+        if (pc->transposed && g_subpix && !pc2 && stride == 2 && pad == 2 && k == 5 && !ep.res1 && !ep.mul && !ep.res2) {
+            auto it = convs.find(name + ".subpix.weight");
+            if (it != convs.end()) sp = &it->second;
+        }
+        if (sp) {
+            a.w = sp->w;
+            a.bias = sp->bias;
+            a.ntaps_total = 9;
+            a.cout_pad = 16;
+        }
         // a channel slice narrower than its 16-padded width inside a wider buffer (STF_united: 24 of 48): stop at the
         // slice end; a buffer of its own gets its pad channels zeroed as usual
         a.cout_store = (pcy->cout % 16 && y.cs != round_up(pcy->cout, 16)) ? round_up(pcy->cout, 4) : pcy->cout_pad;
@@ -603,7 +674,12 @@ struct rgbd_elic {
             a.y3cs = lead_dst->cs;
             a.cout3_pad = pc3->cout_pad;
         }
-        make_taps(*pc, stride, pad, &a);
+        if (sp) {
+            make_taps_subpix(&a);
+            a.cout_store = 16;
+        } else {
+            make_taps(*pc, stride, pad, &a);
+        }
         a.GH = pc->transposed ? x.h : OH;
         a.GW = pc->transposed ? x.w : OW;
         a.act = ep.act;
@@ -2499,7 +2575,8 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
         hb.v.assign(bias, bias + cout);
     }
     PackedConv pc;
-    int rc = pack_conv(hw, bias ? &hb : nullptr, transposed != 0, &pc);
+    const bool subpix = transposed && g_subpix == 2 && cout <= 4 && k == 5 && stride == 2 && pad == 2 && !residual_dev;
+    int rc = subpix ? pack_subpix(hw, bias ? &hb : nullptr, &pc, nullptr) : pack_conv(hw, bias ? &hb : nullptr, transposed != 0, &pc);
     if (rc) return rc;
     int OH, OW;
     if (!transposed) {
@@ -2527,14 +2604,19 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
         a.xcs = pc.cin_pad;
         a.cin_pad = pc.cin_pad;
         a.w = pc.w;
-        a.ntaps_total = k * k;
+        a.ntaps_total = subpix ? 9 : k * k;
         a.bias = pc.bias;
         a.y = yout;
         a.OH = OH;
         a.OW = OW;
         a.ycs = pc.cout_pad;
         a.cout_pad = pc.cout_pad;
-        make_taps(pc, stride, pad, &a);
+        if (subpix) {
+            make_taps_subpix(&a);
+            HIP_TRY(hipMemsetAsync(yout, 0, yb, s));  // channels 4..15 are not written in this form
+        } else {
+            make_taps(pc, stride, pad, &a);
+        }
         a.GH = transposed ? h : OH;
         a.GW = transposed ? w : OW;
         a.act = act;
@@ -2607,6 +2689,15 @@ int rgbd_debug_force_fuse(int32_t mode)
     if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 4) return RGBD_EINVAL;
     g_fuse_force = mode;
     g_fuse_lead_off = lead_off;
+    ++g_cfg_epoch;
+    return RGBD_OK;
+}
+
+// 0: per-phase form, 1: sub-pixel form inside the codec (default), 2: also in rgbd_conv2d_nchw (tests)
+int rgbd_debug_force_subpix(int32_t mode)
+{
+    if (mode < 0 || mode > 2) return RGBD_EINVAL;
+    g_subpix = mode;
     ++g_cfg_epoch;
     return RGBD_OK;
 }
@@ -2959,6 +3050,12 @@ int rgbd_elic_finalize(rgbd_elic* m)
             const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc, gen.get());
             if (r) return r;
             convs[name] = pc;
+            if (transposed && pc.cout <= 4 && pc.k == 5) {  // the image-producing layer: also in its sub-pixel form
+                PackedConv ps;
+                const int r3 = pack_subpix(t, bit == m->raw.end() ? nullptr : &bit->second, &ps, gen.get());
+                if (r3) return r3;
+                convs[name.substr(0, name.size() - 6) + "subpix.weight"] = ps;
+            }
         } else if (ends_with(name, ".weight") && t.shape.size() == 2) {
             // SE_Block linears; fc.2 ([C][hidden]) is kept transposed so the gate kernel reads it coalesced
             std::vector<float> hv = t.v;

@@ -200,3 +200,36 @@ def test_tile_choice_never_changes_a_bit(tile):
         assert torch.equal(y0, y1), (tile, (n, cin, h, w, cout, k, s, p, tr))
         launched += 1
     assert launched >= 1  # (a 64-channel stage only exists for layers whose taps all fit one stage)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout,h,w", [(3, 16, 24), (1, 16, 16), (3, 9, 13), (4, 32, 40)])
+def test_subpixel_deconv(cout, h, w):
+    """The image-producing ConvTranspose2d (N -> 3 / 1, k 5, stride 2) as one 9-tap sub-pixel conv over the input grid:
+    the same bits as the four-phase form (zero weights only add fma(0, x, acc) == acc steps to each chain), and the
+    torch result within the kernel's usual tolerance."""
+    dev = require_gpu()
+    from rgbd_amd._lib import check, lib
+
+    g = torch.Generator().manual_seed(100 + cout + h)
+    x = torch.randn(2, 192, h, w, generator=g)
+    wt = (torch.randn(192, cout, 5, 5, generator=g) / 40).contiguous()
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    xd = x.to(dev).contiguous()
+
+    def run(mode):
+        check(lib().rgbd_debug_force_subpix(mode), "force_subpix")
+        yd = torch.empty(ref.shape, device=dev)
+        check(lib().rgbd_conv2d_nchw(ctypes.c_void_p(xd.data_ptr()), 2, 192, h, w, wt.numpy().ctypes.data_as(f32p),
+                                     b.numpy().ctypes.data_as(f32p), cout, 5, 2, 2, 1, 0, None, ctypes.c_void_p(yd.data_ptr()),
+                                     None), "conv2d")
+        return yd.cpu()
+
+    try:
+        phased, packed = run(0), run(2)
+    finally:
+        lib().rgbd_debug_force_subpix(1)
+    assert torch.equal(phased, packed)
+    assert (packed - ref).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1e-3)

@@ -81,3 +81,21 @@ def test_fused_tail_is_taken(net):
         lib().rgbd_debug_force_fuse(-1)
         lib().rgbd_debug_conv_log(0)
     assert counts[-1] < counts[15] < counts[0], counts
+
+
+def test_subpixel_last_layer_same_pixels(net):
+    """The codec's last transposed conv in its sub-pixel form (default) against the four-phase form: same reconstructions."""
+    from rgbd_amd import synth
+    from rgbd_amd._lib import check, lib
+
+    r, d = synth.synthetic_batch(2, 128, 192, config_id=11)
+    r, d = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+    try:
+        check(lib().rgbd_debug_force_subpix(0), "force_subpix")
+        ref = _run(net, r, d)
+        check(lib().rgbd_debug_force_subpix(1), "force_subpix")
+        got = _run(net, r, d)
+    finally:
+        lib().rgbd_debug_force_subpix(1)
+    assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[3], got[3])
+    assert ref[0]["r_strings"] == got[0]["r_strings"]
