@@ -186,7 +186,9 @@ int rgbd_debug_force_splitk(int32_t s);
 int rgbd_debug_force_fuse(int32_t mode);
 /* The image-producing ConvTranspose2d (N -> 3 / 1, k 5, stride 2; synthesis.py:147,168) runs as one 9-tap sub-pixel conv
  * over the input grid (16 channels = 4 output phases x 4) instead of four phases with the couts padded to 16 each:
- * 0 = per-phase form, 1 = sub-pixel form inside the codec (default), 2 = also in rgbd_conv2d_nchw.  Same bits. */
+ * 0 = per-phase form, 1 = sub-pixel form inside the codec (default), 2 = also in rgbd_conv2d_nchw.  Same bits.
+ * Mode 0 also returns the image-consuming first conv (3 / 1 -> N, k 5, stride 2; analysis.py:125,150) from its K-packed
+ * 1x1 form (25 taps x C real inputs gathered into 80 / 32 channels) to the tap-by-tap form. */
 int rgbd_debug_force_subpix(int32_t mode);
 /* Convolution tile tables: mode 0 (default) = the winners of isolated launches (lowest latency of one compress / decompress),
  * mode 1 = the winners with the chip shared between several engine instances (highest job throughput; CodecPool sets it).

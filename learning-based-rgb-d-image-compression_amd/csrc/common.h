@@ -137,6 +137,8 @@ int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const
                             hipStream_t s);
 int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s);
 int launch_fill_zero(float* p, size_t n, hipStream_t s);
+// packed input of the first analysis conv: y[n][oy][ox][KP], see im2col5s2_kernel
+int launch_im2col5s2(const float* x, int N, int H, int W, int cs, int C, float* y, int OH, int OW, int KP, hipStream_t s);
 // swin.hip (STF_united)
 int launch_layernorm(const float* x, size_t ntok, int C, int xcs, const float* w, const float* b, float* y, int ycs,
                      hipStream_t s);

@@ -234,6 +234,26 @@ int pack_subpix(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen
     return RGBD_OK;
 }
 
+// Conv2d(cin <= 3 -> cout, k 5, stride 2, pad 2) as a 1x1 layer over the packed input of launch_im2col5s2: weight of
+// term n = tap * cin + c at packed index (n / 16) * 16 + (n % 4) * 4 + (n % 16) / 4
+int pack_kpack(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen* gen)
+{
+    if (w.shape.size() != 4 || w.shape[2] != 5 || w.shape[3] != 5 || w.shape[1] > 3) return RGBD_EINVAL;
+    const int cout = (int)w.shape[0], cin = (int)w.shape[1], nterm = 25 * cin;
+    HostTensor w1;
+    const int KP = round_up(nterm, 16);
+    w1.shape = {cout, KP, 1, 1};
+    w1.v.assign((size_t)cout * KP, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int n = 0; n < nterm; ++n) {
+            const int t = n / cin, c = n % cin, r = n % 16;
+            w1.v[(size_t)co * KP + (n / 16) * 16 + (r % 4) * 4 + r / 4] = w.v[((size_t)co * cin + c) * 25 + t];
+        }
+    const int rc = pack_conv(w1, b, false, pc, gen);
+    pc->cin = nterm;  // FLOP accounting: the real reduction length
+    return rc;
+}
+
 void make_taps_subpix(ConvArgs* a)
 {
     memset(&a->taps, 0, sizeof(a->taps));
@@ -308,6 +328,7 @@ std::shared_mutex g_capture_mu;
 int g_cfg_epoch = 0;     // bumped by every debug switch that changes kernel choices: cached HIP graphs of older epochs are not reused
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 int g_bench_streams = 1;  // rgbd_debug_bench_streams: rgbd_conv_bench issues every launch on this many streams at once
+const bool g_kpack = !getenv("RGBD_NO_KPACK");  // A/B switch: first analysis conv over a K-packed input (1x1, K = 80 / 32)
 int g_subpix = getenv("RGBD_NO_SUBPIX") ? 0 : 1;  // rgbd_debug_force_subpix: sub-pixel form of the last transposed conv
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
 const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
@@ -597,6 +618,23 @@ struct rgbd_elic {
     {
         const PackedConv* pc = conv_of(name + ".weight");
         if (!pc) return Act();
+        if (g_kpack && g_subpix && !pc->transposed && pc->k == 5 && stride == 2 && pad == 2 && x.c <= 3 && !fuse1x1) {
+            // first analysis conv: gather the 25 x C real inputs of every output pixel, then a 1x1 layer with K = 80 / 32
+            auto kp = convs.find(name + ".kpack.weight");
+            if (kp != convs.end()) {
+                const int OH = (x.h + 2 * pad - 5) / stride + 1, OW = (x.w + 2 * pad - 5) / stride + 1;
+                Act out = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
+                const size_t mark = arena.top;
+                Act xk = alloc(x.n, OH, OW, kp->second.cin_pad);
+                if (!dry() && !rc) {
+                    const int r = launch_im2col5s2(x.p, x.n, x.h, x.w, x.cs, x.c, xk.p, OH, OW, xk.cs, s);
+                    if (r) fail(r);
+                }
+                conv(name + ".kpack", xk, 1, 0, ep, &out);
+                arena.top = mark;
+                return out;
+            }
+        }
         const PackedConv* pc2 = fuse1x1 ? conv_of(*fuse1x1 + ".weight") : nullptr;
         if (fuse1x1 && !pc2) return Act();
         const PackedConv* pc3 = (pc2 && lead1x1 && lead_dst) ? conv_of(*lead1x1 + ".weight") : nullptr;
@@ -3050,6 +3088,12 @@ int rgbd_elic_finalize(rgbd_elic* m)
             const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc, gen.get());
             if (r) return r;
             convs[name] = pc;
+            if (!transposed && pc.cin <= 3 && pc.k == 5) {  // the image-consuming layer: also as a 1x1 over a K-packed input
+                PackedConv pk;
+                const int r4 = pack_kpack(t, bit == m->raw.end() ? nullptr : &bit->second, &pk, gen.get());
+                if (r4) return r4;
+                convs[name.substr(0, name.size() - 6) + "kpack.weight"] = pk;
+            }
             if (transposed && pc.cout <= 4 && pc.k == 5) {  // the image-producing layer: also in its sub-pixel form
                 PackedConv ps;
                 const int r3 = pack_subpix(t, bit == m->raw.end() ? nullptr : &bit->second, &ps, gen.get());

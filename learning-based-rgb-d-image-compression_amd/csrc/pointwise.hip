@@ -332,6 +332,44 @@ int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npi
     return RGBD_OK;
 }
 
+// First analysis conv (3 / 1 -> N, k 5, stride 2, pad 2): the 25 taps x C real input values of every output pixel, packed
+// densely into KP "channels" so that the conv becomes a 1x1 layer with K = KP (80 / 32) instead of 25 taps x 16 padded
+// channels.  Term n = tap * C + c sits where the 1x1 kernel's MFMA order (k-step e outer, lane group q inner: packed
+// index q * 4 + e) visits it n-th, so every output keeps the fma chain of the tap-by-tap form (taps ascending, channels
+// ascending; the padding terms are exact zeros either way).
+__global__ void im2col5s2_kernel(const float* __restrict__ x, int H, int W, int cs, int C, float* __restrict__ y, int OH,
+                                 int OW, int KP, size_t total4)
+{
+    const int k4n = KP / 4, nterm = 25 * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int kq = (int)(i % k4n);
+        const size_t pix = i / k4n;
+        const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH);
+        const size_t n = pix / ((size_t)OW * OH);
+        const int j = kq >> 2, q = kq & 3;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int term = j * 16 + e * 4 + q;
+            if (term < nterm) {
+                const int t = term / C, c = term - t * C;
+                const int iy = 2 * oy - 2 + t / 5, ix = 2 * ox - 2 + t % 5;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = x[((n * H + iy) * W + ix) * cs + c];
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + pix * KP + kq * 4) = v;
+    }
+}
+
+int launch_im2col5s2(const float* x, int N, int H, int W, int cs, int C, float* y, int OH, int OW, int KP, hipStream_t s)
+{
+    if (KP % 16 || 25 * C > KP || C < 1 || C > cs) return RGBD_EINVAL;
+    const size_t total4 = (size_t)N * OH * OW * (KP / 4);
+    hipLaunchKernelGGL(im2col5s2_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, H, W, cs, C, y, OH, OW, KP, total4);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
 // A kernel rather than hipMemsetAsync: these fills sit inside the bodies that are captured into HIP graphs, and a memset
 // node of a replayed graph was observed not to clear its buffer (the encoder's error flag came back set with whatever the
 // workspace held before) -- a kernel node behaves.

@@ -83,8 +83,9 @@ def test_fused_tail_is_taken(net):
     assert counts[-1] < counts[15] < counts[0], counts
 
 
-def test_subpixel_last_layer_same_pixels(net):
-    """The codec's last transposed conv in its sub-pixel form (default) against the four-phase form: same reconstructions."""
+def test_image_layers_packed_forms_same_bits(net):
+    """The codec's first conv over its K-packed input and its last transposed conv in sub-pixel form (defaults) against
+    the tap-by-tap / four-phase forms (rgbd_debug_force_subpix(0) selects both): same latents, streams, reconstructions."""
     from rgbd_amd import synth
     from rgbd_amd._lib import check, lib
 
@@ -97,5 +98,7 @@ def test_subpixel_last_layer_same_pixels(net):
         got = _run(net, r, d)
     finally:
         lib().rgbd_debug_force_subpix(1)
+    for k in ref[1]:
+        assert np.array_equal(ref[1][k], got[1][k]), k
     assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[3], got[3])
-    assert ref[0]["r_strings"] == got[0]["r_strings"]
+    assert ref[0]["r_strings"] == got[0]["r_strings"] and ref[0]["d_strings"] == got[0]["d_strings"]
