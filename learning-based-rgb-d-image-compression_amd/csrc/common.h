@@ -68,6 +68,8 @@ struct ConvArgs {
     int loaded;      // tile-table flavour: 0 = winners of isolated launches (latency), 1 = winners with the chip shared (throughput)
     int ckbd;        // checkerboard output: 0 = every position, 1 = anchor positions only ((row + col) odd, ckbd.py:37-48),
                      // 2 = non-anchor positions only; the other half of y is left untouched (stride-1, single-phase convs)
+    float* y2;       // optional second destination of the same output (another concat buffer), channel stride y2cs
+    int y2cs;
     int subpix;      // 1: sub-pixel form of a stride-2 transposed conv with <= 4 couts: one stride-1 conv over the input grid
                      // whose 16 channels are (output phase py*2+px) * 4 + channel, each float4 stored to its own output pixel
     // Fused trailing 1x1 (launch_conv_fused; ResidualBottleneck branch.2 -> branch.4, ResidualUnit conv.2 -> conv.4):

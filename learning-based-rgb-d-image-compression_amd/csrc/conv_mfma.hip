@@ -552,6 +552,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     const char* r1n = reinterpret_cast<const char*>(a.res1 + img_px * a.r1cs);
     const char* mln = reinterpret_cast<const char*>(a.mul + img_px * a.mcs);
     const char* r2n = reinterpret_cast<const char*>(a.res2 + img_px * a.r2cs);
+    char* y2n = reinterpret_cast<char*>(a.y2 + img_px * a.y2cs);
     char* ptn = reinterpret_cast<char*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + img_px) * a.cout_pad);
     for (int ip = 0; ip < MT; ip += EMT) {
         __syncthreads();  // LDS is free: the last stage (or the previous pass) has been consumed
@@ -618,6 +619,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                 if (a.mul) w *= ml[u];
                 if (a.res2) w += r2[u];
                 *reinterpret_cast<f32x4*>(yn + (size_t)((pixs[u] * (unsigned)a.ycs + (a.subpix ? 0 : cb)) * 4u)) = w;
+                if (a.y2) *reinterpret_cast<f32x4*>(y2n + (size_t)((pixs[u] * (unsigned)a.y2cs + cb) * 4u)) = w;
             }
         }
     }
@@ -937,6 +939,7 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
             return RGBD_EINVAL;
     }
     if (a.act == ACT_GELU && !a.partial) return RGBD_EINVAL;  // GELU is applied by the reducer: needs one partial plane
+    if (a.y2 && (a.partial || a.subpix || a.y2cs % 4)) return RGBD_EINVAL;  // the reducer / sub-pixel store have one target
     if (a.subpix && (a.cout_pad != 16 || a.nphase != 1 || a.IS != 1 || a.OS != 2 || a.splitk > 1 || a.res1 || a.mul || a.res2 ||
                      a.ckbd || a.ycs < 4))
         return RGBD_EINVAL;

@@ -356,6 +356,7 @@ struct Epi {
     const Act* mul = nullptr;
     const Act* res2 = nullptr;
     int ckbd = 0;  // ConvArgs::ckbd: compute / store only one checkerboard half of the output
+    const Act* dup = nullptr;  // ConvArgs::y2: the output is also written here (same shape, own channel stride)
 };
 
 }  // namespace
@@ -722,6 +723,10 @@ struct rgbd_elic {
         a.GW = pc->transposed ? x.w : OW;
         a.act = ep.act;
         a.ckbd = ep.ckbd;
+        if (ep.dup) {
+            a.y2 = ep.dup->p;
+            a.y2cs = ep.dup->cs;
+        }
         a.loaded = tile_mode;
         if (ep.res1) {
             a.res1 = ep.res1->p;
@@ -980,10 +985,13 @@ struct rgbd_elic {
         Epi relu;
         relu.act = ACT_RELU;
         Act rf = view(rd, 0, half), df = view(rd, half, half);
-        conv(p + ".r_ext", rgb, 1, 1, relu, &rf);
-        conv(p + ".d_ext", depth, 1, 1, relu, &df);
-        copy_ch(df, view(dr, 0, half));
-        copy_ch(rf, view(dr, half, half));
+        // each extractor writes its features into both concat buffers (cat(rf, df) and cat(df, rf)) from its epilogue
+        const Act rf2 = view(dr, half, half), df2 = view(dr, 0, half);
+        Epi er = relu, ed = relu;
+        er.dup = &rf2;
+        ed.dup = &df2;
+        conv(p + ".r_ext", rgb, 1, 1, er, &rf);
+        conv(p + ".d_ext", depth, 1, 1, ed, &df);
         esa(p + ".r_esa", rd, r_dst, residual ? &rgb : nullptr);
         esa(p + ".d_esa", dr, d_dst, residual ? &depth : nullptr);
         arena.top = mark;
