@@ -185,7 +185,8 @@ def main():
     dev = torch.device("cuda", local)
 
     B, H, W, cid, model = WORKLOADS[args.workload]
-    sd = synth.synthetic_state_dict(0, model=model)
+    recipe = os.environ.get("RGBD_BENCH_RECIPE", "stress")  # experiments only: the headline runs the stress recipe
+    sd = synth.synthetic_state_dict(0, model=model) if recipe == "stress" else synth.synthetic_state_dict(0, model=model, recipe=recipe)
     # per-image stream sets (the unit that shards across GPUs); W engine instances overlap one group's serial coder
     # phases with another group's convolutions
     net = CodecPool(sd, config=rgbd_amd.model_config(), workers=args.workers, device=dev, per_image_streams=True,
@@ -342,7 +343,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload,
                        "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)" if model == "ELIC_united" else "STF_united ch4 (N=192,M=384)",
-                       "images_per_gpu": B, "image": [H, W], "padded": list(padded), "weights": "synthetic seed 0 (stress recipe)",
+                       "images_per_gpu": B, "image": [H, W], "padded": list(padded), "weights": f"synthetic seed 0 ({recipe} recipe)",
                        "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers,
                        "conv_tiles": tile_mode, "host_cores_busy_per_rank": host_cores,
                        "warmup_steps_run": host.get("warmup_steps_run", 0),
