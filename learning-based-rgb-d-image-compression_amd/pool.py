@@ -32,6 +32,12 @@ class CodecPool:
         self.streams = []
         import os
 
+        # torch hands out side streams from a pool of 32 per device: a 33rd instance would share its HIP stream with the
+        # first, and one instance's graph capture would then swallow the other's work ("operation not permitted on an event
+        # last recorded in a capturing stream")
+        if workers > 32:
+            raise ValueError(f"CodecPool: {workers} engine instances requested, at most 32 have a HIP stream of their own")
+
         # Host threads that wait for this GPU sleep instead of spinning (hipDeviceScheduleBlockingSync): a pool keeps W
         # threads waiting on W streams.  Measured on c3 with 16 instances and HIP-graph launches: 15.1 -> 1.2 busy host
         # cores per rank at the same throughput (tools/host_cost.sh); RGBD_BLOCKING_SYNC=0 restores the spinning default.

@@ -299,3 +299,13 @@ def test_balanced_workers_fill_every_round():
         w = balanced_workers(k)
         rounds = -(-k // w)
         assert 1 <= w <= 24 and rounds == -(-k // 24) and rounds * w - k < rounds  # no round short by a whole instance
+
+
+def test_codec_pool_refuses_more_instances_than_streams():
+    """torch's side-stream pool holds 32 streams per device; a pool that aliased two instances onto one stream would
+    corrupt graph captures, so it is refused before anything touches the GPU."""
+    import rgbd_amd
+    from rgbd_amd.pool import CodecPool
+
+    with pytest.raises(ValueError, match="at most 32"):
+        CodecPool({}, config=rgbd_amd.model_config(), workers=33, device="cuda:0")
