@@ -188,7 +188,7 @@ class TesterUnited:
         else:
             import threading
 
-            W = min(workers, n)
+            W = min(workers, n, 32)  # torch has 32 side streams per device; instances must not share one (pool.py)
             nets = [self.net] + [self.net.clone_shared() for _ in range(W - 1)]
             if os.environ.get("RGBD_BLOCKING_SYNC", "1") != "0":  # W host threads wait on W streams: sleep, do not spin
                 from ._lib import check, lib
