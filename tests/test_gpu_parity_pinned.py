@@ -2,6 +2,7 @@
 (box-independent: tests/parity_utils.py) and at the batch shapes bench.py runs.
 
   * stream identity where it holds today (Bi-CEE alone 16x16 = BASELINE config 4, ELIC_united_R2D, single-modal ELIC);
+  * the bench's image shape (480x640) with the trained_like weights against the reference's own run of that case;
   * a recorded floor on "parts identical to the reference before the first boundary flip" for every other golden, and on
     |bpp - golden| (<= 1e-3 bpp) and |PSNR - golden| (< 1e-4 dB) -- tests/golden/parity_floors.json holds the values
     measured on MI355X; a regression below them fails;
@@ -94,8 +95,27 @@ def _pad_inputs(B, H, W, cid):
 
 
 # ---- end-to-end ELIC_united against every model golden ----------------------------------------------------------------
+@pytest.fixture(scope="module")
+def net_tl():
+    """ELIC_united with the trained_like synthetic weights (the coder's realistic operating point, ~3.6 bpp)."""
+    require_gpu()
+    from rgbd_amd import synth
+
+    return _model("ELIC_united", synth.synthetic_state_dict(0, recipe="trained_like"))
+
+
+def test_elic_united_trained_like_vs_reference_golden(net_tl, gc):
+    """The bench's image shape (480x640, padded to 512x640) with the trained_like weights against the reference's run of
+    the same case (tests/golden/make_golden.py --only-e)."""
+    _vs_golden(net_tl, gc, "e_480x640_tl")
+
+
 @pytest.mark.parametrize("name", ["a_128x192", "b_100x150", "c_b2_128x128", "d_256x256"])
 def test_elic_united_vs_reference_golden(net, gc, name):
+    _vs_golden(net, gc, name)
+
+
+def _vs_golden(net, gc, name):
     g = load_golden(name)
     B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
     r, d, rp, dp = _pad_inputs(B, H, W, int(g["config_id"]))
