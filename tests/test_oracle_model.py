@@ -55,8 +55,21 @@ def test_full_case_a(codec):
     assert abs(eo.psnr(dec["x_hat"]["r"], r) - g["psnr"][0]) < 1e-9
 
 
+def test_streams_bench_shape_trained_like():
+    """The oracle on the bench's image shape (480x640) with the trained_like weights against the reference's golden."""
+    from rgbd_amd import synth
+
+    c = eo.OracleCodec(synth.synthetic_state_dict(0, recipe="trained_like"))
+    assert c.update()
+    _streams_case(c, "e_480x640_tl")
+
+
 @pytest.mark.parametrize("name", ["b_100x150", "c_b2_128x128", "d_256x256"])
 def test_streams_other_cases(codec, name):
+    _streams_case(codec, name)
+
+
+def _streams_case(codec, name):
     g = load_golden(name)
     r, d, rp, dp = _inputs(g)
     assert tuple(rp.shape[-2:]) == tuple(g["padded"])
