@@ -122,6 +122,7 @@ if os.path.exists(TABLE):  # keep what earlier runs measured for other shapes
     for ln in open(TABLE):
         ln = ln.strip()
         if ln.startswith("{"):
+            ln = ln.split("}")[0]  # hand-added entries may carry a trailing comment (tools/force_new_shapes.sh)
             v = [int(x) for x in ln.strip("{},").replace(" ", "").split(",")]
             if tuple(v[:9]) not in measured:  # a shape measured in this run keeps this run's verdict
                 table.setdefault(tuple(v[:9]), tuple(v[9:]))
