@@ -143,8 +143,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload and the B=1 latency pass")
     ap.add_argument("--workers", type=int, default=0,
-                    help="engine instances (HIP streams) per GPU; 1 = no overlap; 0 = as few full rounds of at most 24 "
-                         "instances as --steps allows (20 steps -> 20 instances, 48 -> 24)")
+                    help="engine instances (HIP streams) per GPU; 1 = no overlap; 0 = as few full rounds of at most 20 "
+                         "instances as --steps allows (20 steps -> 20 instances, 48 -> 16)")
     ap.add_argument("--tile-mode", default="auto", choices=["auto", "latency", "throughput"],
                     help="conv tile tables: auto = throughput tiles when >= 4 engine instances share the GPU (CodecPool's rule)")
     ap.add_argument("--rehearse", action="store_true", help=argparse.SUPPRESS)  # CPU test of the N-rank plumbing
@@ -169,7 +169,7 @@ def main():
     if args.rehearse:
         sys.exit(rehearse(args))
     if args.workers <= 0:  # rgbd_amd.pool.balanced_workers, restated here because nothing may load HIP before the line below
-        rounds = -(-max(1, args.steps) // 24)
+        rounds = -(-max(1, args.steps) // 20)
         args.workers = -(-max(1, args.steps) // rounds)
     if not _USER_QUEUES:
         os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))

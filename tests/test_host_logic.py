@@ -292,13 +292,13 @@ def test_balanced_workers_fill_every_round():
     """Engine instances for a job of K batches: as few rounds as the cap allows, every round full."""
     from rgbd_amd.pool import balanced_workers
 
-    assert balanced_workers(20) == 20 and balanced_workers(48) == 24 and balanced_workers(24) == 24
-    assert balanced_workers(25) == 13 and balanced_workers(1) == 1 and balanced_workers(0) == 1
+    assert balanced_workers(20) == 20 and balanced_workers(48) == 16 and balanced_workers(24) == 12
+    assert balanced_workers(21) == 11 and balanced_workers(1) == 1 and balanced_workers(0) == 1
     assert balanced_workers(20, max_workers=16) == 10 and balanced_workers(7, max_workers=4) == 4
     for k in range(1, 200):
         w = balanced_workers(k)
         rounds = -(-k // w)
-        assert 1 <= w <= 24 and rounds == -(-k // 24) and rounds * w - k < rounds  # no round short by a whole instance
+        assert 1 <= w <= 20 and rounds == -(-k // 20) and rounds * w - k < rounds  # no round short by a whole instance
 
 
 def test_codec_pool_refuses_more_instances_than_streams():
