@@ -43,34 +43,112 @@ WORKLOADS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (dense f32 matrix)
 
 
-def cpu_baseline(sd, H, W, cid, model="ELIC_united", seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference path: PyTorch-CPU eager + C coder) timed on this host, B=1, on single
-    pairs of the workload's image size (replicate-padded to multiples of 64 like the harness does)."""
+def host_cpu_info():
+    """CPU model, logical CPUs this process may run on and the physical cores among them (from /proc/cpuinfo)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "processor":
+                    cur = {"cpu": int(v)}
+                elif k == "model name":
+                    model = v
+                elif k in ("physical id", "core id"):
+                    cur[k] = v
+                    if "physical id" in cur and "core id" in cur and cur.get("cpu") in allowed:
+                        cores.add((cur["physical id"], cur["core id"]))
+    except OSError:
+        pass
+    quota = None
+    try:  # cgroup v2 CPU quota of the box, if any ("max 100000" = none)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    return {"model": model, "logical_allowed": len(allowed), "physical_allowed": len(cores) or len(allowed), "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline(sd, H, W, cid, model="ELIC_united", seconds_budget=25.0, batch8=True):
+    """The oracle (CPU restatement of the reference path: PyTorch-CPU eager + C coder) timed on this host on pairs of the
+    workload's image size (replicate-padded to multiples of 64 like the harness does), SURVEY 8(d): B = 1 (tester
+    semantics) with 16 threads (the figure of rounds 1-2) and with one thread per physical core this process may use
+    (capped by a cgroup CPU quota), and one B = 8 batch with the better of the two.  `value` is the best of all legs."""
     import torch
 
     from oracle import elic_oracle as eo
     from rgbd_amd import synth
 
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    info = host_cpu_info()
+    phys = info["physical_allowed"]
+    if info["cgroup_cpu_quota"]:
+        phys = max(1, min(phys, int(info["cgroup_cpu_quota"] + 0.5)))
     orc = eo.OracleCodec(sd) if model == "ELIC_united" else eo.oracle_stf(sd)
     orc.update()
-    done, spent, best, tot = 0, 0.0, None, 0.0
-    while spent < seconds_budget and done < 6:
-        r, d = synth.synthetic_batch(1, H, W, config_id=cid, start=done)
-        r, d = torch.from_numpy(r), torch.from_numpy(d)
-        r, d = eo.pad_replicate0(r), eo.pad_replicate0(d)
-        t0 = time.time()
-        out = orc.compress(r, d)
-        orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
-        dt = time.time() - t0
-        spent += dt
-        tot += dt
-        done += 1
-        best = dt if best is None else min(best, dt)
-    return {"value": round(H * W / best / 1e6, 5), "unit": "Mpx/s", "cores": cores, "kind": "port",
-            "mean_value": round(done * H * W / tot / 1e6, 5),
-            "sample": f"best of {done} single {H}x{W} pairs, enc+dec, B=1 (tester semantics), torch CPU {cores} threads"}
+
+    def leg(threads, B, budget, max_runs):
+        torch.set_num_threads(threads)
+        done, spent, best = 0, 0.0, None
+        while spent < budget and done < max_runs:
+            r, d = synth.synthetic_batch(B, H, W, config_id=cid, start=done * B)
+            r, d = eo.pad_replicate0(torch.from_numpy(r)), eo.pad_replicate0(torch.from_numpy(d))
+            t0 = time.time()
+            out = orc.compress(r, d)
+            orc.decompress(out["r_strings"], out["d_strings"], out["shape"])
+            dt = time.time() - t0
+            spent += dt
+            done += 1
+            best = dt if best is None else min(best, dt)
+        return {"threads": threads, "batch": B, "runs": done, "value": round(B * H * W / best / 1e6, 5)}
+
+    legs = [leg(min(16, info["logical_allowed"]), 1, seconds_budget * 0.4, 4)]
+    if phys != legs[0]["threads"]:
+        legs.append(leg(phys, 1, seconds_budget * 0.4, 4))
+    top = max(legs, key=lambda x: x["value"])
+    if batch8:
+        legs.append(leg(top["threads"], 8, 1.0, 1))  # one batch of 8 (the reference's interleaved B > 1 stream format)
+    best = max(legs, key=lambda x: x["value"])
+    return {"value": best["value"], "unit": "Mpx/s", "cores": best["threads"], "kind": "port", "cpu": info, "legs": legs,
+            "value_16_threads_b1": legs[0]["value"],
+            "sample": f"best leg: {best['runs']} x (B={best['batch']}, {H}x{W}) enc+dec with {best['threads']} torch-CPU "
+                      f"threads; legs = 16 threads / one thread per usable physical core at B=1 (tester semantics), then B=8"}
+
+
+def visible_gpu_count(base="/sys/class/kfd/kfd/topology/nodes", dri="/dev/dri"):
+    """GPUs this process could open, counted WITHOUT loading torch or the HIP runtime (the launcher parent must never
+    initialise the GPU: its children are fork+exec'd): KFD topology nodes with SIMDs whose DRM render node is accessible,
+    narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when the topology cannot be read
+    (the ranks then check for themselves and exit 2 when LOCAL_RANK has no device)."""
+    try:
+        nodes = sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        props = {}
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue  # a CPU node
+        minor = props.get("drm_render_minor")
+        if minor not in (None, "", "0") and not os.access(os.path.join(dri, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue  # listed by the host's topology but not handed to this container
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def spawn_ranks(n, argv):
@@ -155,22 +233,28 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         # no launcher around us: become the launcher.  Nothing in this process has touched (or will touch) the GPU.
+        # (no torch / HIP call here: the GPUs are counted from sysfs; a rank without a device exits 2 by itself)
         if not args.rehearse and os.environ.get("RGBD_DIST_BACKEND") != "gloo":
-            import torch  # device_count() does not initialise the HIP runtime on this image
-
-            have = torch.cuda.device_count()
-            if have < args.gpus:
+            have = visible_gpu_count()
+            if have is not None and have < args.gpus:
                 print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
                 sys.exit(2)
+        assert "torch" not in sys.modules, "the launcher parent must not load torch / HIP before it starts its ranks"
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if env_world is not None and int(env_world) != args.gpus:
         print(f"[bench] WORLD_SIZE={env_world} does not match --gpus {args.gpus}", file=sys.stderr)
         sys.exit(2)
     if args.rehearse:
         sys.exit(rehearse(args))
-    if args.workers <= 0:  # rgbd_amd.pool.balanced_workers, restated here because nothing may load HIP before the line below
-        rounds = -(-max(1, args.steps) // 20)
-        args.workers = -(-max(1, args.steps) // rounds)
+    if args.workers <= 0:
+        # rgbd_amd.pool.balanced_workers, loaded by file: nothing may load torch / HIP before GPU_MAX_HW_QUEUES is final
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location(
+            "_rgbd_sched", os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "sched.py"))
+        sched = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sched)
+        args.workers = sched.balanced_workers(args.steps)
     if not _USER_QUEUES:
         os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))
 
@@ -179,6 +263,11 @@ def main():
     import rgbd_amd
     from rgbd_amd import CodecPool, distributed, synth
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("RGBD_DIST_BACKEND") != "gloo":
+        have, want = torch.cuda.device_count(), int(os.environ.get("LOCAL_RANK", "0"))
+        if want >= have:  # one process per GPU: a rank without a device of its own must not double up on another rank's
+            print(f"[bench] rank {os.environ.get('RANK')}: LOCAL_RANK {want} but {have} GPU(s) visible", file=sys.stderr)
+            sys.exit(2)
     rank, world, local = distributed.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
@@ -237,6 +326,10 @@ def main():
     rgb, depth, padded = make_inputs(B, H, W, cid)
     elapsed, last = timed(rgb, depth, args.steps, args.warmup)
     host_cores = host.get("cores_busy")
+    if world > 1:  # outside the timed region: what every rank received from this rank is what this rank sent
+        mine = [s for s in last["r_strings"][0] + last["d_strings"][0]]
+        got = distributed.gather_streams(mine)
+        assert len(got) == world and list(got[rank]) == mine, "stream gather returned different bytes"
 
     # ---- conv profile, separate passes (not in the timed region): one engine instance, nothing else on the chip.  Twice:
     # with the tiles the timed region ran (throughput tiles when the chip is shared) and with the latency tiles, which
@@ -388,9 +481,9 @@ def main():
             res["vs_cpu"] = {"throughput": round(res["value"] / cpu["value"], 2),
                              "latency_tester_semantics": None if latency is None else round(latency["value"] / cpu["value"], 2),
                              "latency_tester_semantics_trained_like": None if latency_tl is None else round(latency_tl["value"] / cpu["value"], 2),
-                             "note": "both over the CPU oracle at B=1 tester semantics (best pair); north-star target >= 40x"}
+                             "note": "both over the best CPU-oracle leg (cpu_baseline.legs: thread counts x batch sizes); north-star target >= 40x"}
             if second is not None:
-                cpu2 = cpu_baseline(sd, 256, 256, 2, model, seconds_budget=8.0)
+                cpu2 = cpu_baseline(sd, 256, 256, 2, model, seconds_budget=8.0, batch8=False)
                 second["cpu_baseline"] = cpu2
                 second["vs_cpu"] = round(second["value"] / cpu2["value"], 2)
         print(json.dumps(res), flush=True)

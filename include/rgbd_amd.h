@@ -175,6 +175,12 @@ int rgbd_elic_forward(rgbd_elic* m, const float* rgb_dev, const float* depth_dev
 int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t cap_floats, int32_t* shape_out);
 /* Symbols / indexes of the last compress() in stream order (modality 0/1), total count in *n. */
 int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n);
+/* Parity bookkeeping: with set_debug_floats(1) the next compress() also keeps, per symbol and in stream order, the value
+ * it rounded (y - mean: the argument of quantize(), entropy_models.py:131-137) and the scale it indexed (build_indexes(),
+ * entropy_models.py:561-568); debug_floats copies them out.  Lets a test put the GPU's floats next to the reference's at
+ * the first symbol where the two streams part (tests/test_gpu_parity_pinned.py). */
+int rgbd_elic_set_debug_floats(rgbd_elic* m, int32_t on);
+int rgbd_elic_debug_floats(rgbd_elic* m, int32_t modality, float* x, float* scale, int64_t cap, int64_t* n);
 
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */
@@ -190,6 +196,10 @@ int rgbd_debug_force_fuse(int32_t mode);
  * Mode 0 also returns the image-consuming first conv (3 / 1 -> N, k 5, stride 2; analysis.py:125,150) from its K-packed
  * 1x1 form (25 taps x C real inputs gathered into 80 / 32 channels) to the tap-by-tap form. */
 int rgbd_debug_force_subpix(int32_t mode);
+/* ELIC_united's RGB and depth branches run the same layer shapes on independent data (analysis.py:116-174,
+ * synthesis.py:126-184,305-323, the per-slice channel-context nets of elic_united.py:288-333): 1 (default) issues each such
+ * layer pair as ONE grouped launch (twice the workgroups, half the launches), 0 issues two launches.  Same bits either way. */
+int rgbd_debug_force_pair(int32_t mode);
 /* Convolution tile tables: mode 0 (default) = the winners of isolated launches (lowest latency of one compress / decompress),
  * mode 1 = the winners with the chip shared between several engine instances (highest job throughput; CodecPool sets it).
  * Results are bit-identical in both modes -- tile choice never changes an output. */

@@ -40,6 +40,26 @@ struct TapTable {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };
 
+// Second operand set of a grouped launch (ConvArgs::groups == 2): the same layer shape on independent data with its own
+// weights -- the RGB and the depth branch of the transforms run as ONE launch with twice the workgroups.  Every stride,
+// extent and flag is shared; a pointer is null here exactly when its ConvArgs twin is.
+struct ConvPtrs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    const float* res1;
+    const float* mul;
+    const float* res2;
+    float* partial;
+    float* y2;
+    const float* w2;
+    const float* bias2;
+    const float* w3;
+    const float* bias3;
+    float* y3;
+};
+
 struct ConvArgs {
     const float* x;  // input NHWC (already offset to the first input channel)
     int N, H, W, xcs;
@@ -86,6 +106,8 @@ struct ConvArgs {
     float* y3;
     int y3cs;
     int cout3_pad;
+    int groups;   // 0 / 1: one operand set; 2: workgroups [tiles*N, 2*tiles*N) of the work list run the same layer on g1
+    ConvPtrs g1;
     TapTable taps;
 };
 
@@ -176,7 +198,7 @@ struct PartGeom {
 
 int launch_ckbd_encode_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs,
                             const float* table, PartGeom g, int32_t* sym, int32_t* idx, const int64_t* stream_base,
-                            int64_t part_off_per_image, hipStream_t s);
+                            int64_t part_off_per_image, hipStream_t s, float* dbg_x = nullptr, float* dbg_s = nullptr);
 int launch_ckbd_index_part(const float* params, int pcs, const float* table, PartGeom g, int32_t* idx,
                            const int64_t* stream_base, int64_t part_off_per_image, hipStream_t s);
 int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs, PartGeom g, const int32_t* sym,

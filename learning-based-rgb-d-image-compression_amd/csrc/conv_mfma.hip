@@ -78,7 +78,25 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     const int tile_x = bt % tiles_x;
     bt /= tiles_x;
     const int tile_y = bt % tiles_y;
-    const int n = bt / tiles_y;
+    int n = bt / tiles_y;
+    // grouped launch (ConvArgs::groups == 2): the second half of the image range runs the same layer on the second operand
+    // set.  Everything below addresses through these wave-uniform pointers (scalar selects on kernel arguments).
+    const bool g1 = n >= a.N;
+    if (g1) n -= a.N;
+    const float* const gx = g1 ? a.g1.x : a.x;
+    const float* const gw = g1 ? a.g1.w : a.w;
+    const float* const gbias = g1 ? a.g1.bias : a.bias;
+    float* const gy = g1 ? a.g1.y : a.y;
+    const float* const gres1 = g1 ? a.g1.res1 : a.res1;
+    const float* const gmul = g1 ? a.g1.mul : a.mul;
+    const float* const gres2 = g1 ? a.g1.res2 : a.res2;
+    float* const gpartial = g1 ? a.g1.partial : a.partial;
+    float* const gy2 = g1 ? a.g1.y2 : a.y2;
+    const float* const gw2 = g1 ? a.g1.w2 : a.w2;
+    const float* const gbias2 = g1 ? a.g1.bias2 : a.bias2;
+    const float* const gw3 = g1 ? a.g1.w3 : a.w3;
+    const float* const gbias3 = g1 ? a.g1.bias3 : a.bias3;
+    float* const gy3 = g1 ? a.g1.y3 : a.y3;
     // checkerboard output (a.ckbd): the tile's TW columns are every second column of a 2*TW-wide strip -- pixel (py, k)
     // sits at column 2k + par(row); the staged patch is the whole strip, only the B-fragment rows and the stores move
     const int ck = a.ckbd ? 1 : 0;
@@ -146,7 +164,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     int gw_j[WR];      // tap slot inside the stage
     unsigned gw_voff[WR];  // byte offset of the slot's weight row ((co0+m) * ntaps_total * cin_pad + c4*4 floats; always a valid row)
     int gp_off[PR];    // (iy*W + ix) * xcs + c4*4 inside image n, or -1 when outside the image / patch
-    const float* xn = a.x + (size_t)n * a.H * a.W * a.xcs;  // wave-uniform base of the tile's image
+    const float* xn = gx + (size_t)n * a.H * a.W * a.xcs;  // wave-uniform base of the tile's image
     {
 #pragma unroll
         for (int u = 0; u < WR; ++u) {
@@ -180,7 +198,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             const int c4x4 = ((tid + u * 256) % C4) * 4;
             if (gw_j[u] < tg && (KC == 16 || ci0 + c4x4 < ci_hi))
                 v = *reinterpret_cast<const f32x4*>(
-                    reinterpret_cast<const char*>(a.w) +
+                    reinterpret_cast<const char*>(gw) +
                     (size_t)(gw_voff[u] + (unsigned)(__builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0) * 4u));
             pw[DMA ? 0 : u] = v;
         }
@@ -224,7 +242,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             if (gw_j[u] < tg) {  // wave-uniform
                 const unsigned so = (unsigned)(__builtin_amdgcn_readlane(my_tap_w, t0 + gw_j[u]) + ci0) * 4u;
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.w) + (size_t)(gw_voff[u] + so)),
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(gw) + (size_t)(gw_voff[u] + so)),
                     (__attribute__((address_space(3))) void*)(lds_w + u * 1024), 16, 0, 0);
             }
     };
@@ -352,7 +370,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
         }
         auto issue_w3 = [&](int g) {
             if constexpr (LEAD) {
-                const char* base = reinterpret_cast<const char*>(a.w3) + (size_t)g * (G2 * 16) * 4;  // column slice g
+                const char* base = reinterpret_cast<const char*>(gw3) + (size_t)g * (G2 * 16) * 4;  // column slice g
 #pragma unroll
                 for (int u = 0; u < WU3; ++u)
                     if (tid + u * 256 < SLAB3) pw3[u] = *reinterpret_cast<const f32x4*>(base + w3_off[u]);
@@ -375,7 +393,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
         }
         f32x4 pw2[WU];
         auto issue_w2 = [&](int g) {
-            const char* base = reinterpret_cast<const char*>(a.w2) + (size_t)g * (G2 * 16) * K2 * 4;  // wave-uniform
+            const char* base = reinterpret_cast<const char*>(gw2) + (size_t)g * (G2 * 16) * K2 * 4;  // wave-uniform
 #pragma unroll
             for (int u = 0; u < WU; ++u)
                 if (tid + u * 256 < SLAB4) pw2[u] = *reinterpret_cast<const f32x4*>(base + w2_off[u]);
@@ -391,7 +409,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
         // t = act_mid(acc + bias): the float operations of the stand-alone launch's epilogue
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + i * 16 + q * 4);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(gbias + i * 16 + q * 4);
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 f32x4 t = acc[i][k] + b4;
@@ -407,8 +425,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
         commit_w3(0);
         __syncthreads();
         const size_t img_px2 = (size_t)n * a.OH * a.OW;
-        char* yn2 = reinterpret_cast<char*>(a.y + img_px2 * a.ycs);
-        const char* r1n2 = reinterpret_cast<const char*>(a.res1 + img_px2 * a.r1cs);
+        char* yn2 = reinterpret_cast<char*>(gy + img_px2 * a.ycs);
+        const char* r1n2 = reinterpret_cast<const char*>(gres1 + img_px2 * a.r1cs);
         for (int g = 0; g < ng2; ++g) {
             if (g + 1 < ng2) {
                 issue_w2(g + 1);
@@ -469,7 +487,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                 for (int u = 0; u < UB2; ++u) {
                     if (!ok[u]) continue;
-                    f32x4 w = v[u] + *reinterpret_cast<const f32x4*>(a.bias2 + cbs[u]);
+                    f32x4 w = v[u] + *reinterpret_cast<const f32x4*>(gbias2 + cbs[u]);
                     if (a.res1) w += r1[u];
                     if (a.act == ACT_RELU) {
 #pragma unroll
@@ -518,7 +536,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             __syncthreads();  // the last group's fragments have been read
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias3 + i * 16 + q * 4);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(gbias3 + i * 16 + q * 4);
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     f32x4 t = uacc[i][k] + b4;
@@ -528,7 +546,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                 }
             }
             __syncthreads();
-            char* y3n = reinterpret_cast<char*>(a.y3 + img_px2 * a.y3cs);
+            char* y3n = reinterpret_cast<char*>(gy3 + img_px2 * a.y3cs);
 #pragma unroll
             for (int u = 0; u < EU3; ++u) {
                 const int f = tid + u * 256;
@@ -548,12 +566,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     // consecutive couts of the same pixel (full lines for TM >= 32 couts), which is also how the fused
     // residual / gate / skip operands are read.
     const size_t img_px = (size_t)n * a.OH * a.OW;  // wave-uniform per-image bases (byte pointers)
-    char* yn = reinterpret_cast<char*>(a.y + img_px * a.ycs);
-    const char* r1n = reinterpret_cast<const char*>(a.res1 + img_px * a.r1cs);
-    const char* mln = reinterpret_cast<const char*>(a.mul + img_px * a.mcs);
-    const char* r2n = reinterpret_cast<const char*>(a.res2 + img_px * a.r2cs);
-    char* y2n = reinterpret_cast<char*>(a.y2 + img_px * a.y2cs);
-    char* ptn = reinterpret_cast<char*>(a.partial + ((size_t)split * a.N * a.OH * a.OW + img_px) * a.cout_pad);
+    char* yn = reinterpret_cast<char*>(gy + img_px * a.ycs);
+    const char* r1n = reinterpret_cast<const char*>(gres1 + img_px * a.r1cs);
+    const char* mln = reinterpret_cast<const char*>(gmul + img_px * a.mcs);
+    const char* r2n = reinterpret_cast<const char*>(gres2 + img_px * a.r2cs);
+    char* y2n = reinterpret_cast<char*>(gy2 + img_px * a.y2cs);
+    char* ptn = reinterpret_cast<char*>(gpartial + ((size_t)split * a.N * a.OH * a.OW + img_px) * a.cout_pad);
     for (int ip = 0; ip < MT; ip += EMT) {
         __syncthreads();  // LDS is free: the last stage (or the previous pass) has been consumed
 #pragma unroll
@@ -603,7 +621,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                     *reinterpret_cast<f32x4*>(ptn + (size_t)((pixs[u] * (unsigned)a.cout_pad + cb) * 4u)) = w;
                     continue;
                 }
-                w += *reinterpret_cast<const f32x4*>(a.bias + cb);
+                w += *reinterpret_cast<const f32x4*>(gbias + cb);
                 if (a.res1) w += r1[u];
                 if (a.act == ACT_RELU) {
 #pragma unroll
@@ -700,7 +718,7 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
             if (dev >= 0 && dev < 64) configured[dev] = true;
         }
     }
-    dim3 grid((unsigned)(tiles_x * tiles_y * a.N) * (unsigned)((a.cout_pad + TM - 1) / TM), 1,
+    dim3 grid((unsigned)(tiles_x * tiles_y * a.N * (a.groups == 2 ? 2 : 1)) * (unsigned)((a.cout_pad + TM - 1) / TM), 1,
               (unsigned)(a.nphase * a.splitk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps, (int)(buf_bytes / 4));
     HIP_TRY(hipGetLastError());
@@ -752,7 +770,7 @@ Choice choose(const ConvArgs& a)
         const int tm = 16 * mt * wm, tp = 16 * nt * (wm == 2 ? 2 : 4);
         const int twl = pick_tw_log2(GWe, a.GH, tp);
         const int TW = 1 << twl, TH = tp / TW;
-        const long tiles = (long)((GWe + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N;
+        const long tiles = (long)((GWe + TW - 1) / TW) * ((a.GH + TH - 1) / TH) * a.N * (a.groups == 2 ? 2 : 1);
         const long blocks = tiles * ((a.cout_pad + tm - 1) / tm) * a.nphase * a.splitk;
         const int PH = (TH - 1) * a.IS + a.span_y, PW = ((TW << ck) - 1) * a.IS + a.span_x;
         const int pr = tp >= 128 ? 12 : (tp >= 64 ? 6 : 4);
@@ -812,7 +830,16 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
 {
     const int c4n = a.cout_pad / 4;
     const size_t plane = (size_t)a.N * a.OH * a.OW * a.cout_pad;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t all4 = a.groups == 2 ? 2 * total4 : total4;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < all4; j += (size_t)gridDim.x * blockDim.x) {
+        const bool g1 = j >= total4;  // grouped launch: the second operand set's outputs
+        const size_t i = g1 ? j - total4 : j;
+        const float* const gpartial = g1 ? a.g1.partial : a.partial;
+        const float* const gbias = g1 ? a.g1.bias : a.bias;
+        const float* const gres1 = g1 ? a.g1.res1 : a.res1;
+        const float* const gmul = g1 ? a.g1.mul : a.mul;
+        const float* const gres2 = g1 ? a.g1.res2 : a.res2;
+        float* const gy = g1 ? a.g1.y : a.y;
         const size_t pix = i / c4n;
         const int cb = (int)(i - pix * c4n) * 4;
         if (cb >= a.cout_store) continue;
@@ -820,10 +847,10 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
             const int gx = (int)(pix % a.OW), gy = (int)((pix / a.OW) % a.OH);
             if (((gy + gx) & 1) != (a.ckbd == 1 ? 1 : 0)) continue;
         }
-        f32x4 v = *reinterpret_cast<const f32x4*>(a.partial + pix * a.cout_pad + cb);
-        for (int s = 1; s < a.splitk; ++s) v += *reinterpret_cast<const f32x4*>(a.partial + s * plane + pix * a.cout_pad + cb);
-        v += *reinterpret_cast<const f32x4*>(a.bias + cb);
-        if (a.res1) v += *reinterpret_cast<const f32x4*>(a.res1 + pix * a.r1cs + cb);
+        f32x4 v = *reinterpret_cast<const f32x4*>(gpartial + pix * a.cout_pad + cb);
+        for (int s = 1; s < a.splitk; ++s) v += *reinterpret_cast<const f32x4*>(gpartial + s * plane + pix * a.cout_pad + cb);
+        v += *reinterpret_cast<const f32x4*>(gbias + cb);
+        if (a.res1) v += *reinterpret_cast<const f32x4*>(gres1 + pix * a.r1cs + cb);
         if (a.act == ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -837,13 +864,23 @@ __global__ void splitk_reduce_kernel(ConvArgs a, size_t total4)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
         }
-        if (a.mul) v *= *reinterpret_cast<const f32x4*>(a.mul + pix * a.mcs + cb);
-        if (a.res2) v += *reinterpret_cast<const f32x4*>(a.res2 + pix * a.r2cs + cb);
-        *reinterpret_cast<f32x4*>(a.y + pix * a.ycs + cb) = v;
+        if (a.mul) v *= *reinterpret_cast<const f32x4*>(gmul + pix * a.mcs + cb);
+        if (a.res2) v += *reinterpret_cast<const f32x4*>(gres2 + pix * a.r2cs + cb);
+        *reinterpret_cast<f32x4*>(gy + pix * a.ycs + cb) = v;
     }
 }
 
 static int launch_conv_main(const ConvArgs& a, hipStream_t s);
+
+// grouped launch: the second operand set mirrors the first, pointer by pointer
+static bool conv_groups_ok(const ConvArgs& a)
+{
+    if (a.groups != 2) return a.groups == 0 || a.groups == 1;
+    const ConvPtrs& g = a.g1;
+    return g.x && g.w && g.bias && g.y && !a.res1 == !g.res1 && !a.mul == !g.mul && !a.res2 == !g.res2 &&
+           !a.partial == !g.partial && !a.y2 == !g.y2 && !a.w2 == !g.w2 && !a.bias2 == !g.bias2 && !a.w3 == !g.w3 &&
+           !a.bias3 == !g.bias3 && !a.y3 == !g.y3;
+}
 
 char g_conv_force[64] = {0};  // rgbd_debug_force_tile (tools/tile_sweep.py)
 
@@ -871,13 +908,14 @@ static const TunedTile* table_lookup(const TunedTile* table, const ConvArgs& a, 
     const int stride = a.nphase > 1 ? a.OS : a.IS;
     const TunedTile* near = nullptr;
     *measured = false;
+    const int aN = a.N * (a.groups == 2 ? 2 : 1);  // a grouped launch tiles like the same layer at twice the batch
     for (const TunedTile* t = table; t->N; ++t) {
-        if (t->H == a.H && t->W == a.W && t->N == a.N) *measured = true;
+        if (t->H == a.H && t->W == a.W && t->N == aN) *measured = true;
         if (t->H != a.H || t->W != a.W || t->cin_pad != a.cin_pad || t->cout_pad != a.cout_pad || t->ntaps != a.ntaps_total ||
             t->stride != stride || t->nphase != a.nphase + 10 * a.ckbd || t->splitk != a.splitk)
             continue;
-        if (t->N == a.N) return t;
-        if (!near || abs(t->N - a.N) < abs(near->N - a.N)) near = t;
+        if (t->N == aN) return t;
+        if (!near || abs(t->N - aN) < abs(near->N - aN)) near = t;
     }
     // A batch size that was never measured on this map takes the entry of the same layer whose batch size is closest --
     // the winner depends on N only through the number of tiles, so a neighbour beats the cost model.
@@ -930,6 +968,7 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
     if (a.splitk < 1) a.splitk = 1;
     if (a.splitk > a.cin_pad / 16) a.splitk = a.cin_pad / 16;
     if (a.splitk > 1 && !a.partial) return RGBD_EINVAL;
+    if (!conv_groups_ok(a)) return RGBD_EINVAL;
     {   // the kernels address one image's input / output / fused operands with 32-bit byte offsets from a per-image base
         const size_t lim = (size_t)1 << 32;
         const size_t opx = (size_t)a.OH * a.OW * 4;
@@ -947,7 +986,7 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
     const int rc = launch_conv_main(a, s);
     if (rc || !a.partial) return rc;
     const size_t total4 = (size_t)a.N * a.OH * a.OW * (a.cout_pad / 4);
-    size_t g = (total4 + 255) / 256;
+    size_t g = ((a.groups == 2 ? 2 : 1) * total4 + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, total4);
     HIP_TRY(hipGetLastError());
@@ -971,7 +1010,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     }
     if (g_log_on) {
         char key[160];
-        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", a.N, a.H, a.W, a.cin_pad, a.cout_pad, a.ntaps_total,
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", a.N * (a.groups == 2 ? 2 : 1), a.H, a.W, a.cin_pad, a.cout_pad, a.ntaps_total,
                  a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd, a.splitk);
         std::lock_guard<std::mutex> lk(g_log_mu);
         ++g_log[key];
@@ -1031,7 +1070,7 @@ int conv_fused_plan(int cout_pad, int cout2_pad, int ntaps, int N, int GH, int G
 int launch_conv_fused(const ConvArgs& a_in, hipStream_t s)
 {
     ConvArgs a = a_in;
-    if (!a.w2 || !a.bias2 || a.cout2_pad <= 0) return RGBD_EINVAL;
+    if (!a.w2 || !a.bias2 || a.cout2_pad <= 0 || !conv_groups_ok(a)) return RGBD_EINVAL;
     if (a.cout_store <= 0 || a.cout_store > a.cout2_pad) a.cout_store = a.cout2_pad;
     if (a.cout_store % 4) return RGBD_EINVAL;
     if (a.nphase != 1 || a.IS != 1 || a.OS != 1 || a.splitk > 1 || a.partial || a.mul || a.res2 || a.ckbd) return RGBD_EINVAL;
@@ -1047,7 +1086,7 @@ int launch_conv_fused(const ConvArgs& a_in, hipStream_t s)
         if ((size_t)a.H * a.W * a.xcs * 4 >= lim || opx * ocs >= lim || (size_t)a.cout_pad * a.ntaps_total * a.cin_pad * 4 >= lim)
             return RGBD_EINVAL;
     }
-    const int cls = conv_fused_plan(a.cout_pad, a.cout2_pad, a.ntaps_total, a.N, a.GH, a.GW, a.loaded);
+    const int cls = conv_fused_plan(a.cout_pad, a.cout2_pad, a.ntaps_total, a.N * (a.groups == 2 ? 2 : 1), a.GH, a.GW, a.loaded);
     if (a.cout_pad != 96) return RGBD_EINVAL;
     if (a.w3) {  // + the next block's leading 1x1: 128- and 64-pixel tiles only (u needs TM x TP accumulators as well)
         if (a.cout2_pad % 32) return RGBD_EINVAL;

@@ -13,6 +13,16 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <dirent.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <thread>
+#include <unistd.h>
+
 #include "../../include/rgbd_amd.h"
 #include "common.h"
 
@@ -325,11 +335,94 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
 // poisons that capture.  Captures hold this lock shared (several engine instances may capture at once); everything that
 // frees or synchronises device-wide takes it exclusively.
 std::shared_mutex g_capture_mu;
+
+// ---- hang diagnostics (RGBD_DEBUG_DESTROY=1) -----------------------------------------------------------------------------
+// A HangWatch around a runtime call that may wait for the device (hipFree = implicit device synchronise): if the call has
+// not returned after `secs`, every thread of the process prints its host backtrace (SIGUSR2 handler; the runtime is
+// stripped, but the exported entry points -- hipFree, hipGraphLaunch, hsa_signal_wait_*, pthread lock waits -- tell a
+// host lock cycle from a wait for a GPU signal), then every engine stream is queried (hipStreamQuery does not block), which
+// names the stream that still holds work.  This is how the round-2 "hipFree never returns" report was taken apart.
+std::mutex g_live_mu;
+std::map<const void*, hipStream_t> g_live_streams;  // engine -> the stream of its last call
+const bool g_dbg_destroy = getenv("RGBD_DEBUG_DESTROY") != nullptr;
+
+void bt_handler(int)
+{
+    void* fr[64];
+    const int n = backtrace(fr, 64);
+    char hdr[64];
+    const int l = snprintf(hdr, sizeof(hdr), "[bt tid %ld]\n", (long)syscall(SYS_gettid));
+    if (l > 0) (void)!write(2, hdr, (size_t)l);
+    backtrace_symbols_fd(fr, n, 2);
+}
+
+struct HangWatch {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    HangWatch(const char* what, int secs)
+    {
+        if (!g_dbg_destroy) return;
+        th = std::thread([this, what, secs] {
+            std::unique_lock<std::mutex> lk(mu);
+            if (cv.wait_for(lk, std::chrono::seconds(secs), [this] { return done; })) return;
+            lk.unlock();
+            fprintf(stderr, "[watchdog] %s has not returned after %d s; host backtraces of every thread follow\n", what, secs);
+            void* warm[4];
+            (void)backtrace(warm, 4);  // loads libgcc outside the signal handler
+            struct sigaction sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.sa_handler = bt_handler;
+            sa.sa_flags = SA_RESTART;
+            sigaction(SIGUSR2, &sa, nullptr);
+            const long self = (long)syscall(SYS_gettid);
+            if (DIR* d = opendir("/proc/self/task")) {
+                while (dirent* e = readdir(d)) {
+                    const long tid = atol(e->d_name);
+                    if (tid <= 0 || tid == self) continue;
+                    syscall(SYS_tgkill, (long)getpid(), tid, SIGUSR2);
+                    usleep(200 * 1000);
+                }
+                closedir(d);
+            }
+            std::map<const void*, hipStream_t> live;
+            {
+                std::lock_guard<std::mutex> g(g_live_mu);
+                live = g_live_streams;
+            }
+            for (const auto& kv : live) {
+                fprintf(stderr, "[watchdog] query stream %p of engine %p ...\n", (void*)kv.second, kv.first);
+                fflush(stderr);
+                const hipError_t e = hipStreamQuery(kv.second);
+                fprintf(stderr, "[watchdog]   -> %s\n", hipGetErrorName(e));
+            }
+            fprintf(stderr, "[watchdog] query NULL stream ...\n");
+            fflush(stderr);
+            const hipError_t e0 = hipStreamQuery(nullptr);
+            fprintf(stderr, "[watchdog]   -> %s\n", hipGetErrorName(e0));
+            fflush(stderr);
+            if (getenv("RGBD_DIAG_EXIT")) _exit(86);  // diagnostics runs end by themselves instead of at a time limit
+        });
+    }
+    ~HangWatch()
+    {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+};
+
 int g_cfg_epoch = 0;     // bumped by every debug switch that changes kernel choices: cached HIP graphs of older epochs are not reused
 int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 int g_bench_streams = 1;  // rgbd_debug_bench_streams: rgbd_conv_bench issues every launch on this many streams at once
 const bool g_kpack = !getenv("RGBD_NO_KPACK");  // A/B switch: first analysis conv over a K-packed input (1x1, K = 80 / 32)
 int g_subpix = getenv("RGBD_NO_SUBPIX") ? 0 : 1;  // rgbd_debug_force_subpix: sub-pixel form of the last transposed conv
+int g_pair = getenv("RGBD_NO_PAIR") ? 0 : 1;  // rgbd_debug_force_pair: RGB / depth layer pairs as one grouped launch
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
 const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
 
@@ -391,6 +484,11 @@ struct rgbd_elic {
     int32_t* dbg_sym = nullptr;
     int32_t* dbg_idx = nullptr;
     int64_t dbg_per_mod = 0;
+    // rgbd_elic_set_debug_floats: the encoder also keeps, per symbol and in stream order, the value it rounded (y - mean)
+    // and the scale it indexed -- what the parity bookkeeping compares with the reference's floats at a flipped symbol
+    bool debug_floats = false;
+    float* dbg_x = nullptr;
+    float* dbg_s = nullptr;
 
     bool is_clone = false;  // created by rgbd_elic_clone_shared: shares the parent's buffer generations (DevGen)
 
@@ -434,9 +532,29 @@ struct rgbd_elic {
     // taken out again: with it, a later hipFree -- an implicit device synchronise -- never returned in a process that had
     // also replayed graphs on torch side streams (tests/test_gpu_harness.py run as a whole; the stage is logged by
     // RGBD_DEBUG_DESTROY=1).  Throughput users drive their own streams (CodecPool), which do capture.
+    hipStream_t own_s = nullptr;   // RGBD_NULL_OWN_STREAM=1 only (the configuration of the round-2 hang report)
+    hipEvent_t null_ev = nullptr;
     int use_stream(void* stream)
     {
+        static const bool own = getenv("RGBD_NULL_OWN_STREAM") != nullptr;
         s = (hipStream_t)stream;
+        if (own && !stream) {
+            if (!own_s) {
+                HIP_TRY(hipStreamCreateWithFlags(&own_s, getenv("RGBD_DIAG_OWN_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&null_ev, hipEventDisableTiming));
+            }
+            if (!getenv("RGBD_DIAG_NO_NULL_EV")) {
+                HIP_TRY(hipEventRecord(null_ev, nullptr));
+                HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
+            } else {
+                HIP_TRY(hipStreamSynchronize(nullptr));  // order behind the NULL stream on the host instead
+            }
+            s = own_s;
+        }
+        if (g_dbg_destroy) {
+            std::lock_guard<std::mutex> g(g_live_mu);
+            g_live_streams[this] = s;
+        }
         return RGBD_OK;
     }
     // pinned staging for the per-call uploads (stream bytes, offsets): truly asynchronous copies, no per-call pinning
@@ -610,38 +728,38 @@ struct rgbd_elic {
     }
 
     // --- operators -----------------------------------------------------------------------------
+    // A convolution is planned (layer lookup, shapes, ConvArgs) and then issued.  Two plans of the same shape on independent
+    // data -- the RGB and the depth branch of a transform stage -- are issued as ONE grouped launch (ConvArgs::groups = 2:
+    // twice the workgroups, half the launches; every output keeps its fma chain, so the results are those of the two
+    // launches bit for bit: tests/test_gpu_pairs.py).
+    struct ConvPlan {
+        ConvArgs a{};
+        Act y;
+        std::string name;
+        double flops = 0.0;
+        size_t partial_bytes = 0;  // split-K / GELU partial planes of this layer
+        bool fused = false;        // launch_conv_fused
+        bool ok = false;           // a launch is wanted (not a dry run, no error so far)
+    };
+
     // fuse1x1: name of a 1x1 layer applied to relu(conv(x)) inside the same launch (launch_conv_fused); ep / dst / the
     // returned tensor then describe that second layer's output.  Callers ask fusable() first.
     // lead1x1 / lead_dst (only with fuse1x1): a further 1x1 + ReLU applied to that output inside the same launch -- the
     // leading layer of the block that follows -- written to *lead_dst.
-    Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
-             const std::string* fuse1x1 = nullptr, const std::string* lead1x1 = nullptr, const Act* lead_dst = nullptr)
+    ConvPlan conv_plan(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
+                       const std::string* fuse1x1 = nullptr, const std::string* lead1x1 = nullptr,
+                       const Act* lead_dst = nullptr)
     {
+        ConvPlan cp;
+        cp.name = name;
         const PackedConv* pc = conv_of(name + ".weight");
-        if (!pc) return Act();
-        if (g_kpack && g_subpix && !pc->transposed && pc->k == 5 && stride == 2 && pad == 2 && x.c <= 3 && !fuse1x1) {
-            // first analysis conv: gather the 25 x C real inputs of every output pixel, then a 1x1 layer with K = 80 / 32
-            auto kp = convs.find(name + ".kpack.weight");
-            if (kp != convs.end()) {
-                const int OH = (x.h + 2 * pad - 5) / stride + 1, OW = (x.w + 2 * pad - 5) / stride + 1;
-                Act out = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
-                const size_t mark = arena.top;
-                Act xk = alloc(x.n, OH, OW, kp->second.cin_pad);
-                if (!dry() && !rc) {
-                    const int r = launch_im2col5s2(x.p, x.n, x.h, x.w, x.cs, x.c, xk.p, OH, OW, xk.cs, s);
-                    if (r) fail(r);
-                }
-                conv(name + ".kpack", xk, 1, 0, ep, &out);
-                arena.top = mark;
-                return out;
-            }
-        }
+        if (!pc) return cp;
         const PackedConv* pc2 = fuse1x1 ? conv_of(*fuse1x1 + ".weight") : nullptr;
-        if (fuse1x1 && !pc2) return Act();
+        if (fuse1x1 && !pc2) return cp;
         const PackedConv* pc3 = (pc2 && lead1x1 && lead_dst) ? conv_of(*lead1x1 + ".weight") : nullptr;
         if (lead1x1 && !pc3) {
             fail(RGBD_EINVAL);
-            return Act();
+            return cp;
         }
         const int k = pc->k;
         int OH, OW;
@@ -654,6 +772,7 @@ struct rgbd_elic {
         }
         const PackedConv* pcy = pc2 ? pc2 : pc;  // the layer that produces y
         Act y = dst ? *dst : alloc(x.n, OH, OW, pcy->cout);
+        cp.y = y;
         if (round_up(x.c, 16) != pc->cin_pad || y.h != OH || y.w != OW || y.n != x.n || y.c != pcy->cout ||
             (pc2 && (pc2->k != 1 || pc2->cin_pad != pc->cout_pad || pc2->transposed)) ||
             (pc3 && (pc3->k != 1 || pc3->cin_pad != pc2->cout_pad || pc3->transposed || lead_dst->c != pc3->cout ||
@@ -661,16 +780,12 @@ struct rgbd_elic {
             fprintf(stderr, "[rgbd_amd] shape mismatch at %s: x.c=%d cin=%d y=(%d,%d,%d) expect (%d,%d,%d)\n", name.c_str(),
                     x.c, pc->cin, y.h, y.w, y.c, OH, OW, pc->cout);
             fail(RGBD_EINVAL);
-            return y;
+            return cp;
         }
-        if (dry()) {  // account for the split-K scratch of this layer (upper bound: 8 partial planes)
-            const size_t m0 = arena.top;
-            (void)arena.take((size_t)8 * x.n * OH * OW * pc->cout_pad * sizeof(float));
-            arena.top = m0;
-            return y;
-        }
-        if (rc) return y;
-        ConvArgs a{};
+        // split-K scratch: the sizing pass books the upper bound (8 partial planes) per layer of a launch
+        cp.partial_bytes = (size_t)8 * x.n * OH * OW * pc->cout_pad * sizeof(float);
+        if (dry() || rc) return cp;
+        ConvArgs& a = cp.a;
         a.x = x.p;
         a.N = x.n;
         a.H = x.h;
@@ -752,10 +867,64 @@ struct rgbd_elic {
                 a.splitk = g_force_splitk > 0 ? g_force_splitk : conv_splitk_for(a.cin_pad, mt, (long)OH * OW, a.nphase);
                 break;
             }
-        const size_t pmark = arena.top;
         // split-K partial planes; a GELU layer (STF_united's MLP) also goes through the reducer, with a single plane
-        if (a.splitk > 1 || a.act == ACT_GELU)
-            a.partial = (float*)arena.take((size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float));
+        cp.partial_bytes = (a.splitk > 1 || a.act == ACT_GELU) ? (size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float) : 0;
+        cp.flops = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
+                       (pc->transposed ? (double)(stride * stride) : 1.0) +
+                   (pc2 ? 2.0 * (double)x.n * OH * OW * (double)pc2->cout * pc2->cin : 0.0) +
+                   (pc3 ? 2.0 * (double)x.n * OH * OW * (double)pc3->cout * pc3->cin : 0.0);
+        cp.fused = pc2 != nullptr;
+        cp.ok = true;
+        return cp;
+    }
+
+    // can the two plans share a launch?  Same layer shape, strides and epilogue, operand by operand
+    static bool pairable(const ConvPlan& p, const ConvPlan& q)
+    {
+        if (!p.ok || !q.ok || p.fused != q.fused) return false;
+        const ConvArgs &a = p.a, &b = q.a;
+        return a.N == b.N && a.H == b.H && a.W == b.W && a.xcs == b.xcs && a.cin_pad == b.cin_pad &&
+               a.ntaps_total == b.ntaps_total && a.OH == b.OH && a.OW == b.OW && a.ycs == b.ycs && a.cout_pad == b.cout_pad &&
+               a.cout_store == b.cout_store && a.GH == b.GH && a.GW == b.GW && a.IS == b.IS && a.OS == b.OS &&
+               a.nphase == b.nphase && a.min_dy == b.min_dy && a.min_dx == b.min_dx && a.span_y == b.span_y &&
+               a.span_x == b.span_x && a.act == b.act && !a.res1 == !b.res1 && a.r1cs == b.r1cs && !a.mul == !b.mul &&
+               a.mcs == b.mcs && !a.res2 == !b.res2 && a.r2cs == b.r2cs && a.splitk == b.splitk && a.loaded == b.loaded &&
+               a.ckbd == b.ckbd && !a.y2 == !b.y2 && a.y2cs == b.y2cs && a.subpix == b.subpix && !a.w2 == !b.w2 &&
+               a.cout2_pad == b.cout2_pad && a.act_mid == b.act_mid && !a.w3 == !b.w3 && a.y3cs == b.y3cs &&
+               a.cout3_pad == b.cout3_pad && memcmp(&a.taps, &b.taps, sizeof(TapTable)) == 0;
+    }
+
+    // launch one plan, or two plans as one grouped launch (q != nullptr: the caller has checked pairable())
+    void conv_issue(ConvPlan& p, ConvPlan* q = nullptr)
+    {
+        if (dry()) {  // book the split-K scratch of this launch
+            const size_t m0 = arena.top;
+            (void)arena.take(p.partial_bytes + (q ? q->partial_bytes : 0));
+            arena.top = m0;
+            return;
+        }
+        if (rc || !p.ok || (q && !q->ok)) return;
+        ConvArgs a = p.a;
+        const size_t pmark = arena.top;
+        if (p.partial_bytes) a.partial = (float*)arena.take(p.partial_bytes);
+        if (q) {
+            const ConvArgs& b = q->a;
+            a.groups = 2;
+            a.g1.x = b.x;
+            a.g1.w = b.w;
+            a.g1.bias = b.bias;
+            a.g1.y = b.y;
+            a.g1.res1 = b.res1;
+            a.g1.mul = b.mul;
+            a.g1.res2 = b.res2;
+            a.g1.y2 = b.y2;
+            a.g1.w2 = b.w2;
+            a.g1.bias2 = b.bias2;
+            a.g1.w3 = b.w3;
+            a.g1.bias3 = b.bias3;
+            a.g1.y3 = b.y3;
+            if (q->partial_bytes) a.g1.partial = (float*)arena.take(q->partial_bytes);
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile) {
             if (ev_used + 2 > ev_pool.size()) {
@@ -763,7 +932,7 @@ struct rgbd_elic {
                     hipEvent_t e;
                     if (hipEventCreate(&e) != hipSuccess) {
                         fail(RGBD_EHIP);
-                        return y;
+                        return;
                     }
                     ev_pool.push_back(e);
                 }
@@ -772,23 +941,80 @@ struct rgbd_elic {
             e1 = ev_pool[ev_used++];
             (void)hipEventRecord(e0, s);
         }
-        const int r = pc2 ? launch_conv_fused(a, s) : launch_conv(a, s);
+        const int r = p.fused ? launch_conv_fused(a, s) : launch_conv(a, s);
         if (profile) {
             (void)hipEventRecord(e1, s);
-            const double fl = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
-                                  (pc->transposed ? (double)(stride * stride) : 1.0) +
-                              (pc2 ? 2.0 * (double)x.n * OH * OW * (double)pc2->cout * pc2->cin : 0.0) +
-                              (pc3 ? 2.0 * (double)x.n * OH * OW * (double)pc3->cout * pc3->cin : 0.0);
+            const double fl = p.flops + (q ? q->flops : 0.0);
             prof_flops += fl;
             ++prof_launches;
-            ev_names.emplace_back(name, fl);
+            ev_names.emplace_back(p.name, fl);
         }
         arena.top = pmark;  // stream order protects the scratch: later kernels of this stream run after the reducer
         if (r) {
-            fprintf(stderr, "[rgbd_amd] conv launch failed at %s (%d)\n", name.c_str(), r);
+            fprintf(stderr, "[rgbd_amd] conv launch failed at %s (%d)\n", p.name.c_str(), r);
             fail(r);
         }
-        return y;
+    }
+
+    // first analysis conv (3 / 1 -> N, k 5, stride 2): gather the 25 x C real inputs of every output pixel, then a 1x1 layer
+    // with K = 80 / 32 (pack_kpack); returns false when the layer is not of that kind
+    bool conv_kpacked(const std::string& name, const Act& x, int stride, int pad, const Epi& ep, const Act* dst, Act* out)
+    {
+        auto pcw = convs.find(name + ".weight");
+        if (pcw == convs.end()) return false;
+        const PackedConv* pc = &pcw->second;
+        if (!(g_kpack && g_subpix && !pc->transposed && pc->k == 5 && stride == 2 && pad == 2 && x.c <= 3)) return false;
+        auto kp = convs.find(name + ".kpack.weight");
+        if (kp == convs.end()) return false;
+        const int OH = (x.h + 2 * pad - 5) / stride + 1, OW = (x.w + 2 * pad - 5) / stride + 1;
+        *out = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
+        const size_t mark = arena.top;
+        Act xk = alloc(x.n, OH, OW, kp->second.cin_pad);
+        if (!dry() && !rc) {
+            const int r = launch_im2col5s2(x.p, x.n, x.h, x.w, x.cs, x.c, xk.p, OH, OW, xk.cs, s);
+            if (r) fail(r);
+        }
+        conv(name + ".kpack", xk, 1, 0, ep, out);
+        arena.top = mark;
+        return true;
+    }
+
+    Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
+             const std::string* fuse1x1 = nullptr, const std::string* lead1x1 = nullptr, const Act* lead_dst = nullptr)
+    {
+        Act out;
+        if (!fuse1x1 && conv_kpacked(name, x, stride, pad, ep, dst, &out)) return out;
+        ConvPlan cp = conv_plan(name, x, stride, pad, ep, dst, fuse1x1, lead1x1, lead_dst);
+        conv_issue(cp);
+        return cp.y;
+    }
+
+    // The same layer kind for both modalities (names n[0] / n[1]: RGB / depth branch): one grouped launch when the two
+    // plans agree in every shape, otherwise (first / last image-facing layers: 3 vs 1 channels) two launches.
+    void conv2(const std::string n[2], const Act x[2], int stride, int pad, const Epi ep[2], const Act* const dst[2], Act out[2],
+               const std::string* const fuse1x1[2] = nullptr, const std::string* const lead1x1[2] = nullptr,
+               const Act* const lead_dst[2] = nullptr)
+    {
+        if (!fuse1x1) {
+            Act o0;
+            if (conv_kpacked(n[0], x[0], stride, pad, ep[0], dst ? dst[0] : nullptr, &o0)) {  // (the depth twin is of that kind too)
+                out[0] = o0;
+                out[1] = conv(n[1], x[1], stride, pad, ep[1], dst ? dst[1] : nullptr);
+                return;
+            }
+        }
+        ConvPlan p[2];
+        for (int m = 0; m < 2; ++m)
+            p[m] = conv_plan(n[m], x[m], stride, pad, ep[m], dst ? dst[m] : nullptr, fuse1x1 ? fuse1x1[m] : nullptr,
+                             lead1x1 ? lead1x1[m] : nullptr, lead_dst ? lead_dst[m] : nullptr);
+        out[0] = p[0].y;
+        out[1] = p[1].y;
+        if (g_pair && (dry() || pairable(p[0], p[1]))) {
+            conv_issue(p[0], &p[1]);
+        } else {
+            conv_issue(p[0]);
+            conv_issue(p[1]);
+        }
     }
 
     // drain recorded event pairs into prof_ms (call after the stream has been synchronised)
@@ -818,13 +1044,13 @@ struct rgbd_elic {
     }
 
     // the pair (mid: 3x3 + ReLU, last: 1x1 + residual) as one launch?  (a speed decision: the results are bit-identical)
-    bool fusable(const std::string& mid, const std::string& last, const Act& x)
+    bool fusable(const std::string& mid, const std::string& last, const Act& x, int groups = 1)
     {
         auto a = convs.find(mid + ".weight"), b = convs.find(last + ".weight");
         if (a == convs.end() || b == convs.end()) return false;
         const PackedConv &p3 = a->second, &p1 = b->second;
         if (p3.transposed || p1.transposed || p1.k != 1 || p3.k != 3 || p1.cin_pad != p3.cout_pad || p1.cout % 16) return false;
-        return conv_fused_plan(p3.cout_pad, p1.cout_pad, p3.k * p3.k, x.n, x.h, x.w, tile_mode) > 0;
+        return conv_fused_plan(p3.cout_pad, p1.cout_pad, p3.k * p3.k, x.n * groups, x.h, x.w, tile_mode) > 0;
     }
 
     // ... and can the leading 1x1 + ReLU of the block after it ride along?  (its input is this block's output)
@@ -936,6 +1162,224 @@ struct rgbd_elic {
         return out;
     }
 
+    // ---- the same blocks for both modalities at once (p[0] / p[1]: the RGB / depth branch's layer names) ----------------
+    // Every layer pair is one grouped launch (conv2).  The fusion decisions are taken for the pair: a grouped launch tiles
+    // like the layer at twice the batch.
+    void take_lead2(const std::string n[2], const Act x[2], Act t[2])
+    {
+        auto i0 = pre_leads.find(n[0]), i1 = pre_leads.find(n[1]);
+        if (i0 != pre_leads.end() && i1 != pre_leads.end()) {
+            t[0] = i0->second;
+            t[1] = i1->second;
+            pre_leads.erase(n[0]);
+            pre_leads.erase(n[1]);
+            return;
+        }
+        if (i0 != pre_leads.end() || i1 != pre_leads.end()) {  // (never planned that way; stay correct)
+            t[0] = take_lead(n[0], x[0]);
+            t[1] = take_lead(n[1], x[1]);
+            return;
+        }
+        Epi relu[2];
+        relu[0].act = relu[1].act = ACT_RELU;
+        conv2(n, x, 1, 0, relu, nullptr, t);
+    }
+
+    // res_blk.py:7-27 for both modalities
+    void bottleneck2(const std::string p[2], const Act x[2], const Act* const dst[2], const std::string next_lead[2], Act out[2])
+    {
+        const PackedConv* last[2] = {conv_of(p[0] + ".branch.4.weight"), conv_of(p[1] + ".branch.4.weight")};
+        if (!last[0] || !last[1]) return;
+        const int G = g_pair ? 2 : 1;
+        std::string last_name[2], mid[2], lead0[2];
+        bool fuse = true, lead = true;
+        const bool skip = convs.count(p[0] + ".skip.weight") && convs.count(p[1] + ".skip.weight");
+        for (int m = 0; m < 2; ++m) {
+            out[m] = (dst && dst[m]) ? *dst[m] : alloc(x[m].n, x[m].h, x[m].w, last[m]->cout);
+            last_name[m] = p[m] + ".branch.4";
+            mid[m] = p[m] + ".branch.2";
+            lead0[m] = p[m] + ".branch.0";
+            fuse = fuse && fusable(mid[m], last_name[m], x[m], G);
+        }
+        for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m]);
+        Act lead_out[2];
+        if (lead)
+            for (int m = 0; m < 2; ++m)
+                lead_out[m] = alloc(x[m].n, x[m].h, x[m].w, convs.find(next_lead[m] + ".weight")->second.cout);  // outlives this block
+        const size_t mark = arena.top;
+        Act t1[2];
+        take_lead2(lead0, x, t1);
+        Act idn[2] = {x[0], x[1]};
+        if (skip) {
+            const std::string sk[2] = {p[0] + ".skip", p[1] + ".skip"};
+            const Epi none[2];
+            conv2(sk, x, 1, 0, none, nullptr, idn);
+        } else if (convs.count(p[0] + ".skip.weight") || convs.count(p[1] + ".skip.weight")) {
+            fail(RGBD_EINVAL);  // (the two branches are built alike)
+            return;
+        }
+        Epi e[2];
+        e[0].res1 = &idn[0];
+        e[1].res1 = &idn[1];
+        const Act* odst[2] = {&out[0], &out[1]};
+        Act o[2];
+        if (fuse) {
+            const std::string* f1[2] = {&last_name[0], &last_name[1]};
+            const std::string* l1[2] = {&next_lead[0], &next_lead[1]};
+            const Act* ld[2] = {&lead_out[0], &lead_out[1]};
+            conv2(mid, t1, 1, 1, e, odst, o, f1, lead ? l1 : nullptr, lead ? ld : nullptr);
+            if (lead)
+                for (int m = 0; m < 2; ++m) pre_leads[next_lead[m]] = lead_out[m];
+        } else {
+            Epi relu[2];
+            relu[0].act = relu[1].act = ACT_RELU;
+            Act t2[2];
+            conv2(mid, t1, 1, 1, relu, nullptr, t2);
+            conv2(last_name, t2, 1, 0, e, odst, o);
+        }
+        arena.top = mark;
+    }
+
+    // layers.py:177-196 for both modalities
+    void res_unit2(const std::string p[2], const Act x[2], const std::string next_lead[2], Act out[2])
+    {
+        const int G = g_pair ? 2 : 1;
+        std::string last_name[2], mid[2], lead0[2];
+        bool fuse = true, lead = true;
+        for (int m = 0; m < 2; ++m) {
+            out[m] = alloc(x[m].n, x[m].h, x[m].w, x[m].c);
+            last_name[m] = p[m] + ".conv.4";
+            mid[m] = p[m] + ".conv.2";
+            lead0[m] = p[m] + ".conv.0";
+            fuse = fuse && fusable(mid[m], last_name[m], x[m], G);
+        }
+        for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m]);
+        Act lead_out[2];
+        if (lead)
+            for (int m = 0; m < 2; ++m)
+                lead_out[m] = alloc(x[m].n, x[m].h, x[m].w, convs.find(next_lead[m] + ".weight")->second.cout);
+        const size_t mark = arena.top;
+        Act t1[2];
+        take_lead2(lead0, x, t1);
+        Epi e[2];
+        for (int m = 0; m < 2; ++m) {
+            e[m].act = ACT_RELU;
+            e[m].res1 = &x[m];
+        }
+        const Act* odst[2] = {&out[0], &out[1]};
+        Act o[2];
+        if (fuse) {
+            const std::string* f1[2] = {&last_name[0], &last_name[1]};
+            const std::string* l1[2] = {&next_lead[0], &next_lead[1]};
+            const Act* ld[2] = {&lead_out[0], &lead_out[1]};
+            conv2(mid, t1, 1, 1, e, odst, o, f1, lead ? l1 : nullptr, lead ? ld : nullptr);
+            if (lead)
+                for (int m = 0; m < 2; ++m) pre_leads[next_lead[m]] = lead_out[m];
+        } else {
+            Epi relu[2];
+            relu[0].act = relu[1].act = ACT_RELU;
+            Act t2[2];
+            conv2(mid, t1, 1, 1, relu, nullptr, t2);
+            conv2(last_name, t2, 1, 0, e, odst, o);
+        }
+        arena.top = mark;
+    }
+
+    // layers.py:198-213 for both modalities
+    void attention2(const std::string p[2], const Act x[2], const Act* const dst[2], Act out[2])
+    {
+        for (int m = 0; m < 2; ++m) out[m] = (dst && dst[m]) ? *dst[m] : alloc(x[m].n, x[m].h, x[m].w, x[m].c);
+        const size_t mark = arena.top;
+        Act a[2] = {x[0], x[1]}, b[2] = {x[0], x[1]};
+        for (int br = 0; br < 2; ++br) {
+            const char* tag = br ? ".conv_b." : ".conv_a.";
+            Act* cur = br ? b : a;
+            for (int u = 0; u < 3; ++u) {
+                std::string n[2], nl[2];
+                for (int m = 0; m < 2; ++m) {
+                    n[m] = p[m] + tag + std::to_string(u);
+                    nl[m] = u < 2 ? p[m] + tag + std::to_string(u + 1) + ".conv.0" : std::string();
+                }
+                Act o[2];
+                res_unit2(n, cur, nl, o);
+                cur[0] = o[0];
+                cur[1] = o[1];
+            }
+        }
+        Epi e[2];
+        for (int m = 0; m < 2; ++m) {
+            e[m].act = ACT_SIGMOID;
+            e[m].mul = &a[m];
+            e[m].res2 = &x[m];
+        }
+        const std::string n[2] = {p[0] + ".conv_b.3", p[1] + ".conv_b.3"};
+        const Act* odst[2] = {&out[0], &out[1]};
+        Act o[2];
+        conv2(n, b, 1, 0, e, odst, o);
+        arena.top = mark;
+    }
+
+    // attention.py:84-97 for both modalities: x[m] -> dst[m] = x[m] * sigmoid(...) (+ add[m])
+    void esa2(const std::string p[2], const Act x[2], const Act dst[2], const Act* const add[2])
+    {
+        const size_t mark = arena.top;
+        const Epi none[2];
+        Epi relu[2];
+        relu[0].act = relu[1].act = ACT_RELU;
+        auto names = [&](const char* suf, std::string n[2]) {
+            n[0] = p[0] + suf;
+            n[1] = p[1] + suf;
+        };
+        std::string n[2];
+        Act c1_[2], c1[2];
+        names(".conv1", n);
+        conv2(n, x, 1, 0, none, nullptr, c1_);
+        names(".conv2", n);
+        conv2(n, c1_, 2, 0, none, nullptr, c1);
+        if (c1[0].h < 7 || c1[0].w < 7) {
+            fail(RGBD_EINVAL);
+            return;
+        }
+        const int ph = (c1[0].h - 7) / 3 + 1, pw = (c1[0].w - 7) / 3 + 1;
+        Act v[2];
+        for (int m = 0; m < 2; ++m) {
+            v[m] = alloc(x[m].n, ph, pw, c1[m].c);
+            if (!dry() && !rc) {
+                const int r = launch_maxpool7s3(c1[m].p, c1[m].n, c1[m].h, c1[m].w, c1[m].cs, v[m].p, ph, pw, s);
+                if (r) fail(r);
+            }
+        }
+        Act vr[2], c3[2], c3b[2], up[2], sum[2], o[2];
+        names(".conv_max", n);
+        conv2(n, v, 1, 1, relu, nullptr, vr);
+        names(".conv3", n);
+        conv2(n, vr, 1, 1, relu, nullptr, c3);
+        names(".conv3_", n);
+        conv2(n, c3, 1, 1, none, nullptr, c3b);
+        for (int m = 0; m < 2; ++m) {
+            up[m] = alloc(x[m].n, x[m].h, x[m].w, c3b[m].c);
+            if (!dry() && !rc) {
+                const int r = launch_bilinear(c3b[m].p, c3b[m].n, c3b[m].h, c3b[m].w, c3b[m].cs, up[m].p, x[m].h, x[m].w, s);
+                if (r) fail(r);
+            }
+        }
+        Epi addup[2];
+        addup[0].res1 = &up[0];
+        addup[1].res1 = &up[1];
+        names(".conv_f", n);
+        conv2(n, c1_, 1, 0, addup, nullptr, sum);
+        Epi gate[2];
+        for (int m = 0; m < 2; ++m) {
+            gate[m].act = ACT_SIGMOID;
+            gate[m].mul = &x[m];
+            gate[m].res2 = add ? add[m] : nullptr;
+        }
+        const Act* odst[2] = {&dst[0], &dst[1]};
+        names(".conv4", n);
+        conv2(n, sum, 1, 0, gate, odst, o);
+        arena.top = mark;
+    }
+
     // modules/transform/attention.py:84-97; x: [.., n_feats]; writes x * sigmoid(...) into dst
     void esa(const std::string& p, const Act& x, const Act& dst, const Act* add = nullptr)
     {
@@ -990,10 +1434,21 @@ struct rgbd_elic {
         Epi er = relu, ed = relu;
         er.dup = &rf2;
         ed.dup = &df2;
-        conv(p + ".r_ext", rgb, 1, 1, er, &rf);
-        conv(p + ".d_ext", depth, 1, 1, ed, &df);
-        esa(p + ".r_esa", rd, r_dst, residual ? &rgb : nullptr);
-        esa(p + ".d_esa", dr, d_dst, residual ? &depth : nullptr);
+        {
+            const std::string n[2] = {p + ".r_ext", p + ".d_ext"};
+            const Act x[2] = {rgb, depth};
+            const Epi ep[2] = {er, ed};
+            const Act* dst[2] = {&rf, &df};
+            Act o[2];
+            conv2(n, x, 1, 1, ep, dst, o);
+        }
+        {
+            const std::string n[2] = {p + ".r_esa", p + ".d_esa"};
+            const Act x[2] = {rd, dr};
+            const Act dst[2] = {r_dst, d_dst};
+            const Act* add[2] = {residual ? &rgb : nullptr, residual ? &depth : nullptr};
+            esa2(n, x, dst, add);
+        }
         arena.top = mark;
     }
 
@@ -1048,21 +1503,30 @@ struct rgbd_elic {
                 pr_dst = &rdst;
                 pd_dst = &ddst;
             }
+            const std::string nm[2] = {pr + si, pd + si};
+            const Act xin[2] = {r, d};
+            const Act* dsts[2] = {pr_dst, pd_dst};
+            Act o[2];
             if (k == "conv") {
-                r = conv(pr + si, r, 2, 2);
-                d = conv(pd + si, d, 2, 2);
+                const Epi none[2];
+                conv2(nm, xin, 2, 2, none, nullptr, o);
+                r = o[0];
+                d = o[1];
             } else if (k == "rb") {
                 const bool next_rb = (i + 1 < 18) && std::string(kinds[i + 1]) == "rb";
                 const std::string sn = std::to_string(i + 1) + ".branch.0";
-                r = bottleneck(pr + si, r, pr_dst, next_rb ? pr + sn : std::string());
-                d = bottleneck(pd + si, d, pd_dst, next_rb ? pd + sn : std::string());
+                const std::string nl[2] = {next_rb ? pr + sn : std::string(), next_rb ? pd + sn : std::string()};
+                bottleneck2(nm, xin, dsts, nl, o);
+                r = o[0];
+                d = o[1];
                 if (next_spf) {
                     r = rcat;
                     d = dcat;
                 }
             } else if (k == "attn") {
-                r = attention(pr + si, r, pr_dst);
-                d = attention(pd + si, d, pd_dst);
+                attention2(nm, xin, dsts, o);
+                r = o[0];
+                d = o[1];
                 if (next_spf) {
                     r = rcat;
                     d = dcat;
@@ -1100,18 +1564,23 @@ struct rgbd_elic {
                 pr_dst = &rdst;
                 pd_dst = &ddst;
             }
+            const std::string nm[2] = {pr + si, pd + si};
+            const Act xin[2] = {r, d};
+            const Act* dsts[2] = {pr_dst, pd_dst};
+            Act o[2];
             if (k == "deconv") {
-                r = conv(pr + si, r, 2, 2, Epi(), pr_dst);
-                d = conv(pd + si, d, 2, 2, Epi(), pd_dst);
+                const Epi none[2];
+                conv2(nm, xin, 2, 2, none, next_spf ? dsts : nullptr, o);
             } else if (k == "rb") {
                 const bool next_rb = (i + 1 < 18) && std::string(kinds[i + 1]) == "rb";
                 const std::string sn = std::to_string(i + 1) + ".branch.0";
-                r = bottleneck(pr + si, r, pr_dst, next_rb ? pr + sn : std::string());
-                d = bottleneck(pd + si, d, pd_dst, next_rb ? pd + sn : std::string());
+                const std::string nl[2] = {next_rb ? pr + sn : std::string(), next_rb ? pd + sn : std::string()};
+                bottleneck2(nm, xin, dsts, nl, o);
             } else {
-                r = attention(pr + si, r, pr_dst);
-                d = attention(pd + si, d, pd_dst);
+                attention2(nm, xin, dsts, o);
             }
+            r = o[0];
+            d = o[1];
             if (next_spf) {
                 r = rcat;
                 d = dcat;
@@ -1129,12 +1598,16 @@ struct rgbd_elic {
         const char* mods[2] = {"rgb", "depth"};
         const Act* in[2] = {&yr, &yd};
         Act* out[2] = {zr, zd};
-        for (int m = 0; m < 2; ++m) {
-            const std::string p = std::string("h_a.") + mods[m] + "_reduction.";
-            Act t = conv(p + "0", *in[m], 1, 1, relu);
-            t = conv(p + "2", t, 2, 2, relu);
-            *out[m] = conv(p + "4", t, 2, 2);
-        }
+        const std::string p[2] = {std::string("h_a.") + mods[0] + "_reduction.", std::string("h_a.") + mods[1] + "_reduction."};
+        const Epi relu2[2] = {relu, relu}, none[2];
+        const Act x0[2] = {*in[0], *in[1]};
+        Act t0[2], t1[2], t2[2];
+        const std::string n0[2] = {p[0] + "0", p[1] + "0"}, n2[2] = {p[0] + "2", p[1] + "2"}, n4[2] = {p[0] + "4", p[1] + "4"};
+        conv2(n0, x0, 1, 1, relu2, nullptr, t0);
+        conv2(n2, t0, 2, 2, relu2, nullptr, t1);
+        conv2(n4, t1, 2, 2, none, nullptr, t2);
+        *out[0] = t2[0];
+        *out[1] = t2[1];
     }
 
     // synthesis.py:345-362.  cat(own, other) -> SE -> deconv without materialising the unscaled concatenation: the channel
@@ -1167,15 +1640,54 @@ struct rgbd_elic {
         return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
     }
 
+    // one stage of both modalities: the SE gates stay per modality, the two (transposed) convs are one grouped launch
+    void hs_block2(const std::string p[2], const Act own[2], const Act other[2], bool last, Act out[2])
+    {
+        Act f[2];
+        for (int m = 0; m < 2; ++m) {
+            const int C = own[m].c + other[m].c;
+            f[m] = alloc(own[m].n, own[m].h, own[m].w, C);
+            float* w0 = dense_of(p[m] + ".se.fc.0.weight");
+            float* w1 = dense_of(p[m] + ".se.fc.2.weight");
+            float* mean = (float*)arena.take((size_t)own[m].n * C * sizeof(float));
+            float* sc = (float*)arena.take((size_t)own[m].n * C * sizeof(float));
+            float* hid = (float*)arena.take((size_t)own[m].n * (C / 16 + 1) * sizeof(float));
+            if (C % 16 || own[m].c % 4) {
+                fail(RGBD_EINVAL);
+                return;
+            }
+            if (!dry() && !rc && w0 && w1) {
+                const int HW = own[m].h * own[m].w;
+                int r = launch_channel_mean_strided(own[m].p, own[m].n, HW, own[m].cs, own[m].c, mean, C, s);
+                if (!r) r = launch_channel_mean_strided(other[m].p, other[m].n, HW, other[m].cs, other[m].c, mean + own[m].c, C, s);
+                if (!r) r = launch_se_fc(mean, own[m].n, C, C / 16, w0, w1, hid, sc, s);
+                if (!r) r = launch_channel_scale_to_strided(own[m].p, own[m].n, HW, own[m].cs, own[m].c, sc, C, 0, f[m].p, f[m].cs, s);
+                if (!r)
+                    r = launch_channel_scale_to_strided(other[m].p, other[m].n, HW, other[m].cs, other[m].c, sc + own[m].c, C, 0,
+                                                        f[m].p + own[m].c, f[m].cs, s);
+                if (r) fail(r);
+            }
+        }
+        Epi e[2];
+        e[0].act = e[1].act = last ? ACT_NONE : ACT_LEAKY;
+        const std::string n[2] = {p[0] + ".deconv", p[1] + ".deconv"};
+        conv2(n, f, last ? 1 : 2, last ? 1 : 2, e, nullptr, out);
+    }
+
     // synthesis.py:316-323
     void h_s(const Act& zr, const Act& zd, Act* hr, Act* hd)
     {
-        Act r1 = hs_block("h_s.r_h_s1", zr, zd, false);
-        Act d1 = hs_block("h_s.d_h_s1", zd, zr, false);
-        Act r2 = hs_block("h_s.r_h_s2", r1, d1, false);
-        Act d2 = hs_block("h_s.d_h_s2", d1, r1, false);
-        *hr = hs_block("h_s.r_h_s3", r2, d2, true);
-        *hd = hs_block("h_s.d_h_s3", d2, r2, true);
+        Act cur[2] = {zr, zd};
+        for (int st = 1; st <= 3; ++st) {
+            const std::string p[2] = {"h_s.r_h_s" + std::to_string(st), "h_s.d_h_s" + std::to_string(st)};
+            const Act other[2] = {cur[1], cur[0]};
+            Act o[2];
+            hs_block2(p, cur, other, st == 3, o);
+            cur[0] = o[0];
+            cur[1] = o[1];
+        }
+        *hr = cur[0];
+        *hd = cur[1];
     }
 
     // entropy.py:69-78.  `ctx` is a channel-slice view of the slice's context buffer
@@ -1220,6 +1732,23 @@ struct rgbd_elic {
         return out;
     }
 
+    // context.py:10-30 for both modalities (slice i's two nets read only what earlier slices decoded: independent)
+    void channel_context2(const std::string p[2], const Act x[2], const Act dst[2])
+    {
+        const size_t mark = arena.top;
+        Epi relu[2];
+        relu[0].act = relu[1].act = ACT_RELU;
+        const Epi none[2];
+        const std::string n0[2] = {p[0] + ".fushion.0", p[1] + ".fushion.0"}, n2[2] = {p[0] + ".fushion.2", p[1] + ".fushion.2"},
+                          n4[2] = {p[0] + ".fushion.4", p[1] + ".fushion.4"};
+        Act t0[2], t1[2], o[2];
+        conv2(n0, x, 1, 2, relu, nullptr, t0);
+        conv2(n2, t0, 1, 2, relu, nullptr, t1);
+        const Act* odst[2] = {&dst[0], &dst[1]};
+        conv2(n4, t1, 1, 2, none, odst, o);
+        arena.top = mark;
+    }
+
     // ---- Bi-CEE loop (elic_united.py:265-348 / 454-541) -----------------------------------------
     struct Coding {
         bool encode = true;
@@ -1261,7 +1790,8 @@ struct rgbd_elic {
                                           g, s);
         } else if (cd.encode) {
             r = launch_ckbd_encode_part(y_slice.p, y_slice.cs, params.p, params.cs, yhat_slice.p, yhat_slice.cs,
-                                        scale_table, g, sym, idx, sb, part_off, s);
+                                        scale_table, g, sym, idx, sb, part_off, s, dbg_x ? dbg_x + mod_off : nullptr,
+                                        dbg_s ? dbg_s + mod_off : nullptr);
         } else {
             r = launch_ckbd_index_part(params.p, params.cs, scale_table, g, idx, sb, part_off, s);
             const int64_t count = (int64_t)g.C * g.h * (g.w / 2) * (cd.per_image ? 1 : g.B);
@@ -1300,8 +1830,10 @@ struct rgbd_elic {
             copy_ch(hyp_d, view(ctx, 4 * C + HC, HC));
             if (i) {
                 const Act cr = view(ctx, 4 * C + 2 * HC, 2 * C), cdv = view(ctx, 6 * C + 2 * HC, 2 * C);
-                channel_context("rgb_channel_context." + si, view(yhat_r, 0, c0), &cr);
-                channel_context("depth_channel_context." + si, view(yhat_d, 0, c0), &cdv);
+                const std::string cn[2] = {"rgb_channel_context." + si, "depth_channel_context." + si};
+                const Act cx[2] = {view(yhat_r, 0, c0), view(yhat_d, 0, c0)};
+                const Act cdst[2] = {cr, cdv};
+                channel_context2(cn, cx, cdst);
             }
             const Act yr = y_r ? view(*y_r, c0, C) : Act();
             const Act yd = y_d ? view(*y_d, c0, C) : Act();
@@ -1753,6 +2285,11 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     dbg_sym = sym;
     dbg_idx = idx;
     dbg_per_mod = (int64_t)B * T;
+    dbg_x = dbg_s = nullptr;
+    if (debug_floats) {
+        dbg_x = (float*)arena.take(sizeof(float) * (size_t)(2 * B * T));
+        dbg_s = (float*)arena.take(sizeof(float) * (size_t)(2 * B * T));
+    }
 
     // meta64 layout: [0,B) y stream_base inside a modality region (checkerboard kernels) ; [2B,3B) z base ;
     //   [3B,4B) z counts ; [6B,8B) z out_words ; from 8B: y encoder bases [2ny] (absolute), counts [2ny], out_words [2ny]
@@ -2034,6 +2571,11 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     dbg_sym = sym;
     dbg_idx = idx;
     dbg_per_mod = (int64_t)B * T;
+    dbg_x = dbg_s = nullptr;
+    if (debug_floats) {
+        dbg_x = (float*)arena.take(sizeof(float) * (size_t)(2 * B * T));
+        dbg_s = (float*)arena.take(sizeof(float) * (size_t)(2 * B * T));
+    }
     for (int m = 0; m < 2; ++m) {
         for (int i = 0; i < ns_y; ++i)
             if (!ys[m] || !ys[m][i] || ylen[m][i] < 8 || (ylen[m][i] & 3) || ylen[m][i] / 4 > ycap) return RGBD_EINVAL;
@@ -2208,6 +2750,11 @@ int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_im
     dbg_sym = sym;
     dbg_idx = idx;
     dbg_per_mod = (int64_t)B * T;
+    dbg_x = dbg_s = nullptr;
+    if (debug_floats) {
+        dbg_x = (float*)arena.take(sizeof(float) * (size_t)(B * T));
+        dbg_s = (float*)arena.take(sizeof(float) * (size_t)(B * T));
+    }
     // meta64: [0,B) y stream base (checkerboard kernels); [B,2B) z base; [2B,3B) z counts; [3B,4B) z out_words;
     //         [4B,4B+ny) y encoder bases; [5B,5B+ny) y counts; [6B,6B+ny) y out_words
     std::vector<int64_t> hmeta((size_t)8 * B + 64, 0);
@@ -2341,6 +2888,11 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
     dbg_sym = sym;
     dbg_idx = idx;
     dbg_per_mod = (int64_t)B * T;
+    dbg_x = dbg_s = nullptr;
+    if (debug_floats) {
+        dbg_x = (float*)arena.take(sizeof(float) * (size_t)(B * T));
+        dbg_s = (float*)arena.take(sizeof(float) * (size_t)(B * T));
+    }
     if (!dry()) {
         HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(words, hwords.data(), sizeof(uint32_t) * hwords.size(), hipMemcpyHostToDevice, s));
@@ -2740,6 +3292,15 @@ int rgbd_debug_force_fuse(int32_t mode)
 }
 
 // 0: per-phase form, 1: sub-pixel form inside the codec (default), 2: also in rgbd_conv2d_nchw (tests)
+int rgbd_debug_force_pair(int32_t mode)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
+    if (mode != 0 && mode != 1) return RGBD_EINVAL;
+    g_pair = mode;
+    ++g_cfg_epoch;
+    return RGBD_OK;
+}
+
 int rgbd_debug_force_subpix(int32_t mode)
 {
     if (mode < 0 || mode > 2) return RGBD_EINVAL;
@@ -2983,20 +3544,35 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
 
 void rgbd_elic_destroy(rgbd_elic* m)
 {
-    static const bool dbg = getenv("RGBD_DEBUG_DESTROY") != nullptr;
+    const bool dbg = g_dbg_destroy;
     if (dbg) fprintf(stderr, "[destroy %p] wait lock\n", (void*)m);
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m) return;
     if (dbg) fprintf(stderr, "[destroy %p] locked, graphs %zu\n", (void*)m, m->graphs.size());
+    if (getenv("RGBD_DIAG_SYNC_BEFORE")) {
+        HangWatch w("hipDeviceSynchronize() before the graphs are destroyed", 20);
+        (void)hipDeviceSynchronize();
+        if (dbg) fprintf(stderr, "[destroy %p] device synchronised\n", (void*)m);
+    }
     // weights, tables and the scale table belong to shared generations (DevGen) that go when their last user does
+    if (getenv("RGBD_DIAG_KEEP_GRAPHS")) m->graphs.clear();  // (leaks them)
     m->graphs_invalidate();
     if (dbg) fprintf(stderr, "[destroy %p] graphs gone\n", (void*)m);
-    if (m->arena.base) (void)hipFree(m->arena.base);
+    if (dbg) {
+        std::lock_guard<std::mutex> g(g_live_mu);
+        g_live_streams.erase(m);
+    }
+    {
+        HangWatch w("hipFree(arena) in rgbd_elic_destroy", 20);
+        if (m->arena.base) (void)hipFree(m->arena.base);
+    }
     if (dbg) fprintf(stderr, "[destroy %p] arena freed\n", (void*)m);
     if (m->pin) (void)hipHostFree(m->pin);
     if (m->res_pin) (void)hipHostFree(m->res_pin);
     if (m->pin_ev) (void)hipEventDestroy(m->pin_ev);
     if (m->done_ev) (void)hipEventDestroy(m->done_ev);
+    if (m->null_ev) (void)hipEventDestroy(m->null_ev);
+    if (m->own_s) (void)hipStreamDestroy(m->own_s);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (dbg) fprintf(stderr, "[destroy %p] events/streams gone\n", (void*)m);
     delete m;
@@ -3366,6 +3942,29 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
     if (!r && hipMemcpy(data, tmp, (size_t)need * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) r = RGBD_EHIP;
     (void)hipFree(tmp);
     return r;
+}
+
+int rgbd_elic_set_debug_floats(rgbd_elic* m, int32_t on)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
+    if (!m) return RGBD_EINVAL;
+    if (m->debug_floats != (on != 0)) m->graphs_invalidate();  // the workspace layout changes
+    m->debug_floats = on != 0;
+    return RGBD_OK;
+}
+
+int rgbd_elic_debug_floats(rgbd_elic* m, int32_t modality, float* x, float* scale, int64_t cap, int64_t* n)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
+    if (!m || !n || modality < 0 || modality > 1 || !m->dbg_x || !m->dbg_s) return RGBD_EINVAL;
+    *n = m->dbg_per_mod;
+    if (!x || !scale) return RGBD_OK;
+    if (cap < m->dbg_per_mod) return RGBD_ENOSPC;
+    HIP_TRY(hipStreamSynchronize(m->s));
+    const size_t bytes = sizeof(float) * (size_t)m->dbg_per_mod;
+    HIP_TRY(hipMemcpy(x, m->dbg_x + (size_t)modality * m->dbg_per_mod, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(scale, m->dbg_s + (size_t)modality * m->dbg_per_mod, bytes, hipMemcpyDeviceToHost));
+    return RGBD_OK;
 }
 
 int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, int32_t* indexes, int64_t cap, int64_t* n)

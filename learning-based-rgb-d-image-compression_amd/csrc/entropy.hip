@@ -51,7 +51,8 @@ template <int MODE>
 __global__ void ckbd_part_kernel(const float* __restrict__ y, int ycs, const float* __restrict__ params, int pcs,
                                  float* __restrict__ yhat, int yhcs, const float* __restrict__ table, PartGeom g,
                                  int32_t* __restrict__ sym, int32_t* __restrict__ idx,
-                                 const int64_t* __restrict__ stream_base, int64_t part_off)
+                                 const int64_t* __restrict__ stream_base, int64_t part_off,
+                                 float* __restrict__ dbg_x = nullptr, float* __restrict__ dbg_s = nullptr)
 {
     __shared__ float tbl[64];
     if (threadIdx.x < 64) tbl[threadIdx.x] = table[threadIdx.x];
@@ -71,8 +72,13 @@ __global__ void ckbd_part_kernel(const float* __restrict__ y, int ycs, const flo
         const float mean = params[pix * pcs + g.C + c];
         const int64_t pos = sym_pos(g, stream_base, part_off, b, c, row, k);
         if (MODE == 0) {
-            const float r = rintf(y[pix * ycs + c] - mean);  // round half to even, like torch.round
+            const float xm = y[pix * ycs + c] - mean;
+            const float r = rintf(xm);  // round half to even, like torch.round
             const int s = (int)r;
+            if (dbg_x) {  // parity bookkeeping (rgbd_elic_set_debug_floats): the rounded value and the indexed scale
+                dbg_x[pos] = xm;
+                dbg_s[pos] = scale;
+            }
             sym[pos] = s;
             idx[pos] = scale_to_index(tbl, scale);
             yhat[pix * yhcs + c] = (float)s + mean;
@@ -98,11 +104,11 @@ static inline unsigned part_grid(const PartGeom& g)
 
 int launch_ckbd_encode_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs,
                             const float* table, PartGeom g, int32_t* sym, int32_t* idx, const int64_t* stream_base,
-                            int64_t part_off, hipStream_t s)
+                            int64_t part_off, hipStream_t s, float* dbg_x, float* dbg_s)
 {
     if (g.w % 2) return RGBD_EINVAL;
     hipLaunchKernelGGL(ckbd_part_kernel<0>, dim3(part_grid(g)), dim3(256), 0, s, y, ycs, params, pcs, yhat, yhcs, table,
-                       g, sym, idx, stream_base, part_off);
+                       g, sym, idx, stream_base, part_off, dbg_x, dbg_s);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
@@ -112,7 +118,7 @@ int launch_ckbd_index_part(const float* params, int pcs, const float* table, Par
 {
     if (g.w % 2) return RGBD_EINVAL;
     hipLaunchKernelGGL(ckbd_part_kernel<1>, dim3(part_grid(g)), dim3(256), 0, s, (const float*)nullptr, 0, params, pcs,
-                       (float*)nullptr, 0, table, g, (int32_t*)nullptr, idx, stream_base, part_off);
+                       (float*)nullptr, 0, table, g, (int32_t*)nullptr, idx, stream_base, part_off, (float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
@@ -123,7 +129,7 @@ int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs,
     if (g.w % 2) return RGBD_EINVAL;
     hipLaunchKernelGGL(ckbd_part_kernel<2>, dim3(part_grid(g)), dim3(256), 0, s, (const float*)nullptr, 0, params, pcs,
                        yhat, yhcs, params /*unused table*/, g, const_cast<int32_t*>(sym), (int32_t*)nullptr, stream_base,
-                       part_off);
+                       part_off, (float*)nullptr, (float*)nullptr);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }

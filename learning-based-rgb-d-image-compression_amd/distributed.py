@@ -18,7 +18,10 @@ def init_from_env(backend: str = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # RGBD_DIST_FORCE_INIT=1: build the process group even for a single rank, so that a one-GPU box can run every line of
+    # the RCCL branch below (tests/test_gpu_distributed.py); a one-rank all_gather is a device copy
+    force = os.environ.get("RGBD_DIST_FORCE_INIT") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:  # RGBD_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("RGBD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
@@ -53,8 +56,12 @@ class RankStreams(Sequence):
 
     def _host(self) -> np.ndarray:
         if not isinstance(self._p, np.ndarray):
-            self._p = self._p.cpu().numpy()
+            self._p = self._p.cpu().numpy()  # (drops the reference to the gathered device buffer)
         return self._p
+
+    @property
+    def on_device(self) -> bool:
+        return not isinstance(self._p, np.ndarray) and self._p.is_cuda
 
     def __len__(self):
         return len(self._off) - 1
@@ -72,12 +79,14 @@ class RankStreams(Sequence):
         return list(self) == list(other)
 
 
-def gather_streams(streams: Sequence[bytes]) -> List[Sequence[bytes]]:
+def gather_streams(streams: Sequence[bytes], force: bool = False) -> List[Sequence[bytes]]:
     """All ranks receive every rank's list of byte strings (ranks may hold different numbers of strings): two small
     all_gathers (counts, lengths) and one all_gather of the zero-padded payload.  Element r of the result behaves like
     rank r's list of `bytes`.  With RCCL the payload is packed once into pinned host memory, uploaded asynchronously and
-    gathered HBM to HBM over xGMI; the gathered bytes stay in HBM until somebody reads them (`RankStreams`)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    gathered HBM to HBM over xGMI; the gathered bytes stay in HBM until somebody reads them (`RankStreams`): every result
+    holds world x max_bytes of device memory until it is read (then the host copy replaces it) or dropped.
+    `force`: run the collective path even in a one-rank group (test hook for one-GPU boxes)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return [list(streams)]
     world = dist.get_world_size()
     dev = _comm_device()
@@ -114,9 +123,9 @@ def gather_streams(streams: Sequence[bytes]) -> List[Sequence[bytes]]:
     return out
 
 
-def gather_metrics(values: torch.Tensor) -> torch.Tensor:
+def gather_metrics(values: torch.Tensor, force: bool = False) -> torch.Tensor:
     """values: float64 [n_local, k] (same n_local on every rank) -> [world, n_local, k]."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return values.unsqueeze(0)
     dev = _comm_device()
     v = values.to(dev, torch.float64).contiguous()
@@ -125,14 +134,17 @@ def gather_metrics(values: torch.Tensor) -> torch.Tensor:
     return torch.stack([o.cpu() for o in outs])
 
 
-def max_over_ranks(x: float) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(x: float, force: bool = False) -> float:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(x)
     t = torch.tensor([x], dtype=torch.float64, device=_comm_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+def barrier(force: bool = False):
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

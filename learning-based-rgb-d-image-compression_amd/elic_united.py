@@ -397,6 +397,31 @@ class ELIC_united:
                                             n.value, ctypes.byref(n)), "debug_symbols")
         return sym, idx
 
+    def scale_table_numpy(self) -> np.ndarray:
+        """The Gaussian scale table (float32) the engine indexes with (entropy_models.py:561-568)."""
+        return self._table_slots()[0][1].scale_table.float().contiguous().numpy()
+
+    def eb_medians_numpy(self):
+        """Per-channel medians of the factorised prior(s), in modality order (entropy_models.py:437-440)."""
+        return [h.medians().numpy() for which, h in self._table_slots() if which >= 2]
+
+    def set_debug_floats(self, on: bool):
+        """Keep (y - mean, scale) per symbol of the next compress() (parity bookkeeping; see debug_floats)."""
+        self._ready()
+        check(lib().rgbd_elic_set_debug_floats(self._h, 1 if on else 0), "set_debug_floats")
+
+    def debug_floats(self, modality: int):
+        """(x, scale) float32 arrays in stream order: what the encoder rounded / indexed for every symbol of the last
+        compress() (after set_debug_floats(True))."""
+        n = ctypes.c_int64(0)
+        check(lib().rgbd_elic_debug_floats(self._h, modality, None, None, 0, ctypes.byref(n)), "debug_floats")
+        x = np.empty(n.value, dtype=np.float32)
+        sc = np.empty(n.value, dtype=np.float32)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        check(lib().rgbd_elic_debug_floats(self._h, modality, x.ctypes.data_as(f32p), sc.ctypes.data_as(f32p), n.value,
+                                           ctypes.byref(n)), "debug_floats")
+        return x, sc
+
     def clone_shared(self):
         """Another engine instance on the same GPU that borrows this one's device weights and tables (own workspace and
         stream).  The clone keeps a reference to its parent so the weights outlive it."""

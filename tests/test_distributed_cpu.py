@@ -99,3 +99,52 @@ def test_bench_rank_count_mismatch_is_an_error():
     # a failing rank takes the whole job down with a non-zero exit code
     p = _bench("--gpus", "2", "--rehearse", "--steps", "1", env={"RGBD_REHEARSE_FAIL_RANK": "1"})
     assert p.returncode != 0
+
+
+def test_launcher_counts_gpus_from_sysfs_without_torch(tmp_path, monkeypatch):
+    """bench.visible_gpu_count: KFD topology nodes with SIMDs whose render node this process may open, narrowed by
+    *_VISIBLE_DEVICES -- what the launcher parent uses instead of torch.cuda.device_count()."""
+    import importlib.util
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    base, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor, present) in enumerate([(0, 0, False), (1024, 128, True), (1024, 129, True), (1024, 130, False)]):
+        (base / str(i)).mkdir(parents=True)
+        (base / str(i) / "properties").write_text(f"cpu_cores_count {8 if not simd else 0}\nsimd_count {simd}\n"
+                                                  f"drm_render_minor {minor}\n")
+        if present:
+            (dri / f"renderD{minor}").write_text("")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(base), str(dri)) == 2  # node 0 is a CPU, node 3's render node is not ours
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(base), str(dri)) == 1
+    assert bench.visible_gpu_count(str(tmp_path / "missing"), str(dri)) is None
+
+
+@pytest.mark.timeout(200)
+def test_launcher_parent_stays_off_torch():
+    """The parent of a self-spawned job must not have loaded torch / HIP when it starts its ranks (bench.py asserts it):
+    run the launcher with an import hook that fails the process if the parent imports torch."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = ("import sys, runpy\n"
+            "class Block:\n"
+            "    def find_spec(self, name, path=None, target=None):\n"
+            "        if name == 'torch':\n"
+            "            raise ImportError('launcher parent imported torch')\n"
+            "sys.meta_path.insert(0, Block())\n"
+            f"sys.argv = [{os.path.join(ROOT, 'bench.py')!r}, '--gpus', '2', '--steps', '1', '--rehearse']\n"
+            f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert any(ln.startswith("{") for ln in p.stdout.splitlines())
