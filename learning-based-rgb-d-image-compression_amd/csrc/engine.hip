@@ -422,6 +422,7 @@ int g_force_splitk = 0;  // test hook (rgbd_debug_force_splitk)
 int g_bench_streams = 1;  // rgbd_debug_bench_streams: rgbd_conv_bench issues every launch on this many streams at once
 const bool g_kpack = !getenv("RGBD_NO_KPACK");  // A/B switch: first analysis conv over a K-packed input (1x1, K = 80 / 32)
 int g_subpix = getenv("RGBD_NO_SUBPIX") ? 0 : 1;  // rgbd_debug_force_subpix: sub-pixel form of the last transposed conv
+int g_fail_captures = 0;  // rgbd_debug_fail_captures: the next n graph captures count as lost (test hook)
 int g_pair = getenv("RGBD_NO_PAIR") ? 0 : 1;  // rgbd_debug_force_pair: RGB / depth layer pairs as one grouped launch
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
 const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
@@ -474,6 +475,7 @@ struct rgbd_elic {
     bool finalized = false;
 
     Arena arena;
+    unsigned* tile_ctr = nullptr;  // split-K tile counters of this instance's launches (ConvArgs::tile_ctr), zero between launches
     hipStream_t s = nullptr;
     int rc = 0;
     std::map<std::string, Act> named;  // intermediates of the last call (live in the arena)
@@ -518,10 +520,16 @@ struct rgbd_elic {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         int seen = 0;                       // completed calls of this shape (the first one runs eagerly)
+        int capture_fails = 0;              // failed capture attempts; kMaxCaptureFails of them retire the entry to eager launches
+        uint64_t last_use = 0;              // graph_clock at the entry's last call (least-recently-used eviction)
         std::map<std::string, Act> named;   // debug tensors of the body (same workspace addresses on every replay)
         Act out[2];                         // body outputs the epilogue reads (x_hat or y_hat per modality)
     };
     std::map<std::string, GraphEntry> graphs;
+    static constexpr int kMaxCaptureFails = 3;
+    static constexpr size_t kMaxGraphs = 24;  // instantiated graphs kept per engine instance (~750 nodes each)
+    uint64_t graph_clock = 0;
+    bool capture_failed = false;   // the call in progress lost its capture (body_end / a launch inside the capture failed)
     GraphEntry* cur_ge = nullptr;  // entry of the call in progress (nullptr: graphs off for this call)
     int body_mode = 0;             // 0 eager, 1 capturing, 2 replaying
     const bool use_graphs = getenv("RGBD_NO_GRAPH") == nullptr;
@@ -547,6 +555,7 @@ struct rgbd_elic {
                 HIP_TRY(hipEventRecord(null_ev, nullptr));
                 HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
             } else {
+                HangWatch w("hipStreamSynchronize(NULL) in use_stream", 30);
                 HIP_TRY(hipStreamSynchronize(nullptr));  // order behind the NULL stream on the host instead
             }
             s = own_s;
@@ -567,10 +576,7 @@ struct rgbd_elic {
 
     void graphs_invalidate()
     {
-        for (auto& kv : graphs) {
-            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-            if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-        }
+        for (auto& kv : graphs) drop_entry(kv.second);
         graphs.clear();
         cur_ge = nullptr;
     }
@@ -580,7 +586,40 @@ struct rgbd_elic {
         // (the stream is part of the key: a graph is replayed on the stream it was captured on)
         char sk[32];
         snprintf(sk, sizeof(sk), "|%p", (void*)s);
-        return &graphs[key + "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch) + sk];
+        const std::string suffix = "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch) + sk;
+        const std::string full = key + suffix;
+        auto it = graphs.find(full);
+        if (it == graphs.end()) {
+            // A dataset with many image sizes must not grow this cache without bound: entries of other tile modes / debug
+            // epochs can never be replayed again and go first, then the least recently used ones.
+            for (auto e = graphs.begin(); e != graphs.end();) {
+                const std::string& k = e->first;
+                const bool stale = k.size() < suffix.size() || k.compare(k.size() - suffix.size(), suffix.size(), suffix) != 0;
+                if (stale) {
+                    drop_entry(e->second);
+                    e = graphs.erase(e);
+                } else {
+                    ++e;
+                }
+            }
+            while (graphs.size() >= kMaxGraphs) {
+                auto lru = graphs.begin();
+                for (auto e = graphs.begin(); e != graphs.end(); ++e)
+                    if (e->second.last_use < lru->second.last_use) lru = e;
+                drop_entry(lru->second);
+                graphs.erase(lru);
+            }
+            it = graphs.emplace(full, GraphEntry()).first;
+        }
+        it->second.last_use = ++graph_clock;
+        return &it->second;
+    }
+    static void drop_entry(GraphEntry& ge)
+    {
+        if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        ge.exec = nullptr;
+        ge.graph = nullptr;
     }
     // Start of the capturable part of a call.  Returns true when the caller has to run the body code (eagerly, into a
     // capture, or as a sizing pass), false when a cached graph stands in for it.
@@ -592,7 +631,7 @@ struct rgbd_elic {
             body_mode = 2;
             return false;
         }
-        if (cur_ge->seen < 1) return true;
+        if (cur_ge->seen < 1 || cur_ge->capture_fails >= kMaxCaptureFails) return true;  // first call / retired entry: eager
         // relaxed: other host threads (other engine instances) keep launching while this one captures; the operations
         // that must not overlap a capture are fenced off with g_capture_mu
         g_capture_mu.lock_shared();
@@ -611,17 +650,27 @@ struct rgbd_elic {
         if (dry()) return RGBD_OK;
         if (mode == 1) {
             hipGraph_t gr = nullptr;
-            const hipError_t e = hipStreamEndCapture(s, &gr);
+            hipError_t e = hipStreamEndCapture(s, &gr);
             g_capture_mu.unlock_shared();
+            if (g_fail_captures > 0) {  // test hook (rgbd_debug_fail_captures): this capture counts as lost
+                --g_fail_captures;
+                e = hipErrorStreamCaptureInvalidated;
+            }
             if (e != hipSuccess || rc) {
+                // Nothing of the body has run (it was being recorded, not executed): the caller re-runs the call eagerly
+                // (run_sized).  A capture is lost when anything the runtime forbids during a capture happens on this
+                // stream's behalf -- another library's device-wide call, an allocator trim -- not through any fault of
+                // the call itself.
                 if (gr) (void)hipGraphDestroy(gr);
                 (void)hipGetLastError();
+                capture_failed = true;
                 return rc ? rc : RGBD_EHIP;
             }
             hipGraphExec_t ex = nullptr;
             if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess) {
                 (void)hipGraphDestroy(gr);
                 (void)hipGetLastError();
+                capture_failed = true;
                 return RGBD_EHIP;
             }
             cur_ge->graph = gr;
@@ -639,6 +688,7 @@ struct rgbd_elic {
     void body_abort()
     {
         if (body_mode == 1) {
+            capture_failed = true;  // an error inside a capture: the eager re-run tells a lost capture from a real fault
             hipGraph_t gr = nullptr;
             (void)hipStreamEndCapture(s, &gr);
             g_capture_mu.unlock_shared();
@@ -647,6 +697,18 @@ struct rgbd_elic {
         }
         body_mode = 0;
     }
+    // Is this engine's stream recording into a graph right now?  (Its own body, or -- when two users were handed the same
+    // HIP stream, e.g. past torch's pool of 32 side streams -- somebody else's.)  The NULL stream never captures.
+    bool capturing() const
+    {
+        if (!s) return false;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return st != hipStreamCaptureStatusNone;
+    }
     int wait_stream()
     {
         if (!blocking_wait) {
@@ -654,7 +716,9 @@ struct rgbd_elic {
             return RGBD_OK;
         }
         if (!done_ev) HIP_TRY(hipEventCreateWithFlags(&done_ev, hipEventBlockingSync | hipEventDisableTiming));
+        if (capturing()) return RGBD_ESTATE;  // an event recorded inside a capture never signals: refuse by construction
         HIP_TRY(hipEventRecord(done_ev, s));
+        HangWatch w("hipEventSynchronize(done_ev) in wait_stream", 30);
         HIP_TRY(hipEventSynchronize(done_ev));
         return RGBD_OK;
     }
@@ -662,6 +726,7 @@ struct rgbd_elic {
     int pin_take(size_t bytes, void** out)
     {
         if (pin_busy) {
+            HangWatch w("hipEventSynchronize(pin_ev) in pin_take", 30);
             HIP_TRY(hipEventSynchronize(pin_ev));
             pin_busy = false;
         }
@@ -680,6 +745,7 @@ struct rgbd_elic {
     int pin_release()
     {
         if (!pin_ev) HIP_TRY(hipEventCreateWithFlags(&pin_ev, hipEventBlockingSync | hipEventDisableTiming));
+        if (capturing()) return RGBD_ESTATE;  // (see wait_stream)
         HIP_TRY(hipEventRecord(pin_ev, s));
         pin_busy = true;
         return RGBD_OK;
@@ -907,6 +973,7 @@ struct rgbd_elic {
         ConvArgs a = p.a;
         const size_t pmark = arena.top;
         if (p.partial_bytes) a.partial = (float*)arena.take(p.partial_bytes);
+        if (p.partial_bytes && a.splitk > 1) a.tile_ctr = tile_ctr;  // the last workgroup of a tile reduces it in the kernel
         if (q) {
             const ConvArgs& b = q->a;
             a.groups = 2;
@@ -2247,6 +2314,7 @@ int rgbd_elic::ensure_arena(size_t bytes)
     graphs_invalidate();  // cached graphs have the old workspace addresses baked in
     std::unique_lock<std::shared_mutex> lk(g_capture_mu);  // hipFree synchronises the device: not while anyone captures
     if (arena.base) {
+        HangWatch w("hipStreamSynchronize / hipFree in ensure_arena", 30);
         HIP_TRY(hipStreamSynchronize(s));  // only this instance's stream ever touches this workspace
         HIP_TRY(hipFree(arena.base));
         arena.base = nullptr;
@@ -2255,6 +2323,10 @@ int rgbd_elic::ensure_arena(size_t bytes)
     bytes += bytes / 16;
     HIP_TRY(hipMalloc((void**)&arena.base, bytes));
     arena.cap = bytes;
+    if (!tile_ctr) {
+        HIP_TRY(hipMalloc((void**)&tile_ctr, sizeof(unsigned) * CONV_TILE_CTRS));
+        HIP_TRY(hipMemset(tile_ctr, 0, sizeof(unsigned) * CONV_TILE_CTRS));
+    }
     return RGBD_OK;
 }
 
@@ -2951,8 +3023,19 @@ static int run_sized(rgbd_elic* m, const std::string& key, F&& run)
         ge = m->graph_entry(key);
     }
     m->cur_ge = ge;
-    const int r = run();
+    m->capture_failed = false;
+    int r = run();
     if (r) m->body_abort();
+    if (r && m->capture_failed) {
+        // The capture of this call was lost before anything of its body ran.  Re-run it eagerly (the prologue is
+        // idempotent); the entry tries again on its next call and retires to eager launches after kMaxCaptureFails.
+        if (ge) ++ge->capture_fails;
+        m->cur_ge = nullptr;
+        m->capture_failed = false;
+        r = run();
+        if (r) m->body_abort();
+        if (!r && ge) ++ge->seen;
+    }
     m->cur_ge = nullptr;
     return r;
 }
@@ -3292,6 +3375,22 @@ int rgbd_debug_force_fuse(int32_t mode)
 }
 
 // 0: per-phase form, 1: sub-pixel form inside the codec (default), 2: also in rgbd_conv2d_nchw (tests)
+int rgbd_debug_force_splitk_reducer(int32_t on)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
+    g_splitk_reducer = on ? 1 : 0;
+    ++g_cfg_epoch;
+    return RGBD_OK;
+}
+
+int rgbd_debug_fail_captures(int32_t n)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
+    if (n < 0) return RGBD_EINVAL;
+    g_fail_captures = n;
+    return RGBD_OK;
+}
+
 int rgbd_debug_force_pair(int32_t mode)
 {
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
@@ -3566,6 +3665,7 @@ void rgbd_elic_destroy(rgbd_elic* m)
         HangWatch w("hipFree(arena) in rgbd_elic_destroy", 20);
         if (m->arena.base) (void)hipFree(m->arena.base);
     }
+    if (m->tile_ctr) (void)hipFree(m->tile_ctr);
     if (dbg) fprintf(stderr, "[destroy %p] arena freed\n", (void*)m);
     if (m->pin) (void)hipHostFree(m->pin);
     if (m->res_pin) (void)hipHostFree(m->res_pin);

@@ -6,6 +6,7 @@ networks) that occupies a handful of CUs, while the transforms want the whole ch
 concurrently from W host threads: one group's serial coder phases overlap another group's convolutions.  Results are
 identical to coding each group alone (the kernels are batch-invariant); only the wall clock changes.
 """
+import os
 import threading
 from typing import List
 
@@ -23,7 +24,6 @@ class CodecPool:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.nets: List[ELIC_united] = []
         self.streams = []
-        import os
 
         # torch hands out side streams from a pool of 32 per device: a 33rd instance would share its HIP stream with the
         # first, and one instance's graph capture would then swallow the other's work ("operation not permitted on an event
@@ -34,11 +34,15 @@ class CodecPool:
         # Host threads that wait for this GPU sleep instead of spinning (hipDeviceScheduleBlockingSync): a pool keeps W
         # threads waiting on W streams.  Measured on c3 with 16 instances and HIP-graph launches: 15.1 -> 1.2 busy host
         # cores per rank at the same throughput (tools/host_cost.sh); RGBD_BLOCKING_SYNC=0 restores the spinning default.
+        # The wait policy is a DEVICE flag of this process (hipSetDeviceFlags): it stays in force for every later wait on this
+        # GPU, also outside the pool (a B = 1 latency pass in the same process runs under it: ~1 of 190 ms), until close().
+        self._blocking_sync = False
         if workers > 1 and os.environ.get("RGBD_BLOCKING_SYNC", "1") != "0":
             from ._lib import check, lib
 
             torch.cuda.set_device(self.device)
             check(lib().rgbd_set_blocking_sync(1), "set_blocking_sync")
+            self._blocking_sync = True
         for i in range(workers):
             if i == 0:
                 net = model_cls(config=config, channel=4).eval()  # ELIC_united or its Swin variant STF_united
@@ -56,6 +60,16 @@ class CodecPool:
     @property
     def workers(self):
         return len(self.nets)
+
+    def close(self):
+        """Drop the engine instances and give the device back its default (spinning) wait policy."""
+        self.nets, self.streams = [], []
+        if self._blocking_sync:
+            from ._lib import check, lib
+
+            torch.cuda.set_device(self.device)
+            check(lib().rgbd_set_blocking_sync(0), "set_blocking_sync")
+            self._blocking_sync = False
 
     def _split(self, B):
         w = min(self.workers, B)
@@ -114,12 +128,13 @@ class CodecPool:
         ceil(K / W) rounds and a last round with few workers leaves the chip idle: pick W so that the rounds are full
         (`balanced_workers`).  Breaking the lock-step with staggered starts or a cap on concurrent compress() calls was
         measured (tools/pool_sched_probe.py, c3, K = 20) and gains nothing: fewer instances in their transforms at a
-        time lower the convolution throughput by as much as the overlap wins."""
+        time lower the convolution throughput by as much as the overlap wins.  Round 3 tried two cohorts half a phase
+        apart (the second half of the workers started 150 - 450 ms late, so that one cohort's coder phases fall into the
+        other's transforms while each cohort keeps its lock-step): 19.8 / 20.0 / 18.5 / 17.6 Mpx/s against 20.4 without."""
         n = len(batches)
         torch.cuda.current_stream().synchronize()
         W = min(self.workers, n)
         nxt, lock = [W], threading.Lock()
-
         def fn(i):
             outs = []
             k = i  # worker i starts with batch i (so W batches touch every instance once), then takes what is next

@@ -130,3 +130,108 @@ def test_stf_replay_and_varying_shapes():
                     assert torch.equal(got[2], ref[shp][2]) and torch.equal(got[3], ref[shp][3]), (rnd, shp)
         assert m.graph_count() >= 4
     torch.cuda.synchronize()
+
+
+def test_lost_capture_reruns_eagerly_and_retires_after_three(net):
+    """a capture that the runtime invalidates (another library's device-wide call during it) used to fail the
+    call.  Now the call re-runs eagerly with the same result, the shape tries to capture again on its next call, and after
+    three lost captures it keeps launching eagerly (rgbd_debug_fail_captures simulates the loss at EndCapture)."""
+    from rgbd_amd._lib import check, lib
+
+    a = _pair(1, 128, 256, 61)
+    net.per_image_streams = True
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            ref = _round(net, *a)                       # eager: first call of the shape
+            g0 = net.graph_count()
+            check(lib().rgbd_debug_fail_captures(2), "fail_captures")  # compress's and decompress's capture of call 2
+            lost = _round(net, *a)
+            assert net.graph_count() == g0              # nothing was cached ...
+            assert lost[0]["r_strings"] == ref[0]["r_strings"] and torch.equal(lost[1], ref[1]) and torch.equal(lost[2], ref[2])
+            cap = _round(net, *a)                       # ... the next call captures
+            assert net.graph_count() == g0 + 2
+            rep = _round(net, *a)
+            for o in (cap, rep):
+                assert o[0]["r_strings"] == ref[0]["r_strings"] and o[0]["d_strings"] == ref[0]["d_strings"]
+                assert torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2])
+            # another shape loses three captures in a row (per entry): it retires to eager launches for good
+            b = _pair(1, 128, 320, 62)
+            ref_b = _round(net, *b)
+            g1 = net.graph_count()
+            check(lib().rgbd_debug_fail_captures(6), "fail_captures")
+            for _ in range(3):
+                o = _round(net, *b)
+                assert o[0]["r_strings"] == ref_b[0]["r_strings"] and torch.equal(o[1], ref_b[1])
+            for _ in range(2):                          # no capture is attempted any more: the hook stays unspent
+                o = _round(net, *b)
+                assert o[0]["d_strings"] == ref_b[0]["d_strings"] and torch.equal(o[2], ref_b[2])
+            assert net.graph_count() == g1
+        torch.cuda.synchronize()
+    finally:
+        check(lib().rgbd_debug_fail_captures(0), "fail_captures")
+        net.per_image_streams = False
+
+
+def test_graph_cache_is_bounded(net):
+    """every distinct image shape used to add two instantiated graphs for the life of the engine.  The cache
+    keeps at most 24 (least recently used go first; a round-robin over more shapes than fit simply keeps launching eagerly)
+    and drops entries of other tile modes when a new one is needed."""
+    shapes = [(1, 128, 128 + 64 * k, 70 + k) for k in range(14)]
+    first = {}
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for rnd in range(3):  # 28 entries wanted, 24 kept
+            for shp in shapes:
+                o = _round(net, *_pair(*shp))
+                if rnd == 0:
+                    first[shp] = o
+                else:
+                    assert o[0]["r_strings"] == first[shp][0]["r_strings"] and torch.equal(o[1], first[shp][1]), (rnd, shp)
+            assert net.graph_count() <= 24
+        for rnd in range(3):  # a working set that fits is cached and replayed
+            for shp in shapes[:5]:
+                o = _round(net, *_pair(*shp))
+                assert o[0]["r_strings"] == first[shp][0]["r_strings"] and torch.equal(o[2], first[shp][2]), (rnd, shp)
+        assert 10 <= net.graph_count() <= 24
+        net.set_tile_mode("throughput")
+        for _ in range(3):
+            _round(net, *_pair(*shapes[0]))
+        assert net.graph_count() == 2   # the latency-mode entries could never be replayed again: gone
+        net.set_tile_mode("latency")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_null_stream_caller_next_to_replaying_side_streams_then_destroy(synth_sd):
+    """The sequence of the round-2 hang report: device-wide blocking sync, one engine driven from the
+    caller's NULL stream, shared-weight clones replaying HIP graphs on side streams, then the engines are destroyed one
+    after the other (hipFree = implicit device synchronise) while the others stay alive.  Must finish; a wait inside the
+    runtime fails the test through its timeout."""
+    import gc
+
+    import rgbd_amd
+
+    require_gpu()
+    pool = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=3, device="cuda", per_image_streams=True)
+    lone = pool.nets[0].clone_shared()   # a NULL-stream caller of its own
+    lone.per_image_streams = True
+    r, d = _pair(3, 128, 192, 81)
+    want = None
+    for rnd in range(4):                 # eager, capture, replay, replay on the side streams
+        outs, xr, xd = pool.roundtrip(r, d)
+        one = lone.compress(r, d)        # NULL stream, eager launches
+        rec = lone.decompress(one["r_strings"], one["d_strings"], one["shape"])
+        got = [s for o in outs for s in o["r_strings"][0]]
+        want = want or got
+        assert got == want == list(one["r_strings"][0]) and torch.equal(xr, rec["x_hat"]["r"])
+    assert all(n.graph_count() >= 2 for n in pool.nets) and lone.graph_count() == 0
+    nets = list(pool.nets)
+    del pool
+    while nets:                          # destroy a clone, use the survivors, destroy the next ...
+        n = nets.pop()
+        del n
+        gc.collect()
+        one = lone.compress(r, d)
+        assert list(one["r_strings"][0]) == want
+    del lone
+    gc.collect()
+    torch.cuda.synchronize()

@@ -68,6 +68,52 @@ def test_tester_united_on_files(net, tmp_path, monkeypatch):
     assert d16.dtype == np.uint16 and d16.shape == (100, 150)
 
 
+@pytest.mark.parametrize("case", ["a_128x192", "b_100x150", "c_b2_128x128"])
+def test_harness_meets_the_reference_captured_goldens(net, tmp_path, monkeypatch, case):
+    """SURVEY 8(f) rank 1 against the REFERENCE, not against itself: the reference's harness arithmetic was captured by
+    tests/golden/make_golden.py (container bytes written through utils/IOutils.py:30-104 -> sha, bpp = 8 * filesize / (H W),
+    PSNR of the cropped reconstruction; tests/golden/harness.json + model_*.npz).  The HIP path, driven through this
+    package's TesterUnited methods (pad -> compress -> container file -> read back -> decompress -> crop -> metrics), must
+    write the same container bytes and report the same bpp and PSNR on the goldens whose streams are identical."""
+    import hashlib
+    import json
+
+    import rgbd_amd
+    from conftest import GOLDEN, load_golden
+    from rgbd_amd import synth
+    from rgbd_amd.datautils import pad
+    from rgbd_amd.metrics import compute_metrics
+
+    g = load_golden(case)
+    hj = json.load(open(os.path.join(GOLDEN, "harness.json")))["cases"][case]
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    monkeypatch.chdir(tmp_path)
+    args = types.SimpleNamespace(channel=4, debug=False, experiment="gold", dataset=None, model="ELIC_united", quality="2_2",
+                                 checkpoint=None)
+    t = rgbd_amd.TesterUnited(args, rgbd_amd.model_config(), net=net)
+    r, d = synth.synthetic_batch(B, H, W, config_id=int(g["config_id"]))
+    r, d = torch.from_numpy(r), torch.from_numpy(d)
+    rp, dp = pad(r.cuda(), "replicate0"), pad(d.cuda(), "replicate0")
+    assert list(rp.shape[-2:]) == hj["padded"]
+    paths = (str(tmp_path / "depth_bin"), str(tmp_path / "rgb_bin"))  # (rgb stream -> depth_bin: tester_united.py:62-63)
+    net.per_image_streams = False  # the reference's stream format
+    rb, db, _ = t.compress_one_image_united((rp, dp), paths, H, W, "img")
+    raw = [open(os.path.join(p, "img"), "rb").read() for p in paths]
+    if B == 1:
+        assert hashlib.sha256(raw[0]).hexdigest()[:16].encode() == g["r_container_sha"].tobytes()
+        assert hashlib.sha256(raw[1]).hexdigest()[:16].encode() == g["d_container_sha"].tobytes()
+        assert [rb, db] == hj["bpp"]
+    assert g["r_y"].tobytes() in raw[0] and g["d_y"].tobytes() in raw[1]  # the reference's y-streams, byte for byte
+    xr, xd, _ = t.decompress_one_image_united(paths, "img", mode="replicate0")
+    assert tuple(xr.shape[-2:]) == (H, W)
+    pr, _ = compute_metrics(xr.cpu(), r)
+    pd, _ = compute_metrics(xd.cpu(), d)
+    assert abs(pr - hj["psnr"][0]) < 1e-4 and abs(pd - hj["psnr"][1]) < 1e-4, (pr, pd, hj["psnr"])
+    # (MS-SSIM and the cv2 image decode have no reference-held fixture: utils/metrics.py:13 calls a third-party package that
+    #  is not in the image, dataset/testDataset.py:36-61 reads through OpenCV; the harness log line says so and bpp / PSNR are
+    #  the pinned set.)
+
+
 def test_tester_united_images_in_flight(net, tmp_path, monkeypatch):
     """test_model(workers=W): W images in flight on W engine instances write the same files and report the same bpp /
     PSNR as the reference's one-image-at-a-time loop (tester_united.py:48-88)."""

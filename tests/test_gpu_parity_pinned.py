@@ -213,6 +213,8 @@ def _vs_golden(net, gc, name):
                                           part_sizes(net.slice_ch, h, w, B))
     same = out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes()
     assert same == (clean == total)
+    # (before decompress(): it reuses the workspace the encoder's debug tensors live in)
+    flip = {} if (same and z_same) else _first_flip(net, name, gsym, gidx, medians=net.eb_medians_numpy())
     rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
     xr, xd = rec["x_hat"]["r"].cpu()[..., :H, :W], rec["x_hat"]["d"].cpu()[..., :H, :W]
     vals = {"clean_parts_vs_golden": clean, "identical_streams": same, "identical_z": z_same,
@@ -222,8 +224,7 @@ def _vs_golden(net, gc, name):
     if "bpp" in g:
         bpp = [len(eo.container_bytes(H, W, out["shape"], out[k])) * 8.0 / (H * W) for k in ("r_strings", "d_strings")]
         vals["dbpp_r"], vals["dbpp_d"] = abs(bpp[0] - g["bpp"][0]), abs(bpp[1] - g["bpp"][1])
-    if not (same and z_same):
-        vals.update(_first_flip(net, name, gsym, gidx, medians=net.eb_medians_numpy()))
+    vals.update(flip)
     print(name, vals)
     _check(name, **vals)
 
@@ -247,11 +248,11 @@ def test_bicee_vs_reference_golden(net, gc, name):
                                           part_sizes(net.slice_ch, h, w, B))
     same = sr[0] == g["r_y"].tobytes() and sdp[0] == g["d_y"].tobytes()
     assert same == (clean == total)
+    flip = {} if same else _first_flip(net, "bicee_" + name, gsym, gidx)
     yhat_r, yhat_d = net.decompress_united(sr[0], hr, sdp[0], hd)
     vals = {"clean_parts_vs_golden": clean, "identical_streams": same,
             "dlen_r": abs(len(sr[0]) - g["r_y"].shape[0]), "dlen_d": abs(len(sdp[0]) - g["d_y"].shape[0])}
-    if not same:
-        vals.update(_first_flip(net, "bicee_" + name, gsym, gidx))
+    vals.update(flip)
     if same:  # then y_hat is the reference's, up to the float tolerance of the means
         vals["yhat_rel"] = max(float(np.abs(yhat_r.cpu().numpy() - g["yhat_r"]).max() / np.abs(g["yhat_r"]).max()),
                                float(np.abs(yhat_d.cpu().numpy() - g["yhat_d"]).max() / np.abs(g["yhat_d"]).max()))
@@ -297,12 +298,12 @@ def test_elic_single_vs_reference_golden(gc):
     clean, total = golden_parts_identical(gsym, gidx, {0: g["y_stream"].tobytes()}, gc, part_sizes(m.slice_ch, 16, 16),
                                           modalities=1)
     same = out["strings"][0][0] == g["y_stream"].tobytes() and out["strings"][1][0] == g["z0"].tobytes()
+    flip = {} if same else _first_flip(m, "elic_c1_256x256", gsym, gidx, medians=m.eb_medians_numpy(), mods=("r",))
     rec = m.decompress(out["strings"], out["shape"])
     vals = {"clean_parts_vs_golden": clean, "identical_streams": same,
             "dpsnr": abs(eo.psnr(rec["x_hat"].cpu().clamp(0, 1), x) - g["psnr"][0]),
             "dlen": abs(len(out["strings"][0][0]) - g["y_stream"].shape[0])}
-    if not same:
-        vals.update(_first_flip(m, "elic_c1_256x256", gsym, gidx, medians=m.eb_medians_numpy(), mods=("r",)))
+    vals.update(flip)
     print("elic single", vals)
     _check("elic_c1_256x256", **vals)
 
@@ -324,14 +325,14 @@ def test_stf_vs_reference_golden(kat):
                                           part_sizes(m.slice_ch, 16, 16))
     same = out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes()
     z_same = out["r_strings"][1][0] == g["r_z0"].tobytes() and out["d_strings"][1][0] == g["d_z0"].tobytes()
+    flip = {} if (same and z_same) else _first_flip(m, "stf_c5_256x256", gsym, gidx, medians=m.eb_medians_numpy())
     rec = m.decompress(out["r_strings"], out["d_strings"], out["shape"])
     xr, xd = rec["x_hat"]["r"].cpu(), rec["x_hat"]["d"].cpu()
     vals = {"clean_parts_vs_golden": clean, "identical_streams": same, "identical_z": z_same,
             "dpsnr_r": abs(eo.psnr(xr, torch.from_numpy(r)) - g["psnr"][0]),
             "dpsnr_d": abs(eo.psnr(xd, torch.from_numpy(d)) - g["psnr"][1]),
             "dlen_r": abs(len(out["r_strings"][0][0]) - g["r_y"].shape[0])}
-    if not (same and z_same):
-        vals.update(_first_flip(m, "stf_c5_256x256", gsym, gidx, medians=m.eb_medians_numpy()))
+    vals.update(flip)
     print("stf", vals)
     _check("stf_c5_256x256", **vals)
 
