@@ -224,9 +224,6 @@ int rgbd_elic_graph_count(const rgbd_elic* m);
  * them).  The affected calls must still return correct results (they re-run eagerly); an entry that loses three captures
  * keeps launching eagerly. */
 int rgbd_debug_fail_captures(int32_t n);
-/* Split-K convolutions add their partial planes inside the conv kernel (the workgroup that finishes a tile last reduces it,
- * in split order); 1 = use the separate splitk_reduce_kernel launch instead.  Same bits either way. */
-int rgbd_debug_force_splitk_reducer(int32_t on);
 int rgbd_elic_set_profile(rgbd_elic* m, int32_t on);
 int rgbd_elic_profile_read(rgbd_elic* m, double* conv_ms, int64_t* launches, double* flops);
 

@@ -106,10 +106,6 @@ struct ConvArgs {
     float* y3;
     int y3cs;
     int cout3_pad;
-    // split-K second half inside the kernel: one counter per output tile (CONV_TILE_CTRS of them, zero between launches);
-    // the workgroup arriving last adds the partial planes in split order and applies the epilogue.  nullptr: separate
-    // splitk_reduce_kernel launch.
-    unsigned* tile_ctr;
     int groups;   // 0 / 1: one operand set; 2: workgroups [tiles*N, 2*tiles*N) of the work list run the same layer on g1
     ConvPtrs g1;
     TapTable taps;
@@ -117,8 +113,6 @@ struct ConvArgs {
 
 // split factor of a layer: a function of the layer and of the per-image output grid only -- never of the batch size -- so
 // the summation order of every output is the same in the encoder, the decoder and for any batching of the same images
-enum { CONV_TILE_CTRS = 64 * 1024, CONV_ECTR = -1000 };
-extern int g_splitk_reducer;
 extern char g_conv_force[64];
 extern int g_fuse_force, g_fuse_lead_off;  // rgbd_debug_force_fuse (conv_mfma.hip)
 static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_per_image, int nphase)

@@ -641,58 +641,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             }
         }
     }
-    // ---- split-K, second half inside the kernel (ConvArgs::tile_ctr) ----------------------------------------------------
-    // Every split of an output tile has written its raw partial plane above.  The workgroup that arrives LAST at the tile's
-    // counter (agent-scope release / acquire around one atomic) adds the planes in split order -- a fixed order, whoever
-    // arrives last -- applies the epilogue and resets the counter for the next launch.  Same operations in the same order
-    // as splitk_reduce_kernel: same bits, one launch less per split layer.
-    if (a.partial && a.tile_ctr) {
-        int* flag = reinterpret_cast<int*>(smem + tab_f);  // (the tap table is dead by now)
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) {
-            unsigned* ctr = a.tile_ctr + (size_t)phase * gridDim.x + wid;
-            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == (unsigned)a.splitk - 1u;
-            if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        __threadfence();
-        const size_t plane_b = (size_t)a.N * a.OH * a.OW * a.cout_pad * 4u;  // bytes per partial plane
-        const char* pt0 = reinterpret_cast<const char*>(gpartial + img_px * a.cout_pad);
-        for (int ip = 0; ip < MT; ip += EMT) {
-            for (int u0 = 0; u0 < EU; ++u0) {
-                const int f = tid + u0 * 256;
-                const int p = f / S4, c4 = f - p * S4;
-                const int wmc = c4 / (4 * EMT), ii = (c4 / 4) % EMT;
-                const int cb = co0 + (wmc * MT + ip + ii) * 16 + (c4 & 3) * 4;
-                const int gy = ty0 + (p >> tw_log2);
-                const int gx = tx0 + (ck ? 2 * (p & (TW - 1)) + ((gy & 1) ^ (a.ckbd == 1 ? 1 : 0)) : (p & (TW - 1)));
-                if (!(ip + ii < MT && cb < a.cout_store && gy < a.GH && gx < a.GW)) continue;
-                const unsigned pix = (unsigned)((gy * a.OS + oy_off) * a.OW + (gx * a.OS + ox_off));
-                const size_t po = (size_t)((pix * (unsigned)a.cout_pad + cb) * 4u);
-                f32x4 v = *reinterpret_cast<const f32x4*>(pt0 + po);
-                for (int sp = 1; sp < a.splitk; ++sp) v += *reinterpret_cast<const f32x4*>(pt0 + sp * plane_b + po);
-                v += *reinterpret_cast<const f32x4*>(gbias + cb);
-                if (a.res1) v += *reinterpret_cast<const f32x4*>(r1n + (size_t)((pix * (unsigned)a.r1cs + cb) * 4u));
-                if (a.act == ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (a.act == ACT_LEAKY) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * 0.01f;
-                } else if (a.act == ACT_SIGMOID) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sigmoid_f32(v[e]);
-                }
-                if (a.mul) v *= *reinterpret_cast<const f32x4*>(mln + (size_t)((pix * (unsigned)a.mcs + cb) * 4u));
-                if (a.res2) v += *reinterpret_cast<const f32x4*>(r2n + (size_t)((pix * (unsigned)a.r2cs + cb) * 4u));
-                *reinterpret_cast<f32x4*>(yn + (size_t)((pix * (unsigned)a.ycs + cb) * 4u)) = v;
-            }
-        }
-    }
 }
 
 template <int WM, int WN, int MT, int NT, int KC, bool DMA>
@@ -772,7 +720,6 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     }
     dim3 grid((unsigned)(tiles_x * tiles_y * a.N * (a.groups == 2 ? 2 : 1)) * (unsigned)((a.cout_pad + TM - 1) / TM), 1,
               (unsigned)(a.nphase * a.splitk));
-    if (a.tile_ctr && (size_t)grid.x * a.nphase > (size_t)CONV_TILE_CTRS) return CONV_ECTR;  // launch_conv falls back to the reducer
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tw_log2, tiles_x, tiles_y, tps, (int)(buf_bytes / 4));
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
@@ -936,7 +883,6 @@ static bool conv_groups_ok(const ConvArgs& a)
 }
 
 char g_conv_force[64] = {0};  // rgbd_debug_force_tile (tools/tile_sweep.py)
-int g_splitk_reducer = getenv("RGBD_SPLITK_REDUCER") ? 1 : 0;  // A/B switch + rgbd_debug_force_splitk_reducer: separate reduce launch
 
 // ---- measured tile table -------------------------------------------------------------------------------------------
 // tools/tune_tiles.py times every tile shape / stage depth / staging mode for the layer shapes of a workload and writes
@@ -1037,15 +983,12 @@ int launch_conv(const ConvArgs& a_in, hipStream_t s)
                      a.ckbd || a.ycs < 4))
         return RGBD_EINVAL;
     if (a.ckbd && (a.ckbd > 2 || a.ckbd < 0 || a.nphase != 1 || a.IS != 1 || a.OS != 1)) return RGBD_EINVAL;
-    // in-kernel reduction (tile counters): not for GELU layers (their epilogue lives in the reducer only) and not for
-    // sub-pixel / dual-store layers (never split); grids beyond the counter buffer keep the reducer as well
-    if (a.tile_ctr && (!a.partial || a.act == ACT_GELU || a.splitk < 2 || g_splitk_reducer)) a.tile_ctr = nullptr;
-    int rc = launch_conv_main(a, s);
-    if (rc == CONV_ECTR) {  // more output tiles than counters: the separate reduce launch
-        a.tile_ctr = nullptr;
-        rc = launch_conv_main(a, s);
-    }
-    if (rc || !a.partial || a.tile_ctr) return rc;
+    // (Adding the partial planes inside the conv kernel -- the workgroup that finishes a tile last reduces it, found through a
+    //  per-tile counter -- was built in round 3, bit-identical, and measured: 69.2 instead of 60.6 ms of conv per c3 step.
+    //  Every workgroup of a split launch then pays an agent-scope release / acquire pair, i.e. an L2 write-back and
+    //  invalidate across the XCDs, for a reducer launch of a few microseconds.  Not kept)
+    const int rc = launch_conv_main(a, s);
+    if (rc || !a.partial) return rc;
     const size_t total4 = (size_t)a.N * a.OH * a.OW * (a.cout_pad / 4);
     size_t g = ((a.groups == 2 ? 2 : 1) * total4 + 255) / 256;
     if (g > 2048) g = 2048;

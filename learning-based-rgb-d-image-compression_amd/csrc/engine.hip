@@ -475,7 +475,6 @@ struct rgbd_elic {
     bool finalized = false;
 
     Arena arena;
-    unsigned* tile_ctr = nullptr;  // split-K tile counters of this instance's launches (ConvArgs::tile_ctr), zero between launches
     hipStream_t s = nullptr;
     int rc = 0;
     std::map<std::string, Act> named;  // intermediates of the last call (live in the arena)
@@ -536,10 +535,12 @@ struct rgbd_elic {
     const bool blocking_wait = getenv("RGBD_SPIN_WAIT") == nullptr;
     hipEvent_t done_ev = nullptr;  // blocking-sync event: the host thread sleeps instead of spinning on the stream
     // The legacy NULL stream cannot be captured: a caller that passes it runs the eager launch path (same results, no
-    // graph).  Substituting an engine-owned stream for it (ordered behind the NULL stream by an event) was built and
-    // taken out again: with it, a later hipFree -- an implicit device synchronise -- never returned in a process that had
-    // also replayed graphs on torch side streams (tests/test_gpu_harness.py run as a whole; the stage is logged by
-    // RGBD_DEBUG_DESTROY=1).  Throughput users drive their own streams (CodecPool), which do capture.
+    // graph).  Substituting an engine-owned stream for it was built in round 2 and taken out: with it, host waits inside
+    // the runtime stopped returning once a pool had switched the device to blocking sync (DESIGN.md 3.5 has the analysis:
+    // hipFree -> Device::SyncAllStreams -> HostQueue::finish -> "No HW event ... await command completion" ->
+    // Event::awaitCompletion sleeping on a condition variable nobody signals, GPU idle).  RGBD_NULL_OWN_STREAM=1 brings
+    // the old behaviour back to reproduce that report under RGBD_DEBUG_DESTROY=1; nothing else uses it.  Throughput users
+    // drive their own streams (CodecPool), which do capture.
     hipStream_t own_s = nullptr;   // RGBD_NULL_OWN_STREAM=1 only (the configuration of the round-2 hang report)
     hipEvent_t null_ev = nullptr;
     int use_stream(void* stream)
@@ -548,16 +549,11 @@ struct rgbd_elic {
         s = (hipStream_t)stream;
         if (own && !stream) {
             if (!own_s) {
-                HIP_TRY(hipStreamCreateWithFlags(&own_s, getenv("RGBD_DIAG_OWN_BLOCKING") ? hipStreamDefault : hipStreamNonBlocking));
+                HIP_TRY(hipStreamCreateWithFlags(&own_s, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&null_ev, hipEventDisableTiming));
             }
-            if (!getenv("RGBD_DIAG_NO_NULL_EV")) {
-                HIP_TRY(hipEventRecord(null_ev, nullptr));
-                HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
-            } else {
-                HangWatch w("hipStreamSynchronize(NULL) in use_stream", 30);
-                HIP_TRY(hipStreamSynchronize(nullptr));  // order behind the NULL stream on the host instead
-            }
+            HIP_TRY(hipEventRecord(null_ev, nullptr));
+            HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
             s = own_s;
         }
         if (g_dbg_destroy) {
@@ -973,7 +969,6 @@ struct rgbd_elic {
         ConvArgs a = p.a;
         const size_t pmark = arena.top;
         if (p.partial_bytes) a.partial = (float*)arena.take(p.partial_bytes);
-        if (p.partial_bytes && a.splitk > 1) a.tile_ctr = tile_ctr;  // the last workgroup of a tile reduces it in the kernel
         if (q) {
             const ConvArgs& b = q->a;
             a.groups = 2;
@@ -2323,10 +2318,7 @@ int rgbd_elic::ensure_arena(size_t bytes)
     bytes += bytes / 16;
     HIP_TRY(hipMalloc((void**)&arena.base, bytes));
     arena.cap = bytes;
-    if (!tile_ctr) {
-        HIP_TRY(hipMalloc((void**)&tile_ctr, sizeof(unsigned) * CONV_TILE_CTRS));
-        HIP_TRY(hipMemset(tile_ctr, 0, sizeof(unsigned) * CONV_TILE_CTRS));
-    }
+
     return RGBD_OK;
 }
 
@@ -3375,14 +3367,6 @@ int rgbd_debug_force_fuse(int32_t mode)
 }
 
 // 0: per-phase form, 1: sub-pixel form inside the codec (default), 2: also in rgbd_conv2d_nchw (tests)
-int rgbd_debug_force_splitk_reducer(int32_t on)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
-    g_splitk_reducer = on ? 1 : 0;
-    ++g_cfg_epoch;
-    return RGBD_OK;
-}
-
 int rgbd_debug_fail_captures(int32_t n)
 {
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
@@ -3648,13 +3632,7 @@ void rgbd_elic_destroy(rgbd_elic* m)
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m) return;
     if (dbg) fprintf(stderr, "[destroy %p] locked, graphs %zu\n", (void*)m, m->graphs.size());
-    if (getenv("RGBD_DIAG_SYNC_BEFORE")) {
-        HangWatch w("hipDeviceSynchronize() before the graphs are destroyed", 20);
-        (void)hipDeviceSynchronize();
-        if (dbg) fprintf(stderr, "[destroy %p] device synchronised\n", (void*)m);
-    }
     // weights, tables and the scale table belong to shared generations (DevGen) that go when their last user does
-    if (getenv("RGBD_DIAG_KEEP_GRAPHS")) m->graphs.clear();  // (leaks them)
     m->graphs_invalidate();
     if (dbg) fprintf(stderr, "[destroy %p] graphs gone\n", (void*)m);
     if (dbg) {
@@ -3665,7 +3643,6 @@ void rgbd_elic_destroy(rgbd_elic* m)
         HangWatch w("hipFree(arena) in rgbd_elic_destroy", 20);
         if (m->arena.base) (void)hipFree(m->arena.base);
     }
-    if (m->tile_ctr) (void)hipFree(m->tile_ctr);
     if (dbg) fprintf(stderr, "[destroy %p] arena freed\n", (void*)m);
     if (m->pin) (void)hipHostFree(m->pin);
     if (m->res_pin) (void)hipHostFree(m->res_pin);

@@ -135,6 +135,7 @@ class CodecPool:
         torch.cuda.current_stream().synchronize()
         W = min(self.workers, n)
         nxt, lock = [W], threading.Lock()
+
         def fn(i):
             outs = []
             k = i  # worker i starts with batch i (so W batches touch every instance once), then takes what is next

@@ -81,29 +81,3 @@ def test_grouped_launches_eval_forward(net):
         check(lib().rgbd_debug_force_pair(1), "force_pair")
     assert torch.equal(a["x_hat"]["r"], b["x_hat"]["r"]) and torch.equal(a["x_hat"]["d"], b["x_hat"]["d"])
     assert torch.equal(a["r_likelihoods"]["y"], b["r_likelihoods"]["y"]) and torch.equal(a["d_likelihoods"]["z"], b["d_likelihoods"]["z"])
-
-
-@pytest.mark.parametrize("B,H,W,cid", [(1, 128, 192, 35), (2, 256, 256, 36), (1, 512, 640, 37)])
-def test_inkernel_splitk_reduction_same_bits(net, B, H, W, cid):
-    """Split-K layers (entropy-parameter / channel-context / local-context nets, hyper synthesis) add their partial planes
-    inside the conv kernel: the workgroup that finishes a tile last reduces it in split order and applies the epilogue.
-    Against the separate splitk_reduce_kernel launch (rgbd_debug_force_splitk_reducer(1)): same streams, same pixels; twice
-    in a row, so that a counter left non-zero by the first call would show in the second."""
-    from rgbd_amd import synth
-    from rgbd_amd._lib import check, lib
-
-    r, d = synth.synthetic_batch(B, H, W, config_id=cid)
-    rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
-    net.per_image_streams = True
-    try:
-        check(lib().rgbd_debug_force_splitk_reducer(1), "force_splitk_reducer")
-        ref = _roundtrip(net, rgb, depth)
-        check(lib().rgbd_debug_force_splitk_reducer(0), "force_splitk_reducer")
-        for _ in range(2):
-            got = _roundtrip(net, rgb, depth)
-            assert got[0]["r_strings"] == ref[0]["r_strings"] and got[0]["d_strings"] == ref[0]["d_strings"]
-            assert np.array_equal(got[1][0], ref[1][0]) and np.array_equal(got[1][1], ref[1][1])
-            assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
-    finally:
-        check(lib().rgbd_debug_force_splitk_reducer(0), "force_splitk_reducer")
-        net.per_image_streams = False
