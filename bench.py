@@ -407,7 +407,7 @@ def main():
                   "ms_per_step": round(e2 / args.steps * 1e3, 3), "images_per_gpu": B2, "image": [H2, W2]}
 
     traffic = None
-    for rnd in ("r02", "r01"):  # HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+    for rnd in ("r03", "r02", "r01"):  # HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
             name = {"c2_8x256x256": f"{rnd}_pmc_traffic.json", "c3_4x480x640": f"{rnd}_c3_pmc_traffic.json"}[args.workload]
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -462,7 +462,7 @@ def main():
                                       "conv_ms_per_step": round(prof_lat["conv_ms"] / 2, 3), "conv_tiles": "latency",
                                       "note": "HIP events around every conv launch on its stream, single engine instance, "
                                               "no concurrent kernels, separate pass after the timed region, latency tiles "
-                                              "(what a lone instance runs); profiles/r02_bench_w1_summary.txt"},
+                                              "(what a lone instance runs); profiles/r03_bench_w1_summary.txt"},
                          "isolated_timed_tiles": {"achieved": round(iso_tp_tflops, 3),
                                                   "frac": round(iso_tp_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                                                   "conv_ms_per_step": round(prof1["conv_ms"] / 2, 3), "conv_tiles": tile_mode,

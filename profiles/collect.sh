@@ -5,9 +5,9 @@
 #   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)                              -> <tag>_c3_pmc_*.{csv,json}
 #   4. PMC pass for MFMA utilisation (own run, kernel trace only for the durations)  -> <tag>_mfma_by_kernel.csv
 # Counter passes run the eager launch path (RGBD_NO_GRAPH=1): every dispatch is then an ordinary kernel launch.
-# Usage: bash profiles/collect.sh r02
+# Usage: bash profiles/collect.sh r03
 set -e -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 bench_args=${BENCH_ARGS:---steps 20 --warmup 5}  # the command line the round-end driver uses (BENCH_r01.json)
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
