@@ -147,6 +147,10 @@ int rgbd_elic_compress_single(rgbd_elic* m, const float* x_dev, int32_t B, int32
 int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int64_t* y_len, int32_t n_y,
                                 const uint8_t* const* z, const int64_t* z_len, int32_t B, int32_t zh, int32_t zw,
                                 float* x_dev, void* stream);
+/* Eval-mode forward() of the single-modal model (models/elic.py:60-161 with config quant = "ste"): x_hat [B,in_ch,H,W]
+ * (not clamped), likelihoods of y [B,M,H/16,W/16] and of z [B,N,H/64,W/64] ("y_likelihoods" / "z_likelihoods"). */
+int rgbd_elic_forward_single(rgbd_elic* m, const float* x_dev, int32_t B, int32_t H, int32_t W, float* xhat_dev, float* lik_y,
+                             float* lik_z, void* stream);
 
 /*
  * STF_united (BASELINE config 5): replaces models/stf_united.py: SymmetricalTransFormerUnited :605-678 with

@@ -2282,6 +2282,7 @@ struct rgbd_elic {
         }
     }
     int run_compress1(const float* x_dev, int B, int H, int W, int per_image);
+    int run_forward1(const float* x_dev, int B, int H, int W, float* xhat_dev, float* ly, float* lz);
     int run_decompress1(const uint8_t* const* ys, const int64_t* ylen, int n_y, const uint8_t* const* zs, const int64_t* zlen,
                         int B, int zh, int zw, float* x_out);
 
@@ -2788,6 +2789,57 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     }
     int r = launch_nhwc_to_nchw_clamp(out0.p, B, 3, H, W, out0.cs, xr_dev, 1, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(out1.p, B, 1, H, W, out1.cs, xd_dev, 1, s);
+    return r;
+}
+
+// ---- single-modal ELIC, eval-mode forward() (models/elic.py:60-161, quant = "ste"): y_hat = round(y - mean) + mean slice
+// by slice through the same two-part checkerboard loop as compress(), Gaussian / factorised likelihoods instead of symbols
+int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat_dev, float* ly, float* lz)
+{
+    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    named.clear();
+    pre_leads.clear();
+    arena.top = 0;
+    rc = 0;
+    Act x = alloc(B, H, W, in_ch);
+    if (!dry()) {
+        const int r = launch_nchw_to_nhwc16(x_dev, B, in_ch, H, W, x.p, x.cs, s);
+        if (r) return r;
+    }
+    Act y = alloc(B, h, w, M);
+    {
+        const size_t mark = arena.top;
+        copy_ch(g_a1(x), y);
+        arena.top = mark;
+    }
+    Act z = h_a1(y);
+    Act zhat = alloc(B, zh, zw, N), zlik = alloc(B, zh, zw, N);
+    if (!dry() && !rc) {
+        float* md = dense_of("entropy_bottleneck.medians");
+        float* prm = dense_of("entropy_bottleneck.cumulative");
+        if (md && prm) {
+            const int r = launch_eb_forward(z.p, z.cs, B, zh, zw, N, md, prm, zhat.p, zlik.p, s);
+            if (r) fail(r);
+        }
+    }
+    Act hyper = h_s1(zhat);
+    Act yhat = alloc(B, h, w, M);
+    Coding cd;
+    cd.estimate = true;
+    cd.lik[0] = alloc(B, h, w, M);
+    bicee1(cd, &y, hyper, yhat);
+    named["y"] = y;
+    named["z"] = z;
+    named["zhat"] = zhat;
+    named["hyper"] = hyper;
+    named["yhat"] = yhat;
+    Act xh = g_s1(yhat);
+    if (rc) return rc;
+    if (dry()) return RGBD_OK;
+    int r = launch_nhwc_to_nchw_clamp(xh.p, B, in_ch, H, W, xh.cs, xhat_dev, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(cd.lik[0].p, B, M, h, w, cd.lik[0].cs, ly, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(zlik.p, B, N, zh, zw, zlik.cs, lz, 0, s);
+    if (!r) r = wait_stream();
     return r;
 }
 
@@ -3580,6 +3632,24 @@ int rgbd_elic_compress_single(rgbd_elic* m, const float* x_dev, int32_t B, int32
     r = m->run_compress1(x_dev, B, H, W, per_image);
     if (m->profile) m->profile_collect();
     return r;
+}
+
+int rgbd_elic_forward_single(rgbd_elic* m, const float* x_dev, int32_t B, int32_t H, int32_t W, float* xhat_dev, float* lik_y,
+                             float* lik_z, void* stream)
+{
+    int r = check_ready(m);
+    if (r) return r;
+    if (m->variant != 1 || !x_dev || !xhat_dev || !lik_y || !lik_z || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64)
+        return RGBD_EINVAL;
+    if (const int ur = m->use_stream(stream)) return ur;
+    m->arena.dry = true;
+    m->arena.top = m->arena.peak = 0;
+    r = m->run_forward1(x_dev, B, H, W, xhat_dev, lik_y, lik_z);
+    m->arena.dry = false;
+    if (r) return r;
+    r = m->ensure_arena(m->arena.peak);
+    if (r) return r;
+    return m->run_forward1(x_dev, B, H, W, xhat_dev, lik_y, lik_z);
 }
 
 int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int64_t* y_len, int32_t n_y,

@@ -1046,6 +1046,13 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
                     "s_sub_u32 %[t0], %[t0], 1\n"
                     "73:\n"
+                    // Straight-line common case (round 3): the state update, the count nibble and -- when the state is large
+                    // enough that none of the first nn - 1 payload steps can drop it below 2^31 (x >= 2^(27 + 4 nn): three
+                    // escapes in four) -- all payload nibbles at once, with the three possible renormalisations done by
+                    // selects instead of branches (a taken branch costs 8-17 ns on a lone wave, an ALU instruction ~3).
+                    // %[cum] holds the next unread word of the copy's window position %[lb]; anything unusual (count
+                    // nibble > 8, window nearly used up) leaves for the generic path with the committed state untouched,
+                    // a state too small for the one-shot payload takes the nibble-by-nibble loop at 74.
                     "s_cmp_gt_u32 %[wi], 56\n"
                     "s_cbranch_scc1 8f\n"
                     "s_lshr_b64 s[86:87], s[84:85], 16\n"
@@ -1055,49 +1062,60 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_add_u32 %[t1], %[t1], s89\n"
                     "s_add_u32 s88, s88, %[t0]\n"
                     "s_addc_u32 s89, %[t1], 0\n"
-                    "s_mov_b32 %[lb], %[wi]\n"
-                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cmp_lg_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 91f\n"
-                    "s_mov_b32 s89, s88\n"
-                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
-                    "s_add_u32 %[lb], %[lb], 1\n"
-                    "91:\n"
+                    "s_lshr_b64 s[86:87], s[88:89], 31\n"     // renormalise after the escape symbol: wn = word wi
+                    "s_cmp_eq_u64 s[86:87], 0\n"
+                    "s_cselect_b32 s89, s88, s89\n"
+                    "s_cselect_b32 s88, %[wn], s88\n"
+                    "s_addc_u32 %[lb], %[wi], 0\n"
+                    "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
                     "s_and_b32 %[e0], s88, 15\n"              // count nibble
                     "s_lshr_b64 s[88:89], s[88:89], 4\n"
                     "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cmp_lg_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 91f\n"
-                    "s_mov_b32 s89, s88\n"
-                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
-                    "s_add_u32 %[lb], %[lb], 1\n"
-                    "91:\n"
-                    "s_cmp_gt_u32 %[e0], 8\n"
-                    "s_cbranch_scc1 8f\n"
-                    "s_mov_b32 %[start], 0\n"
-                    "s_mov_b32 %[cum], 0\n"
-                    // All payload nibbles at once when the state is large enough that none of the first nn - 1 steps can
-                    // drop it below 2^31 (x >= 2^(27 + 4 nn): three escapes in four): the payload is then simply the low
-                    // 4 nn bits of x, and only the last step can ask for a word -- the reference's nibble-by-nibble loop
-                    // (rans_interface.cpp:80-96, 323-345) consumes exactly the same words in that case.
-                    "s_sub_u32 %[t1], %[e0], 1\n"             // nn in 1..7 ?
-                    "s_cmp_gt_u32 %[t1], 6\n"
-                    "s_cbranch_scc1 74f\n"
-                    "s_lshl_b32 %[t1], %[e0], 2\n"            // bits = 4 nn
+                    "s_cmp_eq_u64 s[86:87], 0\n"
+                    "s_cselect_b32 s89, s88, s89\n"
+                    "s_cselect_b32 s88, %[cum], s88\n"
+                    "s_addc_u32 %[lb], %[lb], 0\n"
+                    "s_cmp_gt_u32 %[e0], 7\n"
+                    "s_cbranch_scc1 79f\n"                    // nn = 8: step by step; a longer count: generic path
+                    "s_lshl_b32 %[t1], %[e0], 2\n"            // bits = 4 nn (nn = 0: no payload, raw = 0)
                     "s_add_u32 %[t0], %[t1], 27\n"
                     "s_lshr_b64 s[86:87], s[88:89], %[t0]\n"
                     "s_cmp_eq_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 74f\n"                    // too small: step by step
+                    "s_cbranch_scc1 78f\n"                    // too small: step by step
+                    "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
                     "s_bfm_b32 %[t0], %[t1], 0\n"
                     "s_and_b32 %[start], s88, %[t0]\n"        // raw
                     "s_lshr_b64 s[88:89], s[88:89], %[t1]\n"
                     "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cmp_lg_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 75f\n"
-                    "s_mov_b32 s89, s88\n"
-                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
-                    "s_add_u32 %[lb], %[lb], 1\n"
-                    "s_branch 75f\n"
+                    "s_cmp_eq_u64 s[86:87], 0\n"
+                    "s_cselect_b32 s89, s88, s89\n"
+                    "s_cselect_b32 s88, %[cum], s88\n"
+                    "s_addc_u32 %[lb], %[lb], 0\n"
+                    "s_lshr_b32 %[t1], %[start], 1\n"         // value: even raw -> last + raw / 2, odd -> -(raw >> 1) - 1
+                    "s_add_u32 %[t0], %[t1], %[a]\n"
+                    "s_not_b32 %[t1], %[t1]\n"
+                    "s_bitcmp1_b32 %[start], 0\n"
+                    "s_cselect_b32 %[t1], %[t1], %[t0]\n"
+                    "v_writelane_b32 %[outv], %[t1], m0\n"    // (the tail of 77: below, inlined: no taken branch on this path)
+                    "s_mov_b64 s[84:85], s[88:89]\n"
+                    "s_mov_b32 %[wi], %[lb]\n"
+                    "s_add_u32 %[lb], m0, 1\n"
+                    "v_readlane_b32 %[lb], %[rowbase], %[lb]\n"
+                    "v_add_u32 v60, %[lb], %[lane2]\n"
+                    "ds_read_u16 v58, v60 offset:2\n"
+                    "s_sub_u32 %[t0], %[cnt], m0\n"
+                    "s_add_u32 %[t0], %[t0], %[wi]\n"
+                    "s_cmp_le_u32 %[t0], 65\n"
+                    "s_cbranch_scc1 4b\n"
+                    "s_add_u32 m0, m0, 1\n"
+                    "s_mov_b32 %[more], 2\n"
+                    "s_branch 5f\n"
+                    "79:\n"
+                    "s_cmp_gt_u32 %[e0], 8\n"
+                    "s_cbranch_scc1 8f\n"
+                    "78:\n"
+                    "s_mov_b32 %[start], 0\n"
+                    "s_mov_b32 %[cum], 0\n"
                     "74:\n"
                     "s_cmp_eq_u32 %[e0], 0\n"
                     "s_cbranch_scc1 75f\n"

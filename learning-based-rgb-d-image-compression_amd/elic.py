@@ -105,8 +105,25 @@ class ELIC(ELIC_united):
         del k1, k2
         return {"x_hat": out, "cost_time": time.process_time() - t0}
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("eval-mode forward() is built for ELIC_united only")
+    def forward(self, x):  # models/elic.py:60-161 (eval mode, quant = "ste")
+        """Eval-mode forward(): {"x_hat", "likelihoods": {"y_likelihoods", "z_likelihoods"}} like the reference (x_hat is not
+        clamped; y_hat = round(y - mean) + mean slice by slice, Gaussian / factorised-prior likelihoods)."""
+        self._ready()
+        if self.training:
+            raise RuntimeError("forward() is built for eval mode (inference path); call .eval() first")
+        if x.dim() != 4 or x.size(1) != self.channel:
+            raise ValueError(f"expected x [B,{self.channel},H,W]")
+        B, _, H, W = x.shape
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64 (pad first: dataset/utils.py:58-67)")
+        x = x.to(self._device, torch.float32).contiguous()
+        xh = torch.empty((B, self.channel, H, W), dtype=torch.float32, device=self._device)
+        ly = torch.empty((B, self.M, H // 16, W // 16), dtype=torch.float32, device=self._device)
+        lz = torch.empty((B, self.N, H // 64, W // 64), dtype=torch.float32, device=self._device)
+        check(lib().rgbd_elic_forward_single(self._h, ctypes.c_void_p(x.data_ptr()), B, H, W, ctypes.c_void_p(xh.data_ptr()),
+                                             ctypes.c_void_p(ly.data_ptr()), ctypes.c_void_p(lz.data_ptr()),
+                                             self._stream_ptr()), "forward")
+        return {"x_hat": xh, "likelihoods": {"y_likelihoods": ly, "z_likelihoods": lz}}
 
     __call__ = forward
 

@@ -802,6 +802,51 @@ class OracleCodecSingle:
         return _deconv(self.sd, "h_s.increase.4", t, stride=1)
 
     @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        """Eval-mode forward of the single-modal model (models/elic.py:60-161 with config quant = "ste"): per slice
+        y_hat = round(y - mean) + mean on the anchor positions, then on the non-anchor positions with the local context of
+        the anchors; Gaussian likelihoods of the merged parameters, factorised-prior likelihoods of round(z - median)."""
+        sd = self.sd
+        y = _stack1(sd, "g_a.analysis_transform", _GA1, x)
+        t = torch.relu(_conv(sd, "h_a.reduction.0", y))
+        t = torch.relu(_conv(sd, "h_a.reduction.2", t, stride=2))
+        z = _conv(sd, "h_a.reduction.4", t, stride=2)
+        # entropy_models.py:369-428 on the quantised z (same arithmetic as OracleCodec._eb_forward)
+        p = "entropy_bottleneck"
+        med = sd[f"{p}.quantiles"][:, :, 1:2]
+        zt = z.permute(1, 2, 3, 0).contiguous()
+        shape = zt.size()
+        out = torch.round(zt.reshape(zt.size(0), 1, -1) - med) + med
+        lower, upper = _eb_logits(sd, p, out - 0.5), _eb_logits(sd, p, out + 0.5)
+        sign = -torch.sign(lower + upper)
+        lz = torch.max(torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower)), torch.tensor([1e-9]))
+        zhat = out.reshape(shape).permute(3, 0, 1, 2).contiguous()
+        lz = lz.reshape(shape).permute(3, 0, 1, 2).contiguous()
+        hyper = self._hyper(zhat)
+
+        def keep(t_, anchor):  # ckbd_anchor / ckbd_nonanchor: the other checkerboard half becomes zero
+            return unpack(pack(t_, anchor), anchor)
+
+        yhat, ly = [], []
+        c0 = 0
+        for i, c in enumerate(self.slice_ch):
+            ys = y[:, c0:c0 + c]
+            ctx = ([_channel_context(sd, f"channel_context.{i}", torch.cat(yhat, dim=1))] if i else []) + [hyper]
+            sa, ma = _entropy_params1(sd, f"entropy_parameters_anchor.{i}", torch.cat(ctx, dim=1)).chunk(2, 1)
+            sa, ma = keep(sa, True), keep(ma, True)
+            a = keep(torch.round(keep(ys, True) - ma) + ma, True)  # elic.py:84-85 (ste_round on the anchor half)
+            loc = _conv(sd, f"local_context.{i}", a)
+            sn, mn = _entropy_params1(sd, f"entropy_parameters_nonanchor.{i}", torch.cat([loc] + ctx, dim=1)).chunk(2, 1)
+            sn, mn = keep(sn, False), keep(mn, False)
+            n = keep(torch.round(keep(ys, False) - mn) + mn, False)
+            ly.append(OracleCodec._gc_likelihood(ys, sa + sn, ma + mn))  # ckbd_merge, then entropy_models.py:534-558
+            yhat.append(a + n)
+            c0 += c
+        yhat = torch.cat(yhat, dim=1)
+        return {"x_hat": _stack1(sd, "g_s.synthesis_transform", _GS1, yhat),
+                "likelihoods": {"y_likelihoods": torch.cat(ly, dim=1), "z_likelihoods": lz}}
+
+    @torch.no_grad()
     def decompress(self, strings, shape):  # elic.py:255-325
         zhat = self._z_decompress(strings[1], shape)
         hyper = self._hyper(zhat)

@@ -281,6 +281,18 @@ def main():
     import rgbd_amd  # noqa: F401
     from rgbd_amd import synth
 
+    if "--only-elic-fw" in sys.argv:  # eval-mode forward() of the single-modal ELIC (models/elic.py:60-161)
+        net = ext["ELIC"](config=model_config(), channel=3).eval()
+        net.load_state_dict(synth.synthetic_state_dict(0, model="ELIC"))
+        assert net.update(force=True)
+        r, _ = synth.synthetic_batch(2, 128, 192, config_id=11)
+        with torch.no_grad():
+            fw = net(torch.from_numpy(r))
+        g = {"B": 2, "H": 128, "W": 192, "config_id": 11, "x_hat": fw["x_hat"].numpy(),
+             "lik_y": fw["likelihoods"]["y_likelihoods"].numpy(), "lik_z": fw["likelihoods"]["z_likelihoods"].numpy()}
+        np.savez_compressed(os.path.join(HERE, "elic_fw_b2_128x192.npz"), **g)
+        print("elic forward", g["x_hat"].shape, float(g["lik_y"].mean()), float(g["lik_z"].mean()))
+        return
     if "--only-r2d" in sys.argv:  # refresh one fixture without touching the others
         r2d_case(model_config, synth, "128x192", 1, 128, 192, 4)
         return

@@ -103,3 +103,34 @@ def test_batch_and_errors(net1):
         net1.compress(x[:, :, :100])
     with pytest.raises(ValueError):
         net1.compress(torch.zeros(1, 1, 64, 64))
+
+
+def test_single_modal_eval_forward(net1, orc1):
+    """ELIC.forward() (eval mode) on the GPU: the reference's return structure, x_hat and likelihoods against the reference's
+    golden (tests/golden/elic_fw_b2_128x192.npz) and against the oracle on the same inputs."""
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "elic_fw_b2_128x192.npz"))
+    r, _ = synth.synthetic_batch(int(g["B"]), int(g["H"]), int(g["W"]), config_id=int(g["config_id"]))
+    x = torch.from_numpy(r)
+    out = net1(x.cuda())
+    assert set(out) == {"x_hat", "likelihoods"} and set(out["likelihoods"]) == {"y_likelihoods", "z_likelihoods"}
+    ly, lz = out["likelihoods"]["y_likelihoods"].cpu().numpy(), out["likelihoods"]["z_likelihoods"].cpu().numpy()
+    assert ly.shape == g["lik_y"].shape and lz.shape == g["lik_z"].shape and ly.min() >= 1e-9 and ly.max() <= 1.0
+    # z and the first slice do not depend on earlier quantisation decisions: tight; a y value on a rounding boundary changes
+    # the contexts of the later slices (and, through g_s, a neighbourhood of x_hat): totals and medians for the rest
+    np.testing.assert_allclose(lz, g["lik_z"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(ly[:, :16], g["lik_y"][:, :16], rtol=1e-3, atol=1e-6)
+    bits, gbits = -np.log2(ly).sum(), -np.log2(g["lik_y"]).sum()
+    assert abs(bits - gbits) < 0.01 * gbits
+    xh = out["x_hat"].cpu().numpy()
+    assert float(np.median(np.abs(xh - g["x_hat"]))) < 2e-5 * float(np.abs(g["x_hat"]).max()) and _rel(xh, g["x_hat"]) < 5e-2
+    # forward() is the codec without the coder: its x_hat is what decompress(compress(x)) reconstructs, bit for bit
+    c = net1.compress(x.cuda())
+    d = net1.decompress(c["strings"], c["shape"])
+    assert torch.equal(d["x_hat"], out["x_hat"])
+    fw = orc1.forward(x)
+    assert float(np.median(np.abs(xh - fw["x_hat"].numpy()))) < 2e-5 * float(np.abs(xh).max())
+    # forward() twice gives the same bits (deterministic kernels), and it leaves compress() / decompress() usable
+    again = net1(x.cuda())
+    assert torch.equal(again["x_hat"], out["x_hat"]) and torch.equal(again["likelihoods"]["y_likelihoods"], out["likelihoods"]["y_likelihoods"])

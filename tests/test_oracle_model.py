@@ -263,3 +263,22 @@ def test_golden_part_walker_on_the_oracle(codec, kat):
     badi[0][3] = (badi[0][3] + 9) % 64
     clean, total = golden_parts_identical(sym, badi, golden, gc, sizes)
     assert total == 20 and clean == 0
+
+
+def test_single_modal_eval_forward_matches_reference():
+    """ELIC.forward() in eval mode (models/elic.py:60-161, quant = "ste") restated: x_hat and both likelihood tensors against
+    the reference's own run (tests/golden/make_golden.py --only-elic-fw)."""
+    import os
+
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "elic_fw_b2_128x192.npz"))
+    orc = eo.OracleCodecSingle(synth.synthetic_state_dict(0, model="ELIC"))
+    orc.update()
+    r, _ = synth.synthetic_batch(int(g["B"]), int(g["H"]), int(g["W"]), config_id=int(g["config_id"]))
+    fw = orc.forward(torch.from_numpy(r))
+    np.testing.assert_allclose(fw["x_hat"].numpy(), g["x_hat"], rtol=1e-5, atol=1e-5)
+    # a y value on a rounding boundary moves its likelihood by a bin; such positions are isolated
+    for key, name in (("y_likelihoods", "lik_y"), ("z_likelihoods", "lik_z")):
+        a, b = fw["likelihoods"][key].numpy(), g[name]
+        assert a.shape == b.shape and (np.abs(a - b) > 1e-5).mean() < 1e-3
