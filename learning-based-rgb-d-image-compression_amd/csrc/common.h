@@ -145,8 +145,11 @@ long conv_log_read(char* buf, long cap);  // CSV text; returns the size needed
 int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s);
 int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int cs, float* dst, int clamp01,
                               hipStream_t s);
-int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s);
-int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s);
+// x1 / y1 (both or neither): a second tensor pair of the same shape handled by the same launch (the other modality's ESA branch)
+int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s,
+                      const float* x1 = nullptr, float* y1 = nullptr);
+int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s, const float* x1 = nullptr,
+                    float* y1 = nullptr);
 int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s);
 int launch_channel_mean_strided(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s);
 int launch_channel_scale_to_strided(const float* x, int N, int HW, int xcs, int C, const float* scale, int sstride, int mode,

@@ -1404,12 +1404,13 @@ struct rgbd_elic {
         }
         const int ph = (c1[0].h - 7) / 3 + 1, pw = (c1[0].w - 7) / 3 + 1;
         Act v[2];
-        for (int m = 0; m < 2; ++m) {
-            v[m] = alloc(x[m].n, ph, pw, c1[m].c);
-            if (!dry() && !rc) {
-                const int r = launch_maxpool7s3(c1[m].p, c1[m].n, c1[m].h, c1[m].w, c1[m].cs, v[m].p, ph, pw, s);
-                if (r) fail(r);
-            }
+        for (int m = 0; m < 2; ++m) v[m] = alloc(x[m].n, ph, pw, c1[m].c);
+        const bool same = g_pair && c1[0].n == c1[1].n && c1[0].h == c1[1].h && c1[0].w == c1[1].w && c1[0].cs == c1[1].cs;
+        if (!dry() && !rc) {  // both modalities' pooled branches in one launch when they have the same shape (they do)
+            int r = launch_maxpool7s3(c1[0].p, c1[0].n, c1[0].h, c1[0].w, c1[0].cs, v[0].p, ph, pw, s, same ? c1[1].p : nullptr,
+                                      same ? v[1].p : nullptr);
+            if (!r && !same) r = launch_maxpool7s3(c1[1].p, c1[1].n, c1[1].h, c1[1].w, c1[1].cs, v[1].p, ph, pw, s);
+            if (r) fail(r);
         }
         Act vr[2], c3[2], c3b[2], up[2], sum[2], o[2];
         names(".conv_max", n);
@@ -1418,12 +1419,14 @@ struct rgbd_elic {
         conv2(n, vr, 1, 1, relu, nullptr, c3);
         names(".conv3_", n);
         conv2(n, c3, 1, 1, none, nullptr, c3b);
-        for (int m = 0; m < 2; ++m) {
-            up[m] = alloc(x[m].n, x[m].h, x[m].w, c3b[m].c);
-            if (!dry() && !rc) {
-                const int r = launch_bilinear(c3b[m].p, c3b[m].n, c3b[m].h, c3b[m].w, c3b[m].cs, up[m].p, x[m].h, x[m].w, s);
-                if (r) fail(r);
-            }
+        for (int m = 0; m < 2; ++m) up[m] = alloc(x[m].n, x[m].h, x[m].w, c3b[m].c);
+        if (!dry() && !rc) {
+            const bool same2 = same && x[0].h == x[1].h && x[0].w == x[1].w && c3b[0].cs == c3b[1].cs && up[0].cs == up[1].cs;
+            int r = launch_bilinear(c3b[0].p, c3b[0].n, c3b[0].h, c3b[0].w, c3b[0].cs, up[0].p, x[0].h, x[0].w, s,
+                                    same2 ? c3b[1].p : nullptr, same2 ? up[1].p : nullptr);
+            if (!r && !same2)
+                r = launch_bilinear(c3b[1].p, c3b[1].n, c3b[1].h, c3b[1].w, c3b[1].cs, up[1].p, x[1].h, x[1].w, s);
+            if (r) fail(r);
         }
         Epi addup[2];
         addup[0].res1 = &up[0];

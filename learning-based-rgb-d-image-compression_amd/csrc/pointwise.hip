@@ -70,9 +70,12 @@ int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int 
 
 // ---------------------------------------------------------------------------------------------
 // F.max_pool2d(kernel=7, stride=3), no padding, floor mode (attention.py:87)
-__global__ void maxpool7s3_kernel(const float* __restrict__ x, int N, int H, int W, int cs, float* __restrict__ y,
-                                  int OH, int OW)
+__global__ void maxpool7s3_kernel(const float* __restrict__ x0, int N, int H, int W, int cs, float* __restrict__ y0,
+                                  int OH, int OW, const float* __restrict__ x1, float* __restrict__ y1)
 {
+    // blockIdx.y = 1: the second tensor of a pair (the other modality's ESA branch, same shape) in the same launch
+    const float* __restrict__ x = blockIdx.y ? x1 : x0;
+    float* __restrict__ y = blockIdx.y ? y1 : y0;
     const int c4n = cs / 4;
     const size_t total = (size_t)N * OH * OW * c4n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -94,20 +97,23 @@ __global__ void maxpool7s3_kernel(const float* __restrict__ x, int N, int H, int
     }
 }
 
-int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s)
+int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s, const float* x1,
+                      float* y1)
 {
-    if (OH != (H - 7) / 3 + 1 || OW != (W - 7) / 3 + 1 || H < 7 || W < 7) return RGBD_EINVAL;
+    if (OH != (H - 7) / 3 + 1 || OW != (W - 7) / 3 + 1 || H < 7 || W < 7 || !x1 != !y1) return RGBD_EINVAL;
     const size_t work = (size_t)N * OH * OW * (cs / 4);
-    hipLaunchKernelGGL(maxpool7s3_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, N, H, W, cs, y, OH, OW);
+    hipLaunchKernelGGL(maxpool7s3_kernel, dim3(grid_for(work), x1 ? 2 : 1), dim3(256), 0, s, x, N, H, W, cs, y, OH, OW, x1, y1);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
 
 // F.interpolate(mode="bilinear", align_corners=False) to (H, W) (attention.py:91):
 // src = max(0, scale*(dst+0.5)-0.5), i0 = floor(src), i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1
-__global__ void bilinear_kernel(const float* __restrict__ x, int N, int h, int w, int cs, float* __restrict__ y, int H,
-                                int W, float sy, float sx)
+__global__ void bilinear_kernel(const float* __restrict__ x0, int N, int h, int w, int cs, float* __restrict__ y0, int H,
+                                int W, float sy, float sx, const float* __restrict__ x1, float* __restrict__ y1)
 {
+    const float* __restrict__ x = blockIdx.y ? x1 : x0;  // (pair of tensors, see maxpool7s3_kernel)
+    float* __restrict__ y = blockIdx.y ? y1 : y0;
     const int c4n = cs / 4;
     const size_t total = (size_t)N * H * W * c4n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -141,11 +147,12 @@ __global__ void bilinear_kernel(const float* __restrict__ x, int N, int h, int w
     }
 }
 
-int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s)
+int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s, const float* x1, float* y1)
 {
+    if (!x1 != !y1) return RGBD_EINVAL;
     const size_t work = (size_t)N * H * W * (cs / 4);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, N, h, w, cs, y, H, W, sy, sx);
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(work), x1 ? 2 : 1), dim3(256), 0, s, x, N, h, w, cs, y, H, W, sy, sx, x1, y1);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
