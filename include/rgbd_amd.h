@@ -214,7 +214,14 @@ int rgbd_debug_force_ckbd(int32_t part); /* rgbd_conv2d_nchw / rgbd_conv_bench: 
                                            ((row + col) odd, utils/ckbd.py:37-48), 2 = non-anchor only; the rest reads 0 */
 int rgbd_debug_conv_log(int32_t on);                      /* record the shape of every conv launch (tools/tune_tiles.py) */
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap); /* CSV text of the recorded shapes; returns the size needed */
-int rgbd_debug_force_tile(const char* cfg); /* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */
+int rgbd_debug_force_tile(const char* cfg); /* The pointwise operators of Bi-SPF / ESA / SE_Block alone (test hook; NCHW device tensors in and out, host weights):
+ * op 0 = F.max_pool2d(kernel 7, stride 3) (attention.py:87), 1 = F.interpolate(bilinear, align_corners=False) to (oh, ow)
+ * (attention.py:91), 2 = SE_Block x * gate (attention.py:52-67; w0 = fc.0.weight [c/16][c], w1 = fc.2.weight [c][c/16]),
+ * 3 = x + x * gate as the entropy-parameter nets use it (entropy.py:75). */
+int rgbd_pointwise_nchw(int32_t op, const float* x_dev, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                        const float* w0, const float* w1, float* y_dev, void* stream);
+
+/* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */
 int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                     int32_t transposed, int32_t with_residual, int32_t iters, float* ms_out);
 int rgbd_elic_profile_dump(rgbd_elic* m, const char* path);

@@ -80,6 +80,7 @@ def lib():
         "rgbd_rans_decoder_destroy": (None, [c_vp]),
         "rgbd_conv2d_nchw": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32, c_i32,
                                             c_i32, c_i32, c_vp, c_vp, c_vp]),
+        "rgbd_pointwise_nchw": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_vp, c_vp]),
         "rgbd_elic_create": (ctypes.c_int, [c_i32, c_i32, i32p, c_i32, ctypes.POINTER(c_vp)]),
         "rgbd_elic_destroy": (None, [c_vp]),
         "rgbd_elic_clone_shared": (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp)]),
@@ -134,7 +135,7 @@ def lib():
 
 EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
            "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
-           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_elic_create",
+           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count",

@@ -3377,6 +3377,62 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
     return rc;
 }
 
+// Pointwise operators of Bi-SPF / ESA / SE_Block alone (modules/transform/attention.py:52-97), NCHW in, NCHW out: what
+// tests/test_gpu_pointwise.py compares with torch's F.max_pool2d / F.interpolate / the SE_Block arithmetic.
+//   op 0: max_pool2d(kernel 7, stride 3) -> y [n, c, (h-7)/3+1, (w-7)/3+1]
+//   op 1: interpolate(bilinear, align_corners=False) to (oh, ow)
+//   op 2: SE_Block: y = x * sigmoid(fc2(relu(fc0(mean_hw(x)))))   (w0 [c/16][c], w1 [c][c/16], no biases)
+//   op 3: the engine's residual form x + x * gate (entropy.py:75)
+int rgbd_pointwise_nchw(int32_t op, const float* x_dev, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                        const float* w0, const float* w1, float* y_dev, void* stream)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
+    if (!x_dev || !y_dev || n <= 0 || c <= 0 || h <= 0 || w <= 0 || op < 0 || op > 3) return RGBD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int cs = round_up(c, 16);
+    if (op == 0) {
+        oh = (h - 7) / 3 + 1;
+        ow = (w - 7) / 3 + 1;
+        if (h < 7 || w < 7) return RGBD_EINVAL;
+    } else if (op >= 2) {
+        oh = h;
+        ow = w;
+        if (!w0 || !w1 || c % 16) return RGBD_EINVAL;
+    } else if (oh <= 0 || ow <= 0) {
+        return RGBD_EINVAL;
+    }
+    float *xin = nullptr, *yout = nullptr, *aux = nullptr, *dw0 = nullptr, *dw1 = nullptr;
+    HIP_TRY(hipMalloc((void**)&xin, (size_t)n * h * w * cs * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&yout, (size_t)n * oh * ow * cs * sizeof(float)));
+    int rc = launch_nchw_to_nhwc16(x_dev, n, c, h, w, xin, cs, s);
+    if (!rc && op == 0) rc = launch_maxpool7s3(xin, n, h, w, cs, yout, oh, ow, s);
+    if (!rc && op == 1) rc = launch_bilinear(xin, n, h, w, cs, yout, oh, ow, s);
+    if (!rc && op >= 2) {
+        const int hid = c / 16;
+        std::vector<float> w1t((size_t)c * hid);  // fc.2.weight [c][hid] -> [hid][c], as rgbd_elic_finalize stores it
+        for (int i = 0; i < c; ++i)
+            for (int j = 0; j < hid; ++j) w1t[(size_t)j * c + i] = w1[(size_t)i * hid + j];
+        HIP_TRY(hipMalloc((void**)&aux, (size_t)n * (2 * c + hid + 1) * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&dw0, (size_t)c * hid * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&dw1, (size_t)c * hid * sizeof(float)));
+        HIP_TRY(hipMemcpy(dw0, w0, (size_t)c * hid * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dw1, w1t.data(), (size_t)c * hid * sizeof(float), hipMemcpyHostToDevice));
+        float *mean = aux, *sc = aux + (size_t)n * c, *hd = aux + (size_t)2 * n * c;
+        rc = launch_channel_mean(xin, n, h * w, cs, c, mean, s);
+        if (!rc) rc = launch_se_fc(mean, n, c, hid, dw0, dw1, hd, sc, s);
+        if (!rc) rc = launch_channel_scale_to(xin, n, h * w, cs, c, sc, op == 3 ? 1 : 0, yout, cs, s);
+    }
+    if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, c, oh, ow, cs, y_dev, 0, s);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) rc = RGBD_EHIP;
+    (void)hipFree(xin);
+    (void)hipFree(yout);
+    (void)hipFree(aux);
+    (void)hipFree(dw0);
+    (void)hipFree(dw1);
+    return rc;
+}
+
 int rgbd_debug_force_tile(const char* cfg)
 {
     snprintf(g_conv_force, sizeof(g_conv_force), "%s", cfg ? cfg : "");

@@ -1,0 +1,62 @@
+"""SURVEY 8(a) row a6 in isolation: the pointwise operators of Bi-SPF / ESA / SE_Block (modules/transform/attention.py:35-97,
+modules/transform/entropy.py:75) through the C ABI against torch's own CPU operators on the same inputs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_utils import require_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(op, x, oh=0, ow=0, w0=None, w1=None):
+    import rgbd_amd  # noqa: F401
+    from rgbd_amd._lib import check, lib
+
+    require_gpu()
+    n, c, h, w = x.shape
+    if op == 0:
+        oh, ow = (h - 7) // 3 + 1, (w - 7) // 3 + 1
+    elif op >= 2:
+        oh, ow = h, w
+    xd = x.cuda().contiguous()
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device="cuda")
+    f32p = ctypes.POINTER(ctypes.c_float)
+    p0 = w0.contiguous().numpy().ctypes.data_as(f32p) if w0 is not None else None
+    p1 = w1.contiguous().numpy().ctypes.data_as(f32p) if w1 is not None else None
+    check(lib().rgbd_pointwise_nchw(op, ctypes.c_void_p(xd.data_ptr()), n, c, h, w, oh, ow, p0, p1,
+                                    ctypes.c_void_p(y.data_ptr()), None), "pointwise")
+    return y.cpu()
+
+
+@pytest.mark.parametrize("n,c,h,w", [(1, 48, 31, 47), (2, 48, 63, 79), (1, 24, 7, 7), (3, 16, 10, 22)])
+def test_maxpool7s3_matches_torch(n, c, h, w):
+    x = torch.randn(n, c, h, w)
+    assert torch.equal(_run(0, x), F.max_pool2d(x, kernel_size=7, stride=3))  # a maximum is exact
+
+
+@pytest.mark.parametrize("n,c,h,w,oh,ow", [(1, 48, 9, 14, 64, 96), (2, 48, 19, 25, 128, 160), (1, 16, 1, 1, 8, 8),
+                                         (1, 32, 5, 7, 5, 7), (1, 48, 41, 53, 256, 320)])
+def test_bilinear_matches_torch(n, c, h, w, oh, ow):
+    x = torch.randn(n, c, h, w)
+    ref = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False)
+    got = _run(1, x, oh, ow)
+    # same source coordinates and weights as ATen's upsample_bilinear2d; the four-term blend may associate differently
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("n,c,h,w,op", [(1, 192, 16, 24, 2), (2, 384, 8, 10, 2), (4, 1280, 32, 40, 3), (1, 2432, 8, 12, 3)])
+def test_se_block_matches_torch(n, c, h, w, op):
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g)
+    w0 = torch.randn(c // 16, c, generator=g) * 0.05
+    w1 = torch.randn(c, c // 16, generator=g) * 0.2
+    gate = torch.sigmoid(F.linear(torch.relu(F.linear(x.mean(dim=(2, 3)), w0)), w1)).view(n, c, 1, 1)
+    ref = x * gate if op == 2 else x + x * gate
+    got = _run(op, x, w0=w0, w1=w1)
+    # the mean is a different (fixed) summation order from ATen's: 1e-6-level differences in the gate
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got, _run(op, x, w0=w0, w1=w1))  # and it is deterministic
