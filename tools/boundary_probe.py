@@ -21,7 +21,8 @@ import rgbd_amd  # noqa: E402,F401
 from rgbd_amd._lib import lib  # noqa: E402
 
 L = lib()
-SHAPES = [(8, 192, 128, 160, 192, 3, 1), (8, 384, 256, 320, 192, 5, 2), (8, 96, 256, 320, 96, 3, 1)]
+SHAPES = [(8, 192, 128, 160, 192, 3, 1), (8, 384, 256, 320, 192, 5, 2), (8, 96, 256, 320, 96, 3, 1),
+          (8, 192, 64, 80, 96, 1, 1), (4, 96, 32, 40, 96, 3, 1)]  # the last two: 20-60 us launches (dispatch latency shows)
 threads = [int(v) for v in sys.argv[1:]] or [0, 1, 4, 10]
 
 
