@@ -522,7 +522,7 @@ struct rgbd_elic {
         int capture_fails = 0;              // failed capture attempts; kMaxCaptureFails of them retire the entry to eager launches
         uint64_t last_use = 0;              // graph_clock at the entry's last call (least-recently-used eviction)
         std::map<std::string, Act> named;   // debug tensors of the body (same workspace addresses on every replay)
-        Act out[2];                         // body outputs the epilogue reads (x_hat or y_hat per modality)
+        Act out[6];                         // body outputs the epilogue reads (x_hat / y_hat per modality; forward(): + likelihoods)
     };
     std::map<std::string, GraphEntry> graphs;
     static constexpr int kMaxCaptureFails = 3;
@@ -2538,66 +2538,89 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
         if (!r) r = launch_nchw_to_nhwc16(depth_dev, B, 1, H, W, depth.p, depth.cs, s);
         if (r) return r;
     }
-    Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
-    Act z_r, z_d;
-    {
-        const size_t mark = arena.top;
-        Act yr_t, yd_t;
-        if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
-        else if (variant == 3) g_a_r2d(rgb, depth, &yr_t, &yd_t);
-        else g_a(rgb, depth, &yr_t, &yd_t);
-        copy_ch(yr_t, y_r);
-        copy_ch(yd_t, y_d);
-        arena.top = mark;
-    }
-    h_a(y_r, y_d, &z_r, &z_d);
-    Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
-    Act zl_r = alloc(B, zh, zw, N), zl_d = alloc(B, zh, zw, N);
-    if (!dry() && !rc) {
-        const Act* zz[2] = {&z_r, &z_d};
-        const Act* zo[2] = {&zh_r, &zh_d};
-        const Act* zl[2] = {&zl_r, &zl_d};
-        const char* mods[2] = {"rgb", "depth"};
-        for (int m = 0; m < 2 && !rc; ++m) {
-            float* md = dense_of(std::string(mods[m]) + "_entropy_bottleneck.medians");
-            float* prm = dense_of(std::string(mods[m]) + "_entropy_bottleneck.cumulative");
-            if (!md || !prm) break;
-            const int r = launch_eb_forward(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, prm, zo[m]->p, zl[m]->p, s);
-            if (r) fail(r);
+    // ==== body: captured into / replayed from a HIP graph per call shape (the prologue above reads the caller's pointers,
+    // the epilogue below writes them) ====
+    Act xr, xd, lik_r, lik_d, zl_r, zl_d;
+    if (body_begin()) {
+        Act y_r = alloc(B, h, w, M), y_d = alloc(B, h, w, M);
+        Act z_r, z_d;
+        {
+            const size_t mark = arena.top;
+            Act yr_t, yd_t;
+            if (variant == 2) g_a_stf(rgb, depth, &yr_t, &yd_t);
+            else if (variant == 3) g_a_r2d(rgb, depth, &yr_t, &yd_t);
+            else g_a(rgb, depth, &yr_t, &yd_t);
+            copy_ch(yr_t, y_r);
+            copy_ch(yd_t, y_d);
+            arena.top = mark;
         }
+        h_a(y_r, y_d, &z_r, &z_d);
+        Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
+        zl_r = alloc(B, zh, zw, N);
+        zl_d = alloc(B, zh, zw, N);
+        if (!dry() && !rc) {
+            const Act* zz[2] = {&z_r, &z_d};
+            const Act* zo[2] = {&zh_r, &zh_d};
+            const Act* zl[2] = {&zl_r, &zl_d};
+            const char* mods[2] = {"rgb", "depth"};
+            for (int m = 0; m < 2 && !rc; ++m) {
+                float* md = dense_of(std::string(mods[m]) + "_entropy_bottleneck.medians");
+                float* prm = dense_of(std::string(mods[m]) + "_entropy_bottleneck.cumulative");
+                if (!md || !prm) break;
+                const int r = launch_eb_forward(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, prm, zo[m]->p, zl[m]->p, s);
+                if (r) fail(r);
+            }
+        }
+        Act hyp_r, hyp_d;
+        if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
+        else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
+        Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
+        if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
+            int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
+            if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
+            if (zr) fail(zr);
+        }
+        Coding cd;
+        cd.estimate = true;
+        cd.lik[0] = alloc(B, h, w, M);
+        cd.lik[1] = alloc(B, h, w, M);
+        if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+        else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
+        named["y_r"] = y_r;
+        named["y_d"] = y_d;
+        named["yhat_r"] = yhat_r;
+        named["yhat_d"] = yhat_d;
+        if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
+        else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &xr, &xd);
+        else g_s(yhat_r, yhat_d, &xr, &xd);
+        lik_r = cd.lik[0];
+        lik_d = cd.lik[1];
+        if (cur_ge && !dry()) {
+            const Act o[6] = {xr, xd, lik_r, lik_d, zl_r, zl_d};
+            for (int k = 0; k < 6; ++k) cur_ge->out[k] = o[k];
+        }
+    } else {
+        xr = cur_ge->out[0];
+        xd = cur_ge->out[1];
+        lik_r = cur_ge->out[2];
+        lik_d = cur_ge->out[3];
+        zl_r = cur_ge->out[4];
+        zl_d = cur_ge->out[5];
     }
-    Act hyp_r, hyp_d;
-    if (variant == 3) h_s_r2d(zh_r, zh_d, &hyp_r, &hyp_d);
-    else h_s(zh_r, zh_d, &hyp_r, &hyp_d);
-    Act yhat_r = alloc(B, h, w, M), yhat_d = alloc(B, h, w, M);
-    if (variant == 2 && !dry()) {  // 24-wide slices: a 16-channel read chunk may straddle into a slice not coded yet
-        int zr = launch_fill_zero(yhat_r.p, yhat_r.elems(), s);
-        if (!zr) zr = launch_fill_zero(yhat_d.p, yhat_d.elems(), s);
-        if (zr) fail(zr);
+    {
+        const int r = body_end();
+        if (rc) return rc;
+        if (r) return r;
     }
-    Coding cd;
-    cd.estimate = true;
-    cd.lik[0] = alloc(B, h, w, M);
-    cd.lik[1] = alloc(B, h, w, M);
-    if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
-    else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
-    named["y_r"] = y_r;
-    named["y_d"] = y_d;
-    named["yhat_r"] = yhat_r;
-    named["yhat_d"] = yhat_d;
-    Act xr, xd;
-    if (variant == 2) g_s_stf(yhat_r, yhat_d, &xr, &xd);
-    else if (variant == 3) g_s_r2d(yhat_r, yhat_d, &xr, &xd);
-    else g_s(yhat_r, yhat_d, &xr, &xd);
     if (rc) return rc;
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 0, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(cd.lik[0].p, B, M, h, w, cd.lik[0].cs, ly_r, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(cd.lik[1].p, B, M, h, w, cd.lik[1].cs, ly_d, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(lik_r.p, B, M, h, w, lik_r.cs, ly_r, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(lik_d.p, B, M, h, w, lik_d.cs, ly_d, 0, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(zl_r.p, B, N, zh, zw, zl_r.cs, lz_r, 0, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(zl_d.p, B, N, zh, zw, zl_d.cs, lz_d, 0, s);
-    if (!r) HIP_TRY(hipStreamSynchronize(s));
+    if (!r) r = wait_stream();
     return r;
 }
 
@@ -2809,38 +2832,56 @@ int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat
         const int r = launch_nchw_to_nhwc16(x_dev, B, in_ch, H, W, x.p, x.cs, s);
         if (r) return r;
     }
-    Act y = alloc(B, h, w, M);
-    {
-        const size_t mark = arena.top;
-        copy_ch(g_a1(x), y);
-        arena.top = mark;
-    }
-    Act z = h_a1(y);
-    Act zhat = alloc(B, zh, zw, N), zlik = alloc(B, zh, zw, N);
-    if (!dry() && !rc) {
-        float* md = dense_of("entropy_bottleneck.medians");
-        float* prm = dense_of("entropy_bottleneck.cumulative");
-        if (md && prm) {
-            const int r = launch_eb_forward(z.p, z.cs, B, zh, zw, N, md, prm, zhat.p, zlik.p, s);
-            if (r) fail(r);
+    Act xh, lik, zlik;
+    if (body_begin()) {  // (captured / replayed per call shape like every other body)
+        Act y = alloc(B, h, w, M);
+        {
+            const size_t mark = arena.top;
+            copy_ch(g_a1(x), y);
+            arena.top = mark;
         }
+        Act z = h_a1(y);
+        Act zhat = alloc(B, zh, zw, N);
+        zlik = alloc(B, zh, zw, N);
+        if (!dry() && !rc) {
+            float* md = dense_of("entropy_bottleneck.medians");
+            float* prm = dense_of("entropy_bottleneck.cumulative");
+            if (md && prm) {
+                const int r = launch_eb_forward(z.p, z.cs, B, zh, zw, N, md, prm, zhat.p, zlik.p, s);
+                if (r) fail(r);
+            }
+        }
+        Act hyper = h_s1(zhat);
+        Act yhat = alloc(B, h, w, M);
+        Coding cd;
+        cd.estimate = true;
+        cd.lik[0] = alloc(B, h, w, M);
+        bicee1(cd, &y, hyper, yhat);
+        named["y"] = y;
+        named["z"] = z;
+        named["zhat"] = zhat;
+        named["hyper"] = hyper;
+        named["yhat"] = yhat;
+        xh = g_s1(yhat);
+        lik = cd.lik[0];
+        if (cur_ge && !dry()) {
+            cur_ge->out[0] = xh;
+            cur_ge->out[1] = lik;
+            cur_ge->out[2] = zlik;
+        }
+    } else {
+        xh = cur_ge->out[0];
+        lik = cur_ge->out[1];
+        zlik = cur_ge->out[2];
     }
-    Act hyper = h_s1(zhat);
-    Act yhat = alloc(B, h, w, M);
-    Coding cd;
-    cd.estimate = true;
-    cd.lik[0] = alloc(B, h, w, M);
-    bicee1(cd, &y, hyper, yhat);
-    named["y"] = y;
-    named["z"] = z;
-    named["zhat"] = zhat;
-    named["hyper"] = hyper;
-    named["yhat"] = yhat;
-    Act xh = g_s1(yhat);
-    if (rc) return rc;
+    {
+        const int r = body_end();
+        if (rc) return rc;
+        if (r) return r;
+    }
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xh.p, B, in_ch, H, W, xh.cs, xhat_dev, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(cd.lik[0].p, B, M, h, w, cd.lik[0].cs, ly, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(lik.p, B, M, h, w, lik.cs, ly, 0, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(zlik.p, B, N, zh, zw, zlik.cs, lz, 0, s);
     if (!r) r = wait_stream();
     return r;
@@ -2887,50 +2928,62 @@ int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_im
         hmeta[(size_t)5 * B + i] = ycount;
     }
     if (!dry()) {
+        // (pageable source: the copy has left the host buffer when the call returns, so the vector may go out of scope)
         HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(err, 0, 256, s));
     }
     Act x = alloc(B, H, W, in_ch);
     if (!dry()) {
         const int r = launch_nchw_to_nhwc16(x_dev, B, in_ch, H, W, x.p, x.cs, s);
         if (r) return r;
     }
-    Act y = alloc(B, h, w, M);
+    // ==== body: captured into / replayed from a HIP graph per call shape ================================================
+    if (body_begin()) {
+        if (!dry()) {
+            const int zr = launch_fill_zero((float*)err, 64, s);  // (a kernel, not a memset node: DESIGN 3.5)
+            if (zr) fail(zr);
+        }
+        Act y = alloc(B, h, w, M);
+        {
+            const size_t mark = arena.top;
+            copy_ch(g_a1(x), y);
+            arena.top = mark;
+        }
+        Act z = h_a1(y);
+        named["y"] = y;
+        named["z"] = z;
+        Act zhat = alloc(B, zh, zw, N);
+        float* md = dense_of("entropy_bottleneck.medians");
+        if (!dry() && !rc && md) {
+            int r = launch_z_quant(z.p, z.cs, B, zh, zw, N, md, zsym, zidx, s);
+            if (!r)
+                r = launch_rans_encode(zsym, zidx, meta64 + B, meta64 + 2 * B, B, B, tables[2].d, tables[2].d, zwords, zcap,
+                                       meta64 + 3 * B, err, s);
+            if (!r) r = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
+            if (r) fail(r);
+        }
+        named["zhat"] = zhat;
+        Act hyper = h_s1(zhat);
+        named["hyper"] = hyper;
+        Act yhat = alloc(B, h, w, M);
+        named["yhat"] = yhat;
+        Coding cd;
+        cd.encode = true;
+        cd.per_image = per_image;
+        cd.per_image_total = T;
+        cd.sym = sym;
+        cd.idx = idx;
+        cd.stream_base = meta64;
+        bicee1(cd, &y, hyper, yhat);
+        if (!dry() && !rc) {
+            const int r = launch_rans_encode(sym, idx, meta64 + 4 * B, meta64 + 5 * B, ny, ny, tables[0].d, tables[0].d, ywords,
+                                             ycap, meta64 + 6 * B, err, s);
+            if (r) fail(r);
+        }
+    }  // body
     {
-        const size_t mark = arena.top;
-        copy_ch(g_a1(x), y);
-        arena.top = mark;
-    }
-    Act z = h_a1(y);
-    named["y"] = y;
-    named["z"] = z;
-    Act zhat = alloc(B, zh, zw, N);
-    float* md = dense_of("entropy_bottleneck.medians");
-    if (!dry() && !rc && md) {
-        int r = launch_z_quant(z.p, z.cs, B, zh, zw, N, md, zsym, zidx, s);
-        if (!r)
-            r = launch_rans_encode(zsym, zidx, meta64 + B, meta64 + 2 * B, B, B, tables[2].d, tables[2].d, zwords, zcap,
-                                   meta64 + 3 * B, err, s);
-        if (!r) r = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
-        if (r) fail(r);
-    }
-    named["zhat"] = zhat;
-    Act hyper = h_s1(zhat);
-    named["hyper"] = hyper;
-    Act yhat = alloc(B, h, w, M);
-    named["yhat"] = yhat;
-    Coding cd;
-    cd.encode = true;
-    cd.per_image = per_image;
-    cd.per_image_total = T;
-    cd.sym = sym;
-    cd.idx = idx;
-    cd.stream_base = meta64;
-    bicee1(cd, &y, hyper, yhat);
-    if (!dry() && !rc) {
-        const int r = launch_rans_encode(sym, idx, meta64 + 4 * B, meta64 + 5 * B, ny, ny, tables[0].d, tables[0].d, ywords,
-                                         ycap, meta64 + 6 * B, err, s);
-        if (r) fail(r);
+        const int r = body_end();
+        if (rc) return rc;
+        if (r) return r;
     }
     if (rc) return rc;
     if (dry()) return RGBD_OK;
@@ -3681,14 +3734,9 @@ int rgbd_elic_compress_single(rgbd_elic* m, const float* x_dev, int32_t B, int32
     if (m->variant != 1 || !x_dev || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64) return RGBD_EINVAL;
     if (const int ur = m->use_stream(stream)) return ur;
     const int per_image = (per_image_streams || B == 1) ? 1 : 0;
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_compress1(x_dev, B, H, W, per_image);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    r = m->run_compress1(x_dev, B, H, W, per_image);
+    char key[96];
+    snprintf(key, sizeof(key), "c1|%d|%d|%d|%d", B, H, W, per_image);
+    r = run_sized(m, key, [&]() { return m->run_compress1(x_dev, B, H, W, per_image); });
     if (m->profile) m->profile_collect();
     return r;
 }
@@ -3701,14 +3749,9 @@ int rgbd_elic_forward_single(rgbd_elic* m, const float* x_dev, int32_t B, int32_
     if (m->variant != 1 || !x_dev || !xhat_dev || !lik_y || !lik_z || B <= 0 || H <= 0 || W <= 0 || H % 64 || W % 64)
         return RGBD_EINVAL;
     if (const int ur = m->use_stream(stream)) return ur;
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_forward1(x_dev, B, H, W, xhat_dev, lik_y, lik_z);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    return m->run_forward1(x_dev, B, H, W, xhat_dev, lik_y, lik_z);
+    char key[96];
+    snprintf(key, sizeof(key), "f1|%d|%d|%d", B, H, W);
+    return run_sized(m, key, [&]() { return m->run_forward1(x_dev, B, H, W, xhat_dev, lik_y, lik_z); });
 }
 
 int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int64_t* y_len, int32_t n_y,
@@ -3990,14 +4033,11 @@ int rgbd_elic_forward(rgbd_elic* m, const float* rgb_dev, const float* depth_dev
         H <= 0 || W <= 0 || H % 64 || W % 64)
         return RGBD_EINVAL;
     if (const int ur = m->use_stream(stream)) return ur;
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_forward(rgb_dev, depth_dev, B, H, W, xr_dev, xd_dev, lik_y_rgb, lik_y_depth, lik_z_rgb, lik_z_depth);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    return m->run_forward(rgb_dev, depth_dev, B, H, W, xr_dev, xd_dev, lik_y_rgb, lik_y_depth, lik_z_rgb, lik_z_depth);
+    char key[96];
+    snprintf(key, sizeof(key), "f|%d|%d|%d", B, H, W);
+    return run_sized(m, key, [&]() {
+        return m->run_forward(rgb_dev, depth_dev, B, H, W, xr_dev, xd_dev, lik_y_rgb, lik_y_depth, lik_z_rgb, lik_z_depth);
+    });
 }
 
 int rgbd_elic_stream_count(const rgbd_elic* m, int32_t modality, int32_t kind)

@@ -235,3 +235,21 @@ def test_null_stream_caller_next_to_replaying_side_streams_then_destroy(synth_sd
     del lone
     gc.collect()
     torch.cuda.synchronize()
+
+
+def test_eval_forward_is_captured_and_replayed(net):
+    """ELIC_united.forward() goes through the same prologue / captured body / epilogue split as compress(): eager, captured
+    and replayed calls on a side stream return the same tensors, and new pixels in the same shape come out of the replay."""
+    a, b = _pair(1, 128, 192, 91), _pair(1, 128, 192, 92)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        fa = [net(*a) for _ in range(3)]  # eager (may grow the workspace, which drops older graphs), captured, replayed
+        assert net.graph_count() >= 1
+        fb = net(*b)
+        out = net.compress(*b)
+        rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+    torch.cuda.synchronize()
+    for f in fa[1:]:
+        assert torch.equal(f["x_hat"]["r"], fa[0]["x_hat"]["r"]) and torch.equal(f["d_likelihoods"]["y"], fa[0]["d_likelihoods"]["y"])
+        assert torch.equal(f["r_likelihoods"]["z"], fa[0]["r_likelihoods"]["z"])
+    assert not torch.equal(fb["x_hat"]["r"], fa[0]["x_hat"]["r"])
+    assert torch.equal(fb["x_hat"]["r"].clamp(0, 1), rec["x_hat"]["r"]) and torch.equal(fb["x_hat"]["d"].clamp(0, 1), rec["x_hat"]["d"])
