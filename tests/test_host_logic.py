@@ -309,3 +309,23 @@ def test_codec_pool_refuses_more_instances_than_streams():
 
     with pytest.raises(ValueError, match="at most 32"):
         CodecPool({}, config=rgbd_amd.model_config(), workers=33, device="cuda:0")
+
+
+def test_bench_host_cpu_info_and_worker_rule(tmp_path, monkeypatch):
+    """bench.py's host description (what cpu_baseline reports: model, usable logical / physical CPUs, cgroup quota) and the
+    engine-instance rule it shares with CodecPool through the torch-free sched module."""
+    import importlib.util
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("_bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    info = bench.host_cpu_info()
+    assert info["logical_allowed"] >= 1 and 1 <= info["physical_allowed"] <= info["logical_allowed"]
+    assert isinstance(info["model"], str) and (info["cgroup_cpu_quota"] is None or info["cgroup_cpu_quota"] > 0)
+    from rgbd_amd.pool import balanced_workers
+    from rgbd_amd.sched import balanced_workers as bw2
+
+    assert balanced_workers is bw2
+    assert [bw2(n) for n in (1, 5, 20, 21, 40, 48, 64)] == [1, 5, 20, 11, 20, 16, 16]
