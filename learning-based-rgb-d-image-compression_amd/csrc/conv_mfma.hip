@@ -432,6 +432,23 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                 issue_w2(g + 1);
                 issue_w3(g + 1);
             }
+            // the residual operand of this group's outputs is requested before the group's MFMAs (it depends on the pixel
+            // and the channel group only): its round trip hides behind them instead of sitting in front of the stores
+            constexpr bool PRE = EU2 <= 4;
+            f32x4 r1pre[PRE ? EU2 : 1];
+            if constexpr (PRE) {
+#pragma unroll
+                for (int u = 0; u < EU2; ++u) {
+                    const int f = tid + u * 256;
+                    const int p = f / S42, c4 = f - p * S42;
+                    const int cb = g * (G2 * 16) + c4 * 4;
+                    const int gy = ty0 + (p >> tw_log2), gx = tx0 + (p & (TW - 1));
+                    const bool okp = cb < a.cout_store && gy < a.GH && gx < a.GW;
+                    r1pre[u] = (okp && a.res1)
+                                   ? *reinterpret_cast<const f32x4*>(r1n2 + (size_t)(((unsigned)(gy * a.OW + gx) * (unsigned)a.r1cs + cb) * 4u))
+                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
             f32x4 acc2[G2][NT];
 #pragma unroll
             for (int i = 0; i < G2; ++i)
@@ -480,9 +497,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                     cbs[u] = cb;
                     pixs[u] = (unsigned)(gy * a.OW + gx);
                     v[u] = *reinterpret_cast<const f32x4*>(est + p * SW2 + c4 * 4);
-                    r1[u] = (ok[u] && a.res1)
-                                ? *reinterpret_cast<const f32x4*>(r1n2 + (size_t)((pixs[u] * (unsigned)a.r1cs + cb) * 4u))
-                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (PRE) {
+                        r1[u] = r1pre[u0 + u];
+                    } else {
+                        r1[u] = (ok[u] && a.res1)
+                                    ? *reinterpret_cast<const f32x4*>(r1n2 + (size_t)((pixs[u] * (unsigned)a.r1cs + cb) * 4u))
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < UB2; ++u) {
