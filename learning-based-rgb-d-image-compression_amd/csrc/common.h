@@ -190,6 +190,8 @@ struct DevTables {  // packed CDF rows for the device coder
     const uint32_t* enc;
     // decoder side: the rows as cdf - 1, each padded with 64 entries 0xFFFF; row r starts at row_off[r] + 64 * r
     const uint16_t* cm;
+    // decoder, first level: [nrows][64] slots {0xFFFF - cdf[i] << 16 | 0x10000 - cdf[i + 1]} (low half 0: not resolved here)
+    const uint32_t* pk;
 };
 
 struct PartGeom {

@@ -63,7 +63,9 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     std::vector<uint16_t> packed(total);
     // bucket-table resolution: as fine as fits next to the packed rows in one CU's LDS (160 KiB)
     int bits = 8;
-    while (bits > 4 && (size_t)nrows * ((1u << bits) + 1) * 8 + ((size_t)total + 64 * (size_t)nrows) * 2 > 132 * 1024) --bits;
+    while (bits > 4 &&
+           (size_t)nrows * ((1u << bits) + 1) * 8 + ((size_t)total + 64 * (size_t)nrows) * 2 + (size_t)nrows * 256 > 148 * 1024)
+        --bits;
     const int LN = (1 << bits) + 1;
     std::vector<uint32_t> lut((size_t)nrows * LN * 2);  // {j | row[j] << 16, freq_j}
     for (int r = 0; r < nrows; ++r) {
@@ -119,12 +121,26 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
         const int32_t* row = cdf + (size_t)r * stride;
         for (int j = 0; j < sizes[r] - 1; ++j) cm[(size_t)row_off[r] + 64 * (size_t)r + j] = (uint16_t)(j ? row[j] - 1 : 0);
     }
+    // first-level probe rows: slot i of a row's first 64 as {0xFFFF - cdf[i] << 16 | 0xFFFF - (cdf[i + 1] - 1)}.  One 16-bit
+    // compare of the low halves against 0xFFFF - cum counts the symbols below cum and ONE lane read then yields start and
+    // end of the symbol.  A low half of 0 means "not resolved here": the row's last (escape) slot, the pad behind it, and
+    // slot 63 of a row wider than the 64 lanes (the decoder sends index 63 to the bucket table, which knows which it is).
+    std::vector<uint32_t> pk((size_t)nrows * 64, 0u);
+    for (int r = 0; r < nrows; ++r) {
+        const int32_t* row = cdf + (size_t)r * stride;
+        const int n = sizes[r] - 1;  // slots
+        for (int j = 0; j < n && j < 64; ++j) {
+            const uint32_t end = (j == 63 && n > 64) ? 0xFFFFu : (uint32_t)(row[j + 1] - 1);
+            pk[(size_t)r * 64 + j] = ((0xFFFFu - (uint32_t)row[j]) << 16) | (0xFFFFu - end);
+        }
+    }
     const size_t b_cm = (cm.size() * 2 + 15) & ~(size_t)15;
+    const size_t b_pk = pk.size() * 4;
     const size_t b_enc = (size_t)total * 16;
     const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
     const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
-    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm;
+    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk;
     ts->blob = nullptr;  // a previous blob stays with its owner (TableSet::hold / rgbd_tables_destroy)
     ts->ready = false;
     HIP_TRY(hipMalloc(&ts->blob, bytes));
@@ -137,6 +153,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);
     memcpy(p + b_cdf + b_lut + 3 * b_i32, enc.data(), b_enc);
     memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc, cm.data(), cm.size() * 2);
+    memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm, pk.data(), b_pk);
     HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
     unsigned char* dp = (unsigned char*)ts->blob;
     ts->d.cdf = (const uint16_t*)dp;
@@ -147,6 +164,7 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     ts->d.offsets = (const int32_t*)(dp + b_cdf + b_lut + 2 * b_i32);
     ts->d.enc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32);
     ts->d.cm = (const uint16_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc);
+    ts->d.pk = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm);
     ts->d.nrows = nrows;
     ts->d.total = total;
     ts->ready = true;

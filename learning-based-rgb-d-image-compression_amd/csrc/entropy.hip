@@ -834,6 +834,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     // "entry < cum" is then "cdf <= cum" for every lane of a 64-wide probe, pads included, and a probe that runs into
     // the pad has found the row's last (= escape) slot.  Row r starts at row_off[r] + 64 * r.
     uint16_t* cm = reinterpret_cast<uint16_t*>(rowinfo + ((t.nrows + 1) & ~1));           // [t.total + 64 * nrows]
+    // pk: the first 64 slots of every row as {cdf[i] << 16 | cdf[i + 1] - 1} (build_tables): the hot loop's only table
+    uint32_t* pk = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cm) +
+                                               (((size_t)(t.total + 64 * t.nrows) * 2 + 15) & ~(size_t)15));  // [nrows][64]
 
     // Four streams per workgroup, one per wavefront (each on its own SIMD): the ~125 KB of tables in LDS are shared, so a
     // decode launch of 16 streams holds 4 CUs' LDS instead of 16 (a conv workgroup cannot co-reside with these tables).
@@ -846,6 +849,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         const uint4* gcm = reinterpret_cast<const uint4*>(t.cm);
         uint4* lcm = reinterpret_cast<uint4*>(cm);
         for (int i = tid; i < ncm16; i += 256) lcm[i] = gcm[i];
+        const uint4* gpk = reinterpret_cast<const uint4*>(t.pk);
+        uint4* lpk = reinterpret_cast<uint4*>(pk);
+        for (int i = tid; i < t.nrows * 16; i += 256) lpk[i] = gpk[i];
         const uint2* gl = reinterpret_cast<const uint2*>(t.lut);  // bucket entries (escape candidates carry frequency 0)
         for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = gl[i];
     }
@@ -902,96 +908,103 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     typedef __attribute__((address_space(3))) const uint2 lds_u2;
     const uint32_t dsm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm;
     const uint32_t cm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)cm;
-    const uint32_t lane2 = (uint32_t)lane * 2u;
+    const uint32_t pk_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)pk;
+    const uint32_t lane2 = (uint32_t)lane * 2u, lane4 = (uint32_t)lane * 4u;
 
+    // A batch is 64 symbols, one per lane; a shorter (last) batch sits in the TOP lanes (symbol k in lane k + 64 - cnt),
+    // so that the loop counter always ends at lane 64: m0 = lane - 64 then wraps to 0 with a carry, and the increment is
+    // the loop test.
     const int64_t nb = (count + 63) >> 6;
-    int ti_next = (lane < count) ? idx[base + lane] : 0;
+    auto load_ti = [&](int64_t bb) -> int {
+        const int64_t rem = count - bb * 64;
+        const int sh_ = rem < 64 ? 64 - (int)rem : 0;
+        return lane >= sh_ ? idx[base + bb * 64 + lane - sh_] : 0;
+    };
+    int ti_next = load_ti(0);
     for (int64_t b = 0; b < nb; ++b) {
         const int cnt = (int)((count - b * 64) < 64 ? (count - b * 64) : 64);
+        const int sh = 64 - cnt;
         const int ti = ti_next;
         const uint32_t lutbase = dsm_addr + (uint32_t)(ti * lut_n) * 8u;  // LDS address of this lane's symbol's bucket row
         const uint2 rinfo = rowinfo[ti];  // this lane's row: {start : 16 | cdf_length : 16}, {offset : 16}
         const uint32_t rowbase = cm_addr + (rinfo.x & 0xFFFFu) * 2u;  // LDS address of the row in cm
+        const uint32_t pkrow = pk_addr + (uint32_t)ti * 256u;         // ... and of its first-level slots
+        // the same for the NEXT lane's symbol: the loop prefetches symbol m0 + 1's slots with lane select m0
+        const uint32_t pkn = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)pkrow);
         uint32_t outv = 0;
-        int j = 0;
+        int j = sh;
         realign();  // before the prefetch below: its wait then only covers loads issued a whole batch ago
-        if (b + 1 < nb) ti_next = ((b + 1) * 64 + lane < count) ? idx[base + (b + 1) * 64 + lane] : 0;  // prefetch
-        while (j < cnt) {
-            // hot loop: symbols the bucket entry resolves in one read.  The word window is loop-invariant here; anything
-            // else (a symbol boundary inside the bucket, the escape slot) leaves the loop, is finished below and the loop
-            // is re-entered behind it.
-            // Written in ISA: the loop is one dependent scalar chain (x -> bucket address -> LDS -> x) and every
-            // instruction the compiler adds for control flow costs a full issue slot of the only wave.
-            //   s[84:85] = x, s[86:87] = scratch pair, v[62:63] = bucket entry
+        if (b + 1 < nb) ti_next = load_ti(b + 1);  // prefetch
+        while (j < 64) {
+            // hot loop: symbols the first level resolves.  The word window is loop-invariant here; anything else (a row
+            // wider than the lanes, an unusual escape) leaves the loop, is finished below and the loop is re-entered
+            // behind it.
+            // Written in ISA: the loop is one dependent scalar chain (x -> cum -> slot -> x) and every instruction costs
+            // a full issue slot of the only wave (~3 ns, measured one at a time), so it is kept as short as it gets:
+            // 29 instructions per symbol.  The tricks that got it there: the slot word holds complements (cumc = 0xFFFF &
+            // ~x is one instruction, and "end == 0xFFFF" -- the escape slot -- falls out of the s_and that extracts the
+            // low half as SCC = 0); s_lshr_b64 sets SCC = (result != 0), which IS the "no renormalisation" flag; the
+            // loop counter's increment is the loop test (above).
+            //   s[84:85] = x, s[86:87] = scratch pair, s[88:89] = the escape block's copy of x, v58 = slots, v60 = address
             uint32_t a, start, freq, cum, more;
             {
                 uint32_t lb, t0, t1, e0, m0s, wn;
                 asm volatile(
                     "s_mov_b64 s[84:85], %[x]\n"
                     "s_mov_b32 %[m0s], m0\n"
-                    "s_mov_b32 m0, %[j]\n"
-                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"
-                    "s_cmp_ge_i32 m0, %[cnt]\n"
-                    "s_cbranch_scc1 3f\n"
-                    // First level: every lane holds one slot of the symbol's padded cm row (cm = cdf - 1, 0xFFFF
-                    // pad), loaded one symbol AHEAD so the LDS hop overlaps the previous symbol's update.
-                    "v_readlane_b32 %[lb], %[rowbase], m0\n"
-                    "v_add_u32 v60, %[lb], %[lane2]\n"
-                    "ds_read_u16 v58, v60 offset:2\n"
-                    // The loop is bound by the issue rate of the one wave (~3 ns per instruction, measured: every
-                    // instruction removed takes 3 ns off a symbol), so it is kept as short as it gets.
+                    "s_sub_u32 m0, %[j], 64\n"                  // lane - 64 (lane selects use the low six bits)
+                    // First level: every lane holds one slot of the symbol's pk row, loaded one symbol AHEAD so the LDS
+                    // hop overlaps the previous symbol's update.
+                    "v_readlane_b32 %[lb], %[pkrow], m0\n"
+                    "v_add_u32 v60, %[lb], %[lane4]\n"
+                    "ds_read_b32 v58, v60\n"
                     "1:\n"
-                    "s_waitcnt lgkmcnt(0)\n"                    // v58: this symbol's row slots (prefetched at 6: below)
-                    "s_and_b32 %[cum], s84, 0xffff\n"
-                    "v_cmp_gt_u32 vcc, %[cum], v58\n"           // lanes with cdf[i+1] <= cum
-                    "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index when it is < 64
-                    "s_cmp_eq_u32 %[a], 64\n"
-                    "s_cbranch_scc1 60f\n"                      // beyond the first 64 slots: bucket table
-                    "s_sub_u32 %[t0], %[a], 1\n"
-                    "v_readlane_b32 %[t1], v58, %[a]\n"         // cdf[a+1]-1
-                    "v_readlane_b32 %[t0], v58, %[t0]\n"        // cdf[a]-1 (a == 0: lane select -1 reads some lane; -1 below)
-                    "s_cmp_eq_u32 %[a], 0\n"
-                    "s_cselect_b32 %[t0], -1, %[t0]\n"
-                    "s_cmp_eq_u32 %[t1], 0xffff\n"              // cdf[a+1] == 65536: last slot = escape
-                    "s_cbranch_scc1 61f\n"
-                    "s_sub_u32 %[freq], %[t1], %[t0]\n"
-                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
-                    "s_sub_u32 %[t0], %[t0], 1\n"               // cum - start
+                    "s_waitcnt lgkmcnt(0)\n"                    // v58: this symbol's row slots (prefetched below)
+                    "s_andn2_b32 %[cum], 0xffff, s84\n"         // cumc = 0xFFFF - cum
+                    "v_cmp_lt_u16 vcc, %[cum], v58\n"           // low halves: cumc < 0x10000 - cdf[i+1]  <=>  cdf[i+1] <= cum
+                    // (the mask takes ~7 ns to reach the scalar unit and the lane read below as long to come back: work
+                    // that does not depend on them is placed in those shadows, where it is free)
+                    "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x >> 16 for the update below
+                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"  // next unread word (lane 64 wraps: never used then)
+                    "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index, <= 63 (a low half of 0 never compares)
+                    "v_readlane_b32 %[t1], v58, %[a]\n"
+                    // the row slots are dead from here on: the next symbol's row goes straight into v58 (lane 63's
+                    // successor is lane 0: a valid row, value unused), its LDS hop overlaps the state update below
+                    "v_readlane_b32 %[lb], %[pkn], m0\n"
+                    "v_writelane_b32 %[outv], %[a], m0\n"      // (the out-of-line paths write their symbol over it)
+                    "v_add_u32 v60, %[lb], %[lane4]\n"
+                    "ds_read_b32 v58, v60\n"
+                    "s_lshr_b32 %[start], %[t1], 16\n"          // 0xFFFF - cdf[a]
+                    "s_and_b32 %[t0], %[t1], 0xffff\n"          // 0x10000 - cdf[a+1]; SCC = 0: not resolved here
+                    "s_cbranch_scc0 61f\n"
+                    "s_sub_u32 %[freq], %[start], %[t0]\n"
+                    "s_add_u32 %[freq], %[freq], 1\n"
+                    "s_sub_u32 %[t0], %[start], %[cum]\n"       // cum - cdf[a]
                     "6:\n"
-                    // the row slots are dead from here on: the next symbol's row goes straight into v58 (lane 64 wraps
-                    // to lane 0: a valid row, value unused), its LDS hop overlaps the state update below
-                    "s_add_u32 %[t1], m0, 1\n"
-                    "v_readlane_b32 %[lb], %[rowbase], %[t1]\n"
-                    "v_add_u32 v60, %[lb], %[lane2]\n"
-                    "ds_read_u16 v58, v60 offset:2\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x = freq * (x >> 16) + (cum - start)
-                    "s_mul_i32 %[t1], s87, %[freq]\n"
+                    "s_mul_i32 %[t1], s87, %[freq]\n"           // x = freq * (x >> 16) + (cum - start)
                     "s_mul_hi_u32 s85, s86, %[freq]\n"
                     "s_mul_i32 s84, s86, %[freq]\n"
                     "s_add_u32 %[t1], %[t1], s85\n"
                     "s_add_u32 s84, s84, %[t0]\n"
                     "s_addc_u32 s85, %[t1], 0\n"
-                    "v_writelane_b32 %[outv], %[a], m0\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 31\n"      // renormalise when x < 2^31, branch-free: wn = next word
-                    "s_cmp_eq_u64 s[86:87], 0\n"
-                    "s_cselect_b32 s85, s84, s85\n"
-                    "s_cselect_b32 s84, %[wn], s84\n"
-                    "s_addc_u32 %[wi], %[wi], 0\n"             // consumed: advance
+                    "s_lshr_b64 s[86:87], s[84:85], 31\n"      // SCC = (x >= 2^31): keep; else x = x << 32 | next word
+                    "s_cselect_b32 s85, s85, s84\n"
+                    "s_cselect_b32 s84, s84, %[wn]\n"
+                    "s_subb_u32 %[wi], %[wi], -1\n"            // consumed (SCC = 0): advance
                     "4:\n"
-                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"  // next unread word (lane 64 wraps: never used then)
-                    "s_add_u32 m0, m0, 1\n"
-                    "s_cmp_lt_i32 m0, %[cnt]\n"
-                    "s_cbranch_scc1 1b\n"
-                    "3:\n"
+                    "s_add_u32 m0, m0, 1\n"                    // carries out of lane 63: batch done
+                    "s_cbranch_scc0 1b\n"
                     "s_mov_b32 %[more], 0\n"
                     "s_branch 5f\n"
                     // out of line: the row's last slot (escape) and rows wider than the 64 lanes (bucket table)
                     "61:\n"
-                    "s_sub_u32 %[freq], 0xffff, %[t0]\n"
-                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
-                    "s_sub_u32 %[t0], %[t0], 1\n"
+                    "s_cmp_eq_u32 %[a], 63\n"                  // slot 63: the escape slot of a 64-slot row or the rest of a
+                    "s_cbranch_scc1 60f\n"                     // wider one -- the bucket table tells
+                    "s_add_u32 %[freq], %[start], 1\n"         // 0x10000 - cdf[a]
+                    "s_sub_u32 %[t0], %[start], %[cum]\n"
                     "s_branch 73f\n"
                     "60:\n"
+                    "s_and_b32 %[cum], s84, 0xffff\n"
                     "v_readlane_b32 %[lb], %[lutbase], m0\n"
                     "s_lshr_b32 %[t0], %[cum], %[shift]\n"
                     "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n"
@@ -1005,6 +1018,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_and_b32 %[a], %[e0], 0xffff\n"
                     "s_cmp_ge_u32 %[t0], %[freq]\n"
                     "s_cbranch_scc1 2f\n"
+                    "v_writelane_b32 %[outv], %[a], m0\n"
                     "s_branch 6b\n"
                     // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
                     // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
@@ -1032,10 +1046,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_sub_u32 %[freq], %[lb], %[t0]\n"
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
                     "s_sub_u32 %[t0], %[t0], 1\n"             // cum - start
+                    "v_writelane_b32 %[outv], %[a], m0\n"
                     "s_branch 6b\n"
-                    // escape (rans_interface.cpp:323-345).  Worked on a copy of the state (s[88:89], word index in lb) and
-                    // committed at the end; an unusual shape (count nibble > 8, window nearly used up) leaves to the C++
-                    // path with the committed state untouched.  Temporaries: e0 = nibbles left, start = raw, cum = shift.
                     "71:\n"
                     "s_sub_u32 %[t0], %[cum], %[start]\n"
                     "s_sub_u32 %[freq], 0x10000, %[start]\n"
@@ -1045,14 +1057,17 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_sub_u32 %[freq], 0xffff, %[t0]\n"
                     "s_sub_u32 %[t0], %[cum], %[t0]\n"
                     "s_sub_u32 %[t0], %[t0], 1\n"
+                    // escape (rans_interface.cpp:323-345): a = the escape slot, freq / t0 = its table step.  Worked on a
+                    // copy of the state (s[88:89], word index in lb, %[cum] = the next unread word) and committed at the
+                    // end; a count nibble of 15 (more than 8 payload nibbles follow) or a nearly used-up word window
+                    // leaves to the C++ path with the committed state untouched.  Straight-line: every renormalisation is
+                    // a pair of selects on the SCC of the s_lshr_b64 that tests it (a taken branch costs 8-17 ns on a lone
+                    // wave, an ALU instruction ~3).  The nn <= 8 payload nibbles are taken in two steps at most, because
+                    // the state can run dry only once in between: after k = (bits(x) - 28) >> 2 nibbles it is below 2^31
+                    // and takes in a word w, and the other nn - k <= 7 nibbles are then w's low bits, which cannot bring
+                    // it (>= 2^59 after the word) below 2^31 again.  Step A takes min(k, nn) nibbles and renormalises if
+                    // needed, step B the rest.
                     "73:\n"
-                    // Straight-line common case (round 3): the state update, the count nibble and -- when the state is large
-                    // enough that none of the first nn - 1 payload steps can drop it below 2^31 (x >= 2^(27 + 4 nn): three
-                    // escapes in four) -- all payload nibbles at once, with the three possible renormalisations done by
-                    // selects instead of branches (a taken branch costs 8-17 ns on a lone wave, an ALU instruction ~3).
-                    // %[cum] holds the next unread word of the copy's window position %[lb]; anything unusual (count
-                    // nibble > 8, window nearly used up) leaves for the generic path with the committed state untouched,
-                    // a state too small for the one-shot payload takes the nibble-by-nibble loop at 74.
                     "s_cmp_gt_u32 %[wi], 56\n"
                     "s_cbranch_scc1 8f\n"
                     "s_lshr_b64 s[86:87], s[84:85], 16\n"
@@ -1063,95 +1078,49 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_add_u32 s88, s88, %[t0]\n"
                     "s_addc_u32 s89, %[t1], 0\n"
                     "s_lshr_b64 s[86:87], s[88:89], 31\n"     // renormalise after the escape symbol: wn = word wi
-                    "s_cmp_eq_u64 s[86:87], 0\n"
-                    "s_cselect_b32 s89, s88, s89\n"
-                    "s_cselect_b32 s88, %[wn], s88\n"
-                    "s_addc_u32 %[lb], %[wi], 0\n"
+                    "s_cselect_b32 s89, s89, s88\n"
+                    "s_cselect_b32 s88, s88, %[wn]\n"
+                    "s_subb_u32 %[lb], %[wi], -1\n"
                     "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
-                    "s_and_b32 %[e0], s88, 15\n"              // count nibble
+                    "s_and_b32 %[e0], s88, 15\n"              // count nibble nn
                     "s_lshr_b64 s[88:89], s[88:89], 4\n"
                     "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cmp_eq_u64 s[86:87], 0\n"
-                    "s_cselect_b32 s89, s88, s89\n"
-                    "s_cselect_b32 s88, %[cum], s88\n"
-                    "s_addc_u32 %[lb], %[lb], 0\n"
-                    "s_cmp_gt_u32 %[e0], 7\n"
-                    "s_cbranch_scc1 79f\n"                    // nn = 8: step by step; a longer count: generic path
-                    "s_lshl_b32 %[t1], %[e0], 2\n"            // bits = 4 nn (nn = 0: no payload, raw = 0)
-                    "s_add_u32 %[t0], %[t1], 27\n"
-                    "s_lshr_b64 s[86:87], s[88:89], %[t0]\n"
-                    "s_cmp_eq_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 78f\n"                    // too small: step by step
+                    "s_cselect_b32 s89, s89, s88\n"
+                    "s_cselect_b32 s88, s88, %[cum]\n"
+                    "s_subb_u32 %[lb], %[lb], -1\n"
+                    "s_cmp_gt_u32 %[e0], 8\n"
+                    "s_cbranch_scc1 8f\n"                     // a longer count: generic path
                     "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
-                    "s_bfm_b32 %[t0], %[t1], 0\n"
-                    "s_and_b32 %[start], s88, %[t0]\n"        // raw
+                    "s_flbit_i32_b64 %[t0], s[88:89]\n"       // leading zeros (<= 32)
+                    "s_sub_u32 %[t0], 36, %[t0]\n"
+                    "s_lshr_b32 %[t0], %[t0], 2\n"            // k
+                    "s_min_u32 %[t0], %[t0], %[e0]\n"         // step A: k' = min(k, nn) nibbles
+                    "s_lshl_b32 %[t1], %[t0], 2\n"
+                    "s_bfm_b64 s[86:87], %[t1], 0\n"
+                    "s_and_b32 %[start], s88, s86\n"          // raw, low part
                     "s_lshr_b64 s[88:89], s[88:89], %[t1]\n"
                     "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cmp_eq_u64 s[86:87], 0\n"
-                    "s_cselect_b32 s89, s88, s89\n"
-                    "s_cselect_b32 s88, %[cum], s88\n"
-                    "s_addc_u32 %[lb], %[lb], 0\n"
+                    "s_cselect_b32 s89, s89, s88\n"
+                    "s_cselect_b32 s88, s88, %[cum]\n"
+                    "s_subb_u32 %[lb], %[lb], -1\n"
+                    "s_sub_u32 %[e0], %[e0], %[t0]\n"         // step B: the other nn - k' (<= 7; 0 unless A renormalised)
+                    "s_lshl_b32 %[e0], %[e0], 2\n"
+                    "s_bfm_b32 %[t0], %[e0], 0\n"
+                    "s_and_b32 %[t0], s88, %[t0]\n"
+                    "s_lshr_b64 s[88:89], s[88:89], %[e0]\n"
+                    "s_lshl_b32 %[t0], %[t0], %[t1]\n"        // (k' = 8: this part is 0 and so is the 5-bit shift count)
+                    "s_or_b32 %[start], %[start], %[t0]\n"    // raw
                     "s_lshr_b32 %[t1], %[start], 1\n"         // value: even raw -> last + raw / 2, odd -> -(raw >> 1) - 1
                     "s_add_u32 %[t0], %[t1], %[a]\n"
                     "s_not_b32 %[t1], %[t1]\n"
                     "s_bitcmp1_b32 %[start], 0\n"
                     "s_cselect_b32 %[t1], %[t1], %[t0]\n"
-                    "v_writelane_b32 %[outv], %[t1], m0\n"    // (the tail of 77: below, inlined: no taken branch on this path)
-                    "s_mov_b64 s[84:85], s[88:89]\n"
-                    "s_mov_b32 %[wi], %[lb]\n"
-                    "s_add_u32 %[lb], m0, 1\n"
-                    "v_readlane_b32 %[lb], %[rowbase], %[lb]\n"
-                    "v_add_u32 v60, %[lb], %[lane2]\n"
-                    "ds_read_u16 v58, v60 offset:2\n"
-                    "s_sub_u32 %[t0], %[cnt], m0\n"
-                    "s_add_u32 %[t0], %[t0], %[wi]\n"
-                    "s_cmp_le_u32 %[t0], 65\n"
-                    "s_cbranch_scc1 4b\n"
-                    "s_add_u32 m0, m0, 1\n"
-                    "s_mov_b32 %[more], 2\n"
-                    "s_branch 5f\n"
-                    "79:\n"
-                    "s_cmp_gt_u32 %[e0], 8\n"
-                    "s_cbranch_scc1 8f\n"
-                    "78:\n"
-                    "s_mov_b32 %[start], 0\n"
-                    "s_mov_b32 %[cum], 0\n"
-                    "74:\n"
-                    "s_cmp_eq_u32 %[e0], 0\n"
-                    "s_cbranch_scc1 75f\n"
-                    "s_and_b32 %[t1], s88, 15\n"
-                    "s_lshl_b32 %[t1], %[t1], %[cum]\n"
-                    "s_or_b32 %[start], %[start], %[t1]\n"
-                    "s_add_u32 %[cum], %[cum], 4\n"
-                    "s_lshr_b64 s[88:89], s[88:89], 4\n"
-                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cmp_lg_u64 s[86:87], 0\n"
-                    "s_cbranch_scc1 91f\n"
-                    "s_mov_b32 s89, s88\n"
-                    "v_readlane_b32 s88, %[wcur], %[lb]\n"
-                    "s_add_u32 %[lb], %[lb], 1\n"
-                    "91:\n"
-                    "s_sub_u32 %[e0], %[e0], 1\n"
-                    "s_branch 74b\n"
-                    "75:\n"
-                    "s_lshr_b32 %[t1], %[start], 1\n"          // raw >> 1
-                    "s_bitcmp1_b32 %[start], 0\n"
-                    "s_cbranch_scc1 76f\n"
-                    "s_add_u32 %[t1], %[t1], %[a]\n"          // even: value = last + raw / 2
-                    "s_branch 77f\n"
-                    "76:\n"
-                    "s_not_b32 %[t1], %[t1]\n"                // odd: value = -(raw >> 1) - 1
-                    "77:\n"
                     "v_writelane_b32 %[outv], %[t1], m0\n"
                     "s_mov_b64 s[84:85], s[88:89]\n"           // commit
                     "s_mov_b32 %[wi], %[lb]\n"
-                    "s_add_u32 %[lb], m0, 1\n"                 // (this path does not pass 6: -- prefetch the next row here)
-                    "v_readlane_b32 %[lb], %[rowbase], %[lb]\n"
-                    "v_add_u32 v60, %[lb], %[lane2]\n"
-                    "ds_read_u16 v58, v60 offset:2\n"
-                    "s_sub_u32 %[t0], %[cnt], m0\n"           // rest of the batch still inside the word window?
+                    "s_not_b32 %[t0], m0\n"                    // symbols left behind this one: do they fit the word window?
                     "s_add_u32 %[t0], %[t0], %[wi]\n"
-                    "s_cmp_le_u32 %[t0], 65\n"
+                    "s_cmp_le_u32 %[t0], 64\n"
                     "s_cbranch_scc1 4b\n"
                     "s_add_u32 m0, m0, 1\n"                   // no: hand the realign to the caller (symbol is done)
                     "s_mov_b32 %[more], 2\n"
@@ -1161,13 +1130,13 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "5:\n"
                     "s_waitcnt lgkmcnt(0)\n"                    // drain the row prefetch
                     "s_mov_b64 %[x], s[84:85]\n"
-                    "s_mov_b32 %[j], m0\n"
+                    "s_add_u32 %[j], m0, 64\n"
                     "s_mov_b32 m0, %[m0s]\n"
                     : [x] "+s"(x), [j] "+s"(j), [wi] "+s"(wi), [outv] "+v"(outv), [a] "=&s"(a), [start] "=&s"(start),
                       [freq] "=&s"(freq), [cum] "=&s"(cum), [more] "=&s"(more), [lb] "=&s"(lb), [t0] "=&s"(t0),
                       [t1] "=&s"(t1), [e0] "=&s"(e0), [m0s] "=&s"(m0s), [wn] "=&s"(wn)
-                    : [cnt] "s"(cnt), [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
-                      [lane2] "v"(lane2)
+                    : [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
+                      [lane2] "v"(lane2), [pkrow] "v"(pkrow), [pkn] "v"(pkn), [lane4] "v"(lane4)
                     : "s84", "s85", "s86", "s87", "s88", "s89", "v58", "v59", "v60", "v62", "v63", "vcc", "scc", "memory");
             }
             more = rfl(more);
@@ -1234,14 +1203,14 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 else v += last;
                 // an escape may have used many words: restore the window invariant -- but only when the rest of the
                 // batch (one word per symbol at most) could run past lane 63; a realign waits for a fresh global load
-                if (wi + (cnt - 1 - j) > 64) realign();
+                if (wi + (63 - j) > 64) realign();
             }
             outv = wrl((uint32_t)v, j, outv);
             ++j;
         }
         // table offset of each symbol (entropy_models' _offset) added by its own lane, then one coalesced store
         const int off = (int)(int16_t)(rinfo.y & 0xFFFFu);
-        if (lane < cnt) sym[base + b * 64 + lane] = (int32_t)outv + off;
+        if (lane >= sh) sym[base + b * 64 + lane - sh] = (int32_t)outv + off;
     }
     if (lane == 0) {
         state[2 * s] = x;
@@ -1253,7 +1222,7 @@ size_t rans_decode_lds_bytes(const DevTables& t)
 {
     const size_t lut_n = ((size_t)1 << t.lut_bits) + 1;
     return (((size_t)t.nrows * lut_n + 1) & ~(size_t)1) * 8 + (((size_t)t.nrows + 1) & ~(size_t)1) * 8 +
-           ((((size_t)t.total + 64 * (size_t)t.nrows) * 2 + 15) & ~(size_t)15);
+           ((((size_t)t.total + 64 * (size_t)t.nrows) * 2 + 15) & ~(size_t)15) + (size_t)t.nrows * 256;
 }
 
 int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,
