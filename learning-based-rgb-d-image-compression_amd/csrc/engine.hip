@@ -130,8 +130,11 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
         const int32_t* row = cdf + (size_t)r * stride;
         const int n = sizes[r] - 1;  // slots
         for (int j = 0; j < n && j < 64; ++j) {
-            const uint32_t end = (j == 63 && n > 64) ? 0xFFFFu : (uint32_t)(row[j + 1] - 1);
-            pk[(size_t)r * 64 + j] = ((0xFFFFu - (uint32_t)row[j]) << 16) | (0xFFFFu - end);
+            if (j == 63 && n > 64) {  // the rest of a wide row: the identity step (freq 65536, start 0)
+                pk[(size_t)r * 64 + j] = 0xFFFF0000u;
+                continue;
+            }
+            pk[(size_t)r * 64 + j] = ((0xFFFFu - (uint32_t)row[j]) << 16) | (0x10000u - (uint32_t)row[j + 1]);
         }
     }
     const size_t b_cm = (cm.size() * 2 + 15) & ~(size_t)15;

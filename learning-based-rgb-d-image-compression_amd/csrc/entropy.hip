@@ -939,12 +939,17 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
             // hot loop: symbols the first level resolves.  The word window is loop-invariant here; anything else (a row
             // wider than the lanes, an unusual escape) leaves the loop, is finished below and the loop is re-entered
             // behind it.
-            // Written in ISA: the loop is one dependent scalar chain (x -> cum -> slot -> x) and every instruction costs
-            // a full issue slot of the only wave (~3 ns, measured one at a time), so it is kept as short as it gets:
-            // 29 instructions per symbol.  The tricks that got it there: the slot word holds complements (cumc = 0xFFFF &
-            // ~x is one instruction, and "end == 0xFFFF" -- the escape slot -- falls out of the s_and that extracts the
-            // low half as SCC = 0); s_lshr_b64 sets SCC = (result != 0), which IS the "no renormalisation" flag; the
-            // loop counter's increment is the loop test (above).
+            // Written in ISA.  The loop is one dependent chain (x -> cum -> slot -> x) run by a lone wave, and what it
+            // costs was measured one piece at a time (knock-out builds, tools/ko_probe.py): ~2 ns of issue per scalar
+            // instruction, 3-6 per vector one, ~9 per branch, taken or not.  So: 31 instructions and ONE branch per symbol
+            // -- the loop edge, whose condition also carries "this was an escape slot": the escape slot and slot 63 of a
+            // wider row take the ordinary update too (for the latter the slot encodes the identity step, freq = 65536,
+            // start = 0) and are told apart after the loop has been left.  The slot word holds complements so that
+            // cumc = 0xFFFF & ~x is one instruction and the s_and that splits the word yields "not resolved" as 0;
+            // s_lshr_b64 sets SCC = (result != 0), which IS the "no renormalisation" flag; the loop counter's increment
+            // (lane - 64, so it carries out of lane 63) and the escape flag meet in one s_subb.  (v_cmpx + v_readfirstlane
+            // instead of v_cmp / s_bcnt1 / v_readlane was built too: two more instructions and a wait -- the lane read
+            // sees the old EXEC for 4 cycles, tools/ubench/cmpx_first.hip -- for no gain.)
             //   s[84:85] = x, s[86:87] = scratch pair, s[88:89] = the escape block's copy of x, v58 = slots, v60 = address
             uint32_t a, start, freq, cum, more;
             {
@@ -953,34 +958,29 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_mov_b64 s[84:85], %[x]\n"
                     "s_mov_b32 %[m0s], m0\n"
                     "s_sub_u32 m0, %[j], 64\n"                  // lane - 64 (lane selects use the low six bits)
-                    // First level: every lane holds one slot of the symbol's pk row, loaded one symbol AHEAD so the LDS
-                    // hop overlaps the previous symbol's update.
                     "v_readlane_b32 %[lb], %[pkrow], m0\n"
                     "v_add_u32 v60, %[lb], %[lane4]\n"
                     "ds_read_b32 v58, v60\n"
                     "1:\n"
-                    "s_waitcnt lgkmcnt(0)\n"                    // v58: this symbol's row slots (prefetched below)
+                    "s_waitcnt lgkmcnt(0)\n"                    // v58: this symbol's row slots (loaded one symbol ahead)
                     "s_andn2_b32 %[cum], 0xffff, s84\n"         // cumc = 0xFFFF - cum
                     "v_cmp_lt_u16 vcc, %[cum], v58\n"           // low halves: cumc < 0x10000 - cdf[i+1]  <=>  cdf[i+1] <= cum
-                    // (the mask takes ~7 ns to reach the scalar unit and the lane read below as long to come back: work
-                    // that does not depend on them is placed in those shadows, where it is free)
                     "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x >> 16 for the update below
-                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"  // next unread word (lane 64 wraps: never used then)
                     "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index, <= 63 (a low half of 0 never compares)
-                    "v_readlane_b32 %[t1], v58, %[a]\n"
+                    "v_readlane_b32 %[t1], v58, %[a]\n"         // {0xFFFF - cdf[a] << 16 | 0x10000 - cdf[a+1]}
                     // the row slots are dead from here on: the next symbol's row goes straight into v58 (lane 63's
                     // successor is lane 0: a valid row, value unused), its LDS hop overlaps the state update below
                     "v_readlane_b32 %[lb], %[pkn], m0\n"
-                    "v_writelane_b32 %[outv], %[a], m0\n"      // (the out-of-line paths write their symbol over it)
+                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"  // next unread word (lane 64 wraps: never used then)
+                    "v_writelane_b32 %[outv], %[a], m0\n"      // (an escape's value is written over it)
                     "v_add_u32 v60, %[lb], %[lane4]\n"
                     "ds_read_b32 v58, v60\n"
-                    "s_lshr_b32 %[start], %[t1], 16\n"          // 0xFFFF - cdf[a]
-                    "s_and_b32 %[t0], %[t1], 0xffff\n"          // 0x10000 - cdf[a+1]; SCC = 0: not resolved here
-                    "s_cbranch_scc0 61f\n"
-                    "s_sub_u32 %[freq], %[start], %[t0]\n"
+                    "s_lshr_b32 %[start], %[t1], 16\n"
+                    "s_and_b32 %[e0], %[t1], 0xffff\n"          // 0: not resolved here (escape slot / wide row)
+                    "s_min_u32 %[lb], %[e0], 1\n"               // ... as 0 / 1 for the loop test
+                    "s_sub_u32 %[freq], %[start], %[e0]\n"
                     "s_add_u32 %[freq], %[freq], 1\n"
                     "s_sub_u32 %[t0], %[start], %[cum]\n"       // cum - cdf[a]
-                    "6:\n"
                     "s_mul_i32 %[t1], s87, %[freq]\n"           // x = freq * (x >> 16) + (cum - start)
                     "s_mul_hi_u32 s85, s86, %[freq]\n"
                     "s_mul_i32 s84, s86, %[freq]\n"
@@ -991,105 +991,37 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_cselect_b32 s85, s85, s84\n"
                     "s_cselect_b32 s84, s84, %[wn]\n"
                     "s_subb_u32 %[wi], %[wi], -1\n"            // consumed (SCC = 0): advance
-                    "4:\n"
                     "s_add_u32 m0, m0, 1\n"                    // carries out of lane 63: batch done
+                    "s_subb_u32 %[lb], %[lb], 1\n"             // borrows (0 - 1, or 1 - 1 - carry) when either holds: leave
                     "s_cbranch_scc0 1b\n"
-                    "s_mov_b32 %[more], 0\n"
-                    "s_branch 5f\n"
-                    // out of line: the row's last slot (escape) and rows wider than the 64 lanes (bucket table)
-                    "61:\n"
-                    "s_cmp_eq_u32 %[a], 63\n"                  // slot 63: the escape slot of a 64-slot row or the rest of a
-                    "s_cbranch_scc1 60f\n"                     // wider one -- the bucket table tells
-                    "s_add_u32 %[freq], %[start], 1\n"         // 0x10000 - cdf[a]
-                    "s_sub_u32 %[t0], %[start], %[cum]\n"
-                    "s_branch 73f\n"
-                    "60:\n"
-                    "s_and_b32 %[cum], s84, 0xffff\n"
-                    "v_readlane_b32 %[lb], %[lutbase], m0\n"
-                    "s_lshr_b32 %[t0], %[cum], %[shift]\n"
-                    "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n"
-                    "v_mov_b32 v62, %[lb]\n"
-                    "ds_read_b64 v[62:63], v62\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_readfirstlane_b32 %[e0], v62\n"
-                    "v_readfirstlane_b32 %[freq], v63\n"
-                    "s_lshr_b32 %[start], %[e0], 16\n"
-                    "s_sub_u32 %[t0], %[cum], %[start]\n"
-                    "s_and_b32 %[a], %[e0], 0xffff\n"
-                    "s_cmp_ge_u32 %[t0], %[freq]\n"
-                    "s_cbranch_scc1 2f\n"
-                    "v_writelane_b32 %[outv], %[a], m0\n"
-                    "s_branch 6b\n"
-                    // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
-                    // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
-                    // path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot.
-                    "2:\n"
-                    "s_cmp_eq_u32 %[freq], 0\n"               // escape marker: the bucket's first candidate is the row's
-                    "s_cbranch_scc1 71f\n"                     // last slot, so the symbol is that slot -- no probe needed
-                    "v_readlane_b32 %[lb], %[rowbase], m0\n"
-                    "s_lshl1_add_u32 %[lb], %[a], %[lb]\n"
-                    "v_add_u32 v62, %[lb], %[lane2]\n"
-                    "ds_read_u16 v63, v62 offset:2\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_cmp_gt_u32 vcc, %[cum], v63\n"
-                    "s_bcnt1_i32_b64 %[t1], vcc\n"
-                    "s_cmp_eq_u32 %[t1], 64\n"
-                    "s_cbranch_scc1 8f\n"
-                    "s_cmp_eq_u32 %[t1], 0\n"
-                    "s_cbranch_scc1 71f\n"                     // escape marker: symbol a is the escape slot
-                    "s_sub_u32 %[t0], %[t1], 1\n"
-                    "v_readlane_b32 %[lb], v63, %[t1]\n"      // cm[a + 1 + k]  = next start - 1
-                    "v_readlane_b32 %[t0], v63, %[t0]\n"      // cm[a + k]      = start - 1
-                    "s_cmp_eq_u32 %[lb], 0xffff\n"
-                    "s_cbranch_scc1 72f\n"                     // the row's last slot: escape
-                    "s_add_u32 %[a], %[a], %[t1]\n"
-                    "s_sub_u32 %[freq], %[lb], %[t0]\n"
-                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
-                    "s_sub_u32 %[t0], %[t0], 1\n"             // cum - start
-                    "v_writelane_b32 %[outv], %[a], m0\n"
-                    "s_branch 6b\n"
-                    "71:\n"
-                    "s_sub_u32 %[t0], %[cum], %[start]\n"
-                    "s_sub_u32 %[freq], 0x10000, %[start]\n"
-                    "s_branch 73f\n"
-                    "72:\n"
-                    "s_add_u32 %[a], %[a], %[t1]\n"
-                    "s_sub_u32 %[freq], 0xffff, %[t0]\n"
-                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
-                    "s_sub_u32 %[t0], %[t0], 1\n"
-                    // escape (rans_interface.cpp:323-345): a = the escape slot, freq / t0 = its table step.  Worked on a
-                    // copy of the state (s[88:89], word index in lb, %[cum] = the next unread word) and committed at the
-                    // end; a count nibble of 15 (more than 8 payload nibbles follow) or a nearly used-up word window
-                    // leaves to the C++ path with the committed state untouched.  Straight-line: every renormalisation is
-                    // a pair of selects on the SCC of the s_lshr_b64 that tests it (a taken branch costs 8-17 ns on a lone
-                    // wave, an ALU instruction ~3).  The nn <= 8 payload nibbles are taken in two steps at most, because
-                    // the state can run dry only once in between: after k = (bits(x) - 28) >> 2 nibbles it is below 2^31
-                    // and takes in a word w, and the other nn - k <= 7 nibbles are then w's low bits, which cannot bring
-                    // it (>= 2^59 after the word) below 2^31 again.  Step A takes min(k, nn) nibbles and renormalises if
-                    // needed, step B the rest.
-                    "73:\n"
+                    // the loop has been left behind symbol m0 - 1: batch done, escape slot, or slot 63 of a wider row
+                    "63:\n"
+                    "s_cmp_lg_u32 %[e0], 0\n"
+                    "s_cbranch_scc1 3f\n"
+                    "s_cmp_eq_u32 %[start], 0xffff\n"
+                    "s_cbranch_scc1 60f\n"
+                    // escape (rans_interface.cpp:323-345): a = the escape slot; its table step is done.  The nibbles are
+                    // worked on a copy of the state (s[88:89], word index in lb, %[cum] = the next unread word) that is
+                    // committed at the end; a count nibble of 15 (more than 8 payload nibbles follow) or a nearly used-up
+                    // word window leaves to the C++ path with the committed state untouched.  Straight-line: every
+                    // renormalisation is a pair of selects on the SCC of the s_lshr_b64 that tests it.  The nn <= 8 payload
+                    // nibbles are taken in two steps at most, because the state can run dry only once in between: after
+                    // k = (bits(x) - 28) >> 2 nibbles it is below 2^31 and takes in a word w, and the other nn - k <= 7
+                    // nibbles are then w's low bits, which cannot bring it (>= 2^59 after the word) below 2^31 again.
+                    // Step A takes min(k, nn) nibbles and renormalises if needed, step B the rest.
+                    "64:\n"
                     "s_cmp_gt_u32 %[wi], 56\n"
-                    "s_cbranch_scc1 8f\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 16\n"
-                    "s_mul_i32 %[t1], s87, %[freq]\n"
-                    "s_mul_hi_u32 s89, s86, %[freq]\n"
-                    "s_mul_i32 s88, s86, %[freq]\n"
-                    "s_add_u32 %[t1], %[t1], s89\n"
-                    "s_add_u32 s88, s88, %[t0]\n"
-                    "s_addc_u32 s89, %[t1], 0\n"
-                    "s_lshr_b64 s[86:87], s[88:89], 31\n"     // renormalise after the escape symbol: wn = word wi
-                    "s_cselect_b32 s89, s89, s88\n"
-                    "s_cselect_b32 s88, s88, %[wn]\n"
-                    "s_subb_u32 %[lb], %[wi], -1\n"
-                    "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
+                    "s_cbranch_scc1 9f\n"
+                    "v_readlane_b32 %[cum], %[wcur], %[wi]\n"
+                    "s_mov_b64 s[88:89], s[84:85]\n"
                     "s_and_b32 %[e0], s88, 15\n"              // count nibble nn
                     "s_lshr_b64 s[88:89], s[88:89], 4\n"
                     "s_lshr_b64 s[86:87], s[88:89], 31\n"
                     "s_cselect_b32 s89, s89, s88\n"
                     "s_cselect_b32 s88, s88, %[cum]\n"
-                    "s_subb_u32 %[lb], %[lb], -1\n"
+                    "s_subb_u32 %[lb], %[wi], -1\n"
                     "s_cmp_gt_u32 %[e0], 8\n"
-                    "s_cbranch_scc1 8f\n"                     // a longer count: generic path
+                    "s_cbranch_scc1 9f\n"                     // a longer count: C++ path
                     "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
                     "s_flbit_i32_b64 %[t0], s[88:89]\n"       // leading zeros (<= 32)
                     "s_sub_u32 %[t0], 36, %[t0]\n"
@@ -1115,15 +1047,100 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                     "s_not_b32 %[t1], %[t1]\n"
                     "s_bitcmp1_b32 %[start], 0\n"
                     "s_cselect_b32 %[t1], %[t1], %[t0]\n"
+                    "s_sub_u32 m0, m0, 1\n"                  // (one scalar operand besides m0 is all v_writelane takes)
                     "v_writelane_b32 %[outv], %[t1], m0\n"
+                    "s_add_u32 m0, m0, 1\n"
                     "s_mov_b64 s[84:85], s[88:89]\n"           // commit
                     "s_mov_b32 %[wi], %[lb]\n"
-                    "s_not_b32 %[t0], m0\n"                    // symbols left behind this one: do they fit the word window?
-                    "s_add_u32 %[t0], %[t0], %[wi]\n"
-                    "s_cmp_le_u32 %[t0], 64\n"
-                    "s_cbranch_scc1 4b\n"
-                    "s_add_u32 m0, m0, 1\n"                   // no: hand the realign to the caller (symbol is done)
+                    "s_sub_u32 %[t0], %[wi], m0\n"            // + symbols left in the batch: do they fit the word window?
+                    "s_cmp_gt_u32 %[t0], 64\n"
+                    "s_cbranch_scc1 92f\n"                    // no: hand the realign to the caller
+                    // on with the next symbol (its row has been prefetched)
+                    "65:\n"
+                    "s_cmp_eq_u32 m0, 0\n"
+                    "s_cbranch_scc1 3f\n"
+                    "s_branch 1b\n"
+                    // rows wider than the 64 lanes: the bucket table (cum >> shift -> first candidate, its start, its
+                    // frequency) and, behind it, a probe of the next 64 row entries.  The state is untouched (identity step).
+                    "60:\n"
+                    "s_sub_u32 m0, m0, 1\n"
+                    "s_and_b32 %[cum], s84, 0xffff\n"
+                    "v_readlane_b32 %[lb], %[lutbase], m0\n"
+                    "s_lshr_b32 %[t0], %[cum], %[shift]\n"
+                    "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n"
+                    "v_mov_b32 v62, %[lb]\n"
+                    "ds_read_b64 v[62:63], v62\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_readfirstlane_b32 %[e0], v62\n"
+                    "v_readfirstlane_b32 %[freq], v63\n"
+                    "s_lshr_b32 %[start], %[e0], 16\n"
+                    "s_sub_u32 %[t0], %[cum], %[start]\n"
+                    "s_and_b32 %[a], %[e0], 0xffff\n"
+                    "s_mov_b32 %[e0], 1\n"                     // (from here on: 1 = table symbol, 0 = escape slot)
+                    "s_cmp_ge_u32 %[t0], %[freq]\n"
+                    "s_cbranch_scc0 68f\n"
+                    // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
+                    // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
+                    // path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot.
+                    "s_cmp_eq_u32 %[freq], 0\n"               // escape marker: the bucket's first candidate is the row's
+                    "s_cbranch_scc1 71f\n"                     // last slot, so the symbol is that slot -- no probe needed
+                    "v_readlane_b32 %[lb], %[rowbase], m0\n"
+                    "s_lshl1_add_u32 %[lb], %[a], %[lb]\n"
+                    "v_add_u32 v62, %[lb], %[lane2]\n"
+                    "ds_read_u16 v63, v62 offset:2\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "v_cmp_gt_u32 vcc, %[cum], v63\n"
+                    "s_bcnt1_i32_b64 %[t1], vcc\n"
+                    "s_cmp_eq_u32 %[t1], 64\n"
+                    "s_cbranch_scc1 8f\n"
+                    "s_cmp_eq_u32 %[t1], 0\n"
+                    "s_cbranch_scc1 71f\n"                     // escape marker: symbol a is the escape slot
+                    "s_sub_u32 %[t0], %[t1], 1\n"
+                    "v_readlane_b32 %[lb], v63, %[t1]\n"      // cm[a + 1 + k]  = next start - 1
+                    "v_readlane_b32 %[t0], v63, %[t0]\n"      // cm[a + k]      = start - 1
+                    "s_cmp_eq_u32 %[lb], 0xffff\n"
+                    "s_cbranch_scc1 72f\n"                     // the row's last slot: escape
+                    "s_add_u32 %[a], %[a], %[t1]\n"
+                    "s_sub_u32 %[freq], %[lb], %[t0]\n"
+                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
+                    "s_sub_u32 %[t0], %[t0], 1\n"             // cum - start
+                    "s_branch 68f\n"
+                    "71:\n"
+                    "s_sub_u32 %[t0], %[cum], %[start]\n"
+                    "s_sub_u32 %[freq], 0x10000, %[start]\n"
+                    "s_mov_b32 %[e0], 0\n"
+                    "s_branch 68f\n"
+                    "72:\n"
+                    "s_add_u32 %[a], %[a], %[t1]\n"
+                    "s_sub_u32 %[freq], 0xffff, %[t0]\n"
+                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
+                    "s_sub_u32 %[t0], %[t0], 1\n"
+                    "s_mov_b32 %[e0], 0\n"
+                    "68:\n"                                    // a, freq, cum - start: the table step, as in the loop
+                    "v_writelane_b32 %[outv], %[a], m0\n"
+                    "s_lshr_b64 s[86:87], s[84:85], 16\n"
+                    "s_mul_i32 %[t1], s87, %[freq]\n"
+                    "s_mul_hi_u32 s85, s86, %[freq]\n"
+                    "s_mul_i32 s84, s86, %[freq]\n"
+                    "s_add_u32 %[t1], %[t1], s85\n"
+                    "s_add_u32 s84, s84, %[t0]\n"
+                    "s_addc_u32 s85, %[t1], 0\n"
+                    "s_lshr_b64 s[86:87], s[84:85], 31\n"
+                    "s_cselect_b32 s85, s85, s84\n"
+                    "s_cselect_b32 s84, s84, %[wn]\n"
+                    "s_subb_u32 %[wi], %[wi], -1\n"
+                    "s_add_u32 m0, m0, 1\n"
+                    "s_cmp_eq_u32 %[e0], 0\n"
+                    "s_cbranch_scc1 64b\n"                    // escape slot: the nibbles
+                    "s_branch 65b\n"
+                    "3:\n"
+                    "s_mov_b32 %[more], 0\n"
+                    "s_branch 5f\n"
+                    "92:\n"
                     "s_mov_b32 %[more], 2\n"
+                    "s_branch 5f\n"
+                    "9:\n"
+                    "s_mov_b32 %[more], 3\n"
                     "s_branch 5f\n"
                     "8:\n"
                     "s_mov_b32 %[more], 1\n"
@@ -1145,40 +1162,47 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 realign();
                 continue;
             }
-            // rare shapes (candidate more than 64 entries away, long escapes, window nearly used up): generic path,
-            // starting again from the bucket entry
-            cum = (uint32_t)x & 0xFFFFu;
-            {
-                const uint2 ev = sl[rdl((uint32_t)ti, j) * lut_n + (int)(cum >> shift)];
-                const uint32_t e0 = rfl(ev.x);
-                a = e0 & 0xFFFFu;
-                start = e0 >> 16;
-                freq = rfl(ev.y);
-            }
-            const uint32_t r0 = rdl(rinfo.x, j);
+            // rare shapes: generic path.  more == 1: symbol j from the bucket entry (candidate more than 64 entries away);
+            // more == 3: symbol j - 1 was an escape slot whose table step is done -- only its nibbles are left (a count
+            // above 8, or the word window nearly used up)
+            const int jj = more == 3 ? j - 1 : j;
+            const uint32_t r0 = rdl(rinfo.x, jj);
             const int ro = (int)(r0 & 0xFFFFu), last = (int)(r0 >> 16) - 2;  // last = escape slot
-            if ((int)a == last) freq = 65536u - start;                        // undo the fast-path marker
-            if (cum - start >= freq) {
-                // the symbol lies behind the bucket's first candidate: the 64 lanes compare the next 64 row entries with
-                // cum at once (one LDS read + ballot per 64 candidates instead of one dependent read per candidate)
-                uint32_t lo = a + 1, prev = start;
-                for (;;) {
-                    const int ci = (int)lo + lane;
-                    const uint32_t c = (ci <= last) ? (uint32_t)cm[ro + ci] + 1u : 65536u;  // entry i = start of symbol i
-                    const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c <= cum));
-                    if (k == 64) {
-                        prev = rdl(c, 63);
-                        lo += 64;
-                        continue;
-                    }
-                    a = lo + (uint32_t)k - 1u;
-                    start = k ? rdl(c, k - 1) : prev;
-                    freq = rdl(c, k) - start;
-                    break;
+            if (more == 1) {
+                cum = (uint32_t)x & 0xFFFFu;
+                {
+                    const uint2 ev = sl[rdl((uint32_t)ti, j) * lut_n + (int)(cum >> shift)];
+                    const uint32_t e0 = rfl(ev.x);
+                    a = e0 & 0xFFFFu;
+                    start = e0 >> 16;
+                    freq = rfl(ev.y);
                 }
+                if ((int)a == last) freq = 65536u - start;                        // undo the fast-path marker
+                if (cum - start >= freq) {
+                    // the symbol lies behind the bucket's first candidate: the 64 lanes compare the next 64 row entries
+                    // with cum at once (one LDS read + ballot per 64 candidates instead of one dependent read per candidate)
+                    uint32_t lo = a + 1, prev = start;
+                    for (;;) {
+                        const int ci = (int)lo + lane;
+                        const uint32_t c = (ci <= last) ? (uint32_t)cm[ro + ci] + 1u : 65536u;  // entry i = start of symbol i
+                        const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c <= cum));
+                        if (k == 64) {
+                            prev = rdl(c, 63);
+                            lo += 64;
+                            continue;
+                        }
+                        a = lo + (uint32_t)k - 1u;
+                        start = k ? rdl(c, k - 1) : prev;
+                        freq = rdl(c, k) - start;
+                        break;
+                    }
+                }
+                x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);
+                if ((uint32_t)(x >> 31) == 0u) x = (x << 32) | rdl(wcur, wi++);
+                ++j;
+            } else {
+                a = (uint32_t)last;
             }
-            x = (uint64_t)freq * (x >> PROB_BITS) + (cum - start);
-            if ((uint32_t)(x >> 31) == 0u) x = (x << 32) | rdl(wcur, wi++);
             int v = (int)a;
             if ((int)a == last) {  // escape: rans_interface.cpp:323-345 (4-bit nibbles, 80-96)
                 auto bits = [&]() -> int {
@@ -1203,10 +1227,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
                 else v += last;
                 // an escape may have used many words: restore the window invariant -- but only when the rest of the
                 // batch (one word per symbol at most) could run past lane 63; a realign waits for a fresh global load
-                if (wi + (63 - j) > 64) realign();
+                if (wi + (64 - j) > 64) realign();
             }
-            outv = wrl((uint32_t)v, j, outv);
-            ++j;
+            outv = wrl((uint32_t)v, jj, outv);
         }
         // table offset of each symbol (entropy_models' _offset) added by its own lane, then one coalesced store
         const int off = (int)(int16_t)(rinfo.y & 0xFFFFu);
