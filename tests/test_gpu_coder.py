@@ -152,3 +152,41 @@ def test_very_wide_row():
     d = ans.RansDecoder()
     d.set_stream(s)
     assert np.array_equal(np.asarray(d.decode_stream(idx, cdf, sizes, offsets), np.int32), sym)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_rows_around_the_lane_count(seed):
+    """Rows of 2 ... 70 slots with random frequencies (many of them 1): the decoder's first level holds 64 slots of a row in
+    the 64 lanes, so 63 / 64 / 65 slots are its edges (escape slot in the last lane; slot 63 standing for the rest of a wider
+    row), and symbol 0 / the slot before the escape are the edges of the lane search.  Every slot of every row is coded, with
+    escapes of both signs in between and stream lengths around the 64-symbol batch."""
+    require_gpu()
+    from rgbd_amd import ans
+
+    rng = np.random.RandomState(100 + seed)
+    slots = [2, 3, 5, 17, 31, 32, 33, 62, 63, 64, 65, 66, 70]
+    stride = max(slots) + 1
+    cdf = np.zeros((len(slots), stride), np.int32)
+    for r, n in enumerate(slots):
+        f = np.ones(n, np.int64)
+        extra = rng.multinomial(65536 - n, rng.dirichlet(np.full(n, 0.3)))
+        f += extra
+        cdf[r, : n + 1] = np.concatenate([[0], np.cumsum(f)])
+        assert cdf[r, n] == 65536
+    sizes = np.array([n + 1 for n in slots], np.int32)
+    offsets = np.array([-(n // 2) for n in slots], np.int32)
+    t, ot = ans.Tables(cdf, sizes, offsets), coder.Tables(cdf, sizes, offsets)
+    for n in (1, 63, 64, 65, 4000):
+        idx = rng.randint(0, len(slots), n).astype(np.int32)
+        v = (rng.rand(n) * (sizes[idx] - 2)).astype(np.int64)      # a table slot (escape slot excluded) ...
+        edge = rng.rand(n)
+        v = np.where(edge < 0.15, 0, np.where(edge < 0.3, sizes[idx] - 3, v))
+        sym = v + offsets[idx]
+        esc = rng.rand(n) < 0.1                                     # ... or an escape on either side
+        far = (2.0 ** rng.uniform(0, 20, n)).astype(np.int64)
+        sym = np.where(esc, np.where(rng.rand(n) < 0.5, offsets[idx] - far, offsets[idx] + sizes[idx] - 2 + far), sym).astype(np.int32)
+        s = ans._encode(t, sym, idx)
+        assert s == coder.rans_encode(sym, idx, ot)
+        d = ans.RansDecoder()
+        d.set_stream(s)
+        assert np.array_equal(np.asarray(d.decode_stream(idx, cdf, sizes, offsets), np.int32), sym), n
