@@ -583,7 +583,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
 // first-generation loop above spends a third of its 137 ns per symbol in its four branches.  Here
 //   * escapes are expanded into ITEMS beforehand, in parallel by the 64 lanes: an item is either a table symbol or a raw
 //     4-bit nibble (rans_interface.cpp:60-78,147-162), and both are the same arithmetic
-//         renormalise when (x >> 47) >= thr;   x = x + bias + (mulhi64(x, m) >> shift) * mult
+//         renormalise when (x >> 47) >= thr (items hold thr << 15, compared with x's high word);
+//         x = x + bias + (mulhi64(x, m) >> shift) * mult
 //     (symbol: thr = freq, mult = 65536 - freq, m the exact reciprocal of rans64.h:167-278; nibble v: thr = 4096 (x >= 2^59),
 //      m = 2^64 - 1 so q = x - 1, mult = 15, bias = v + 15, i.e. x = (x << 4) | v), so the serial loop has no escape path;
 //   * the renormalisation is branch-free: the candidate word is ALWAYS written to an LDS staging slot and the slot
@@ -593,9 +594,8 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
 // Per batch of 64 symbols the staged words are copied out with one coalesced store.
 #define ENC_ITEM_CAP 704  // 64 symbols x (1 slot + 1 count + 8 payload nibbles) + padding
 #define ENC_ITEM(S0, S1, S2, S3, S4, S5)                                                            \
-    "v_lshrrev_b64 v[62:63], 47, v[60:61]\n"                                                        \
     "ds_write_b32 %[wa], v60\n"                      /* candidate word (kept only if due) */        \
-    "v_cmp_ge_u32 vcc, v62, " S5 "\n"                /* (x >> 47) >= thr: renormalise */             \
+    "v_cmp_ge_u32 vcc, v61, " S5 "\n"                /* x.hi >= thr << 15, i.e. (x >> 47) >= thr: renormalise */ \
     "v_cndmask_b32 v60, v60, v61, vcc\n"                                                            \
     "v_cndmask_b32 v61, v61, v84, vcc\n"             /* v84 = 0 */                                   \
     "v_cndmask_b32 v63, 0, v85, vcc\n"               /* v85 = 4 */                                   \
@@ -703,17 +703,17 @@ __global__ __launch_bounds__(64) void rans_encode_kernel2(const int32_t* __restr
                 p[0] = make_uint4(mlo, mhi, bias, shift);
                 p[1] = make_uint4(mult, thr, 0u, 0u);
             };
-            put(o0, hf.e.x, hf.e.y, hf.e.z & 0x1FFFFu, hf.e.z >> 17, 65536u - hf.e.w, hf.e.w);
+            put(o0, hf.e.x, hf.e.y, hf.e.z & 0x1FFFFu, hf.e.z >> 17, 65536u - hf.e.w, hf.e.w << 15);
             if (hf.c > 1) {
-                put(o0 + 1, ~0u, ~0u, (uint32_t)hf.nn + 15u, 0u, 15u, 4096u);
+                put(o0 + 1, ~0u, ~0u, (uint32_t)hf.nn + 15u, 0u, 15u, 4096u << 15);
                 for (int k = 0; k < hf.nn; ++k)
-                    put(o0 + 2 + k, ~0u, ~0u, ((hf.raw >> (k * ESC_BITS)) & ESC_MAX) + 15u, 0u, 15u, 4096u);
+                    put(o0 + 2 + k, ~0u, ~0u, ((hf.raw >> (k * ESC_BITS)) & ESC_MAX) + 15u, 0u, 15u, 4096u << 15);
             }
         }
         if (lane == 0 && (total & 1)) {  // no-op item: never renormalises (thr > any x >> 47), x + 0 + q * 0
             uint4* p = reinterpret_cast<uint4*>(items + (size_t)total * 8);
             p[0] = make_uint4(~0u, ~0u, 0u, 0u);
-            p[1] = make_uint4(0u, 65536u, 0u, 0u);
+            p[1] = make_uint4(0u, 65536u << 15, 0u, 0u);
         }
         return (total + 1) & ~1;
     };
