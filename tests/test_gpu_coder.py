@@ -190,3 +190,42 @@ def test_rows_around_the_lane_count(seed):
         d = ans.RansDecoder()
         d.set_stream(s)
         assert np.array_equal(np.asarray(d.decode_stream(idx, cdf, sizes, offsets), np.int32), sym), n
+
+
+def test_all_encoder_generations_make_the_same_stream(kat, gc_tables, gpu_tables):
+    """The library keeps its earlier encoder loops selectable (RGBD_CODER_V1 / RGBD_CODER_V2, read once per process) for A/B
+    timing.  Each generation, in its own process, must produce the oracle's bytes for a stream with escapes of every length
+    and a ragged last batch."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    from rgbd_amd import ans
+
+    rng = np.random.RandomState(11)
+    n = 20011
+    idx = rng.randint(0, 64, n).astype(np.int32)
+    sym = np.rint(rng.standard_normal(n) * kat["scale_table"][idx]).astype(np.int64)
+    esc = rng.rand(n) < 0.15
+    mag = (2.0 ** rng.uniform(0, 26.5, int(esc.sum()))).astype(np.int64)
+    sym[esc] = np.where(rng.rand(int(esc.sum())) < 0.5, mag, -mag)
+    sym = sym.astype(np.int32)
+    want = hashlib.sha256(coder.rans_encode(sym, idx, gc_tables)).hexdigest()
+    assert hashlib.sha256(ans._encode(gpu_tables, sym, idx)).hexdigest() == want
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); import rgbd_amd; from rgbd_amd import ans;"
+            "from rgbd_amd.entropy_models import GaussianConditional, get_scale_table;"
+            "gc = GaussianConditional(); gc.update_scale_table(get_scale_table(), force=True);"
+            "t = ans.Tables(*gc.numpy_tables()); d = np.load(sys.argv[1]);"
+            "print(hashlib.sha256(ans._encode(t, d['sym'], d['idx'])).hexdigest())" % root)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "in.npz")
+        np.savez(path, sym=sym, idx=idx)
+        for var in ("RGBD_CODER_V1", "RGBD_CODER_V2"):
+            env = dict(os.environ, **{var: "1"})
+            out = subprocess.run([sys.executable, "-c", prog, path], env=env, capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr[-2000:]
+            assert out.stdout.split()[-1] == want, var
