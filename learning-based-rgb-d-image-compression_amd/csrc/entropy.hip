@@ -864,7 +864,7 @@ __global__ __launch_bounds__(128) void rans_encode_kernel3(const int32_t* __rest
     };
     // items of a batch into LDS in WALK order (position 0 is coded first): the last symbol of the batch first, and per
     // escape symbol the payload nibbles from the most significant one, the count, then the escape slot itself (the reverse
-    // of the decoder's order, rans_interface.cpp:147-162); padded to an even number with a no-op item.  Returns the count.
+    // of the decoder's order, rans_interface.cpp:147-162); padded to a multiple of four with no-op items.  Returns the count.
     auto expand = [&](const Half& hf, uint32_t* items) -> int {
         int incl = hf.c;  // inclusive prefix sum over the lanes
         int total;
@@ -895,12 +895,13 @@ __global__ __launch_bounds__(128) void rans_encode_kernel3(const int32_t* __rest
                     put(o0 + 2 + k, ~0u, ~0u, ((hf.raw >> (k * ESC_BITS)) & ESC_MAX) + 15u, 0u, 15u, 4096u << 15);
             }
         }
-        if (lane == 0 && (total & 1)) {  // no-op item: never renormalises (thr > any x >> 47), x + 0 + q * 0
-            uint4* p = reinterpret_cast<uint4*>(items + (size_t)total * 8);
+        const int padded = (total + 3) & ~3;  // the walk is unrolled four times
+        if (lane < padded - total) {  // no-op items: never renormalise (thr > any x >> 47), x + 0 + q * 0
+            uint4* p = reinterpret_cast<uint4*>(items + (size_t)(total + lane) * 8);
             p[0] = make_uint4(~0u, ~0u, 0u, 0u);
             p[1] = make_uint4(0u, 65536u << 15, 0u, 0u);
         }
-        return (total + 1) & ~1;
+        return padded;
     };
 
     // Step st (nb-1 ... -2), one barrier each: the producer expands batch st into items[st & 1] and writes batch st+2's
@@ -961,8 +962,16 @@ __global__ __launch_bounds__(128) void rans_encode_kernel3(const int32_t* __rest
                     "ds_read_b128 v[70:73], %[ia] offset:64\n"   // the item after (set a; reads past the end hit the padding)
                     "ds_read_b64 v[74:75], %[ia] offset:80\n"
                     ENC_ITEM("v76", "v77", "v78", "v79", "v80", "v81")
-                    "v_add_u32 %[ia], 64, %[ia]\n"
-                    "s_sub_u32 %[n], %[n], 2\n"
+                    "s_waitcnt lgkmcnt(1)\n"
+                    "ds_read_b128 v[76:79], %[ia] offset:96\n"
+                    "ds_read_b64 v[80:81], %[ia] offset:112\n"
+                    ENC_ITEM("v70", "v71", "v72", "v73", "v74", "v75")
+                    "s_waitcnt lgkmcnt(1)\n"
+                    "ds_read_b128 v[70:73], %[ia] offset:128\n"
+                    "ds_read_b64 v[74:75], %[ia] offset:144\n"
+                    ENC_ITEM("v76", "v77", "v78", "v79", "v80", "v81")
+                    "v_add_u32 %[ia], 0x80, %[ia]\n"
+                    "s_sub_u32 %[n], %[n], 4\n"
                     "s_cmp_lg_u32 %[n], 0\n"
                     "s_waitcnt lgkmcnt(1)\n"
                     "s_cbranch_scc1 1b\n"
