@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Encoder, second generation: the same stream bit for bit, with a branch-free serial loop.
+// Encoder, second / third generation: the same stream bit for bit, with a branch-free serial loop.
 //
 // Measured on gfx950 (tools/ubench/oplat.hip): one dependent ALU instruction of a single wave costs ~3.5 ns, an
 // independent one ~2.3 ns of issue time, but every branch costs 8-17 ns (s_cbranch_vccz after a v_cmp: 17 ns) -- the
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
 //      m = 2^64 - 1 so q = x - 1, mult = 15, bias = v + 15, i.e. x = (x << 4) | v), so the serial loop has no escape path;
 //   * the renormalisation is branch-free: the candidate word is ALWAYS written to an LDS staging slot and the slot
 //     pointer moves only when the word was due (v_cndmask), the state halves are selected with v_cndmask;
-//   * items are read from LDS one item ahead (two register sets, loop unrolled twice), nothing is fetched with
+//   * items are read from LDS one item ahead (two register sets, loop unrolled four times), nothing is fetched with
 //     v_readlane, and the loop runs with a single active lane (all of it is uniform work).
 // Per batch of 64 symbols the staged words are copied out with one coalesced store.
 #define ENC_ITEM_CAP 704  // 64 symbols x (1 slot + 1 count + 8 payload nibbles) + padding
@@ -613,188 +613,11 @@ __global__ __launch_bounds__(64) void rans_encode_kernel(const int32_t* __restri
     "v_mad_u64_u32 v[60:61], s[94:95], v68, " S4 ", v[82:83]\n"   /* x = xb + q.lo * mult */         \
     "v_add_u32 v61, v61, v64\n"
 
-__global__ __launch_bounds__(64) void rans_encode_kernel2(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
-                                                          const int64_t* __restrict__ sym_base,
-                                                          const int64_t* __restrict__ counts, int split, DevTables t0,
-                                                          DevTables t1, uint32_t* __restrict__ out, int64_t cap_words,
-                                                          int64_t* __restrict__ out_words, int* __restrict__ err)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char esm[];
-    // LDS: items [ENC_ITEM_CAP + 2][8 dwords] | staged words [ENC_ITEM_CAP] | row metadata [nrows] int3
-    uint32_t* items = reinterpret_cast<uint32_t*>(esm);
-    uint32_t* obuf = items + (ENC_ITEM_CAP + 2) * 8;
-    int3* rowmeta = reinterpret_cast<int3*>(obuf + ENC_ITEM_CAP);
-    const int s = blockIdx.x;
-    const int lane = threadIdx.x;
-    const DevTables& t = s < split ? t0 : t1;
-    const int64_t n = counts[s];
-    const int64_t base = sym_base[s];
-    uint32_t* o = out + (size_t)s * cap_words;
-    uint64_t x = RANS_LOW;
-    int64_t w = cap_words;  // next free slot is w-1
-    int bad = 0;
-
-    for (int i = lane; i < t.nrows; i += 64) rowmeta[i] = make_int3(t.row_off[i], t.sizes[i], t.offsets[i]);
-    __syncthreads();
-    const uint32_t items_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)items;
-    const uint32_t obuf_top = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)(obuf + ENC_ITEM_CAP);
-
-    // stage 1 of a batch (two batches ahead of the serial loop): symbol and index from HBM
-    // stage 2 (one batch ahead): row geometry, escape split, gather of the symbol's reciprocal entry
-    struct Half {
-        uint4 e;       // table entry of the (clamped) symbol
-        uint32_t raw;  // escape payload
-        int nn;        // payload nibbles (escape only)
-        int c;         // items of this symbol: 0 (invalid lane), 1, or nn + 2
-    };
-    auto finish = [&](const EncRaw& r) -> Half {
-        Half hf;
-        hf.e = make_uint4(~0u, ~0u, 65535u, 1u);
-        hf.raw = 0;
-        hf.nn = 0;
-        hf.c = 0;
-        if (r.valid) {
-            const int3 rm = rowmeta[r.ti];  // {row_off, cdf_length, offset}
-            const int top = rm.y - 2;
-            int v = r.sv - rm.z;
-            uint32_t raw = 0;
-            bool esc = false;
-            if (v < 0) {
-                raw = (uint32_t)(-2 * v - 1);
-                v = top;
-                esc = true;
-            } else if (v >= top) {
-                raw = (uint32_t)(2 * (v - top));
-                v = top;
-                esc = true;
-            }
-            hf.e = reinterpret_cast<const uint4*>(t.enc)[rm.x + v];
-            hf.raw = raw;
-            int nn = 0;
-            while (nn < 8 && (raw >> (nn * ESC_BITS)) != 0) ++nn;
-            hf.nn = nn;
-            hf.c = esc ? nn + 2 : 1;
-        }
-        return hf;
-    };
-    // items of a batch into LDS in WALK order (position 0 is coded first): the last symbol of the batch first, and per
-    // escape symbol the payload nibbles from the most significant one, the count, then the escape slot itself (the reverse
-    // of the decoder's order, rans_interface.cpp:147-162); padded to an even number with a no-op item.  Returns the count.
-    auto expand = [&](const Half& hf) -> int {
-        int incl = hf.c;  // inclusive prefix sum over the lanes
-        int total;
-        if (__builtin_amdgcn_ballot_w64(hf.c > 1) == 0) {
-            // no escape in this batch (the common case at a trained model's rates): one item per valid lane, and the
-            // valid lanes are a prefix of the wave
-            total = __builtin_popcountll(__builtin_amdgcn_ballot_w64(hf.c != 0));
-            incl = lane + 1;
-        } else {
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int up = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += up;
-            }
-            total = __builtin_amdgcn_readlane(incl, 63);
-        }
-        if (hf.c) {
-            const int o0 = incl - hf.c;  // first item index of this symbol; walk position = total - 1 - index
-            auto put = [&](int index, uint32_t mlo, uint32_t mhi, uint32_t bias, uint32_t shift, uint32_t mult, uint32_t thr) {
-                uint4* p = reinterpret_cast<uint4*>(items + (size_t)(total - 1 - index) * 8);
-                p[0] = make_uint4(mlo, mhi, bias, shift);
-                p[1] = make_uint4(mult, thr, 0u, 0u);
-            };
-            put(o0, hf.e.x, hf.e.y, hf.e.z & 0x1FFFFu, hf.e.z >> 17, 65536u - hf.e.w, hf.e.w << 15);
-            if (hf.c > 1) {
-                put(o0 + 1, ~0u, ~0u, (uint32_t)hf.nn + 15u, 0u, 15u, 4096u << 15);
-                for (int k = 0; k < hf.nn; ++k)
-                    put(o0 + 2 + k, ~0u, ~0u, ((hf.raw >> (k * ESC_BITS)) & ESC_MAX) + 15u, 0u, 15u, 4096u << 15);
-            }
-        }
-        if (lane == 0 && (total & 1)) {  // no-op item: never renormalises (thr > any x >> 47), x + 0 + q * 0
-            uint4* p = reinterpret_cast<uint4*>(items + (size_t)total * 8);
-            p[0] = make_uint4(~0u, ~0u, 0u, 0u);
-            p[1] = make_uint4(0u, 65536u << 15, 0u, 0u);
-        }
-        return (total + 1) & ~1;
-    };
-
-    const int64_t nb = (n + 63) >> 6;
-    Half cur = finish(enc_load(sym, idx, base + (nb - 1) * 64 + lane, nb > 0 && (nb - 1) * 64 + lane < n));
-    EncRaw raw1 = enc_load(sym, idx, base + (nb - 2) * 64 + lane, nb > 1);
-    for (int64_t b = nb - 1; b >= 0; --b) {
-        int nitems = expand(cur);                     // batch b -> LDS (its gather was issued a whole batch ago)
-        const Half nxt = finish(raw1);                // batch b-1: table gather in flight during the serial loop
-        raw1 = enc_load(sym, idx, base + (b - 2) * 64 + lane, b > 1);  // batch b-2
-        if (w < ENC_ITEM_CAP + 8) {  // worst case for one batch: every item a word (rgbd_rans_max_bytes sizes for this)
-            bad = 1;
-            break;
-        }
-        uint32_t wa = obuf_top - 4u;  // LDS byte address of the next staged word (the staging area fills downwards)
-        if (nitems > 0) {
-            uint32_t ia = items_addr;
-            nitems = (int)rfl((uint32_t)nitems);
-            asm volatile(
-                "s_mov_b64 s[92:93], exec\n"
-                "s_mov_b64 exec, 1\n"                     // uniform work: one lane
-                "v_mov_b64 v[60:61], %[x]\n"
-                "v_mov_b32 v84, 0\n"
-                "v_mov_b32 v85, 4\n"
-                "v_mov_b32 v87, 0\n"                      // high halves of the 64-bit addend pairs
-                "v_mov_b32 v89, 0\n"
-                "v_mov_b32 v91, 0\n"
-                "s_waitcnt lgkmcnt(0)\n"                  // the items are in LDS
-                "ds_read_b128 v[70:73], %[ia]\n"
-                "ds_read_b64 v[74:75], %[ia] offset:16\n"
-                "s_waitcnt lgkmcnt(0)\n"
-                "1:\n"
-                "ds_read_b128 v[76:79], %[ia] offset:32\n"   // next item (set b)
-                "ds_read_b64 v[80:81], %[ia] offset:48\n"
-                ENC_ITEM("v70", "v71", "v72", "v73", "v74", "v75")
-                "s_waitcnt lgkmcnt(1)\n"                     // set b has arrived (the staged word may still be in flight)
-                "ds_read_b128 v[70:73], %[ia] offset:64\n"   // the item after (set a; reads past the end hit the padding)
-                "ds_read_b64 v[74:75], %[ia] offset:80\n"
-                ENC_ITEM("v76", "v77", "v78", "v79", "v80", "v81")
-                "v_add_u32 %[ia], 64, %[ia]\n"
-                "s_sub_u32 %[n], %[n], 2\n"
-                "s_cmp_lg_u32 %[n], 0\n"
-                "s_waitcnt lgkmcnt(1)\n"
-                "s_cbranch_scc1 1b\n"
-                "s_waitcnt lgkmcnt(0)\n"
-                "v_mov_b64 %[x], v[60:61]\n"
-                "s_mov_b64 exec, s[92:93]\n"
-                : [x] "+v"(x), [ia] "+v"(ia), [wa] "+v"(wa), [n] "+s"(nitems)
-                :
-                : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
-                  "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90",
-                  "v91", "s92", "s93", "s94", "s95",
-                  "vcc", "scc", "memory");
-            x = rfl64(x);
-            wa = rfl(wa);
-        }
-        // staged words [wa + 4, obuf_top) -> the stream, same relative order (the stream grows downwards as well)
-        const int nout = (int)((obuf_top - 4u - wa) >> 2);
-        for (int i = lane; i < nout; i += 64) o[w - nout + i] = obuf[ENC_ITEM_CAP - nout + i];
-        w -= nout;
-        cur = nxt;
-    }
-    if (bad) {
-        if (lane == 0) {
-            *err = 1;
-            out_words[s] = 0;
-        }
-        return;
-    }
-    if (lane == 0) {  // rans64.h:96-103: the two state words go in front
-        o[w - 1] = (uint32_t)(x >> 32);
-        o[w - 2] = (uint32_t)x;
-        out_words[s] = cap_words - (w - 2);
-    }
-}
-
-// Encoder, third generation: the second-generation loop with a producer wave.  Expanding a batch into items (prefix sums,
-// LDS writes, the table gather) and writing a batch's staged words to the stream took ~15 % of the coder's time between
-// two serial walks; here a second wavefront of the workgroup does both, a step ahead of / behind the coder, with double-
-// buffered item and staging areas and one barrier per 64-symbol batch.  Same stream, bit for bit.
+// The kernel (third generation: the loop above, unrolled four times, fed by a producer wave).  Expanding a batch into items
+// (prefix sums, LDS writes, the table gather) and writing a batch's staged words to the stream took ~15 % of the coder's
+// time between two serial walks when one wave did everything (second generation); here a second wavefront of the
+// workgroup does both, a step ahead of / behind the coder, with double-buffered item and staging areas and one barrier per
+// 64-symbol batch.  Same stream, bit for bit.
 __global__ __launch_bounds__(128) void rans_encode_kernel3(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx,
                                                           const int64_t* __restrict__ sym_base,
                                                           const int64_t* __restrict__ counts, int split, DevTables t0,
@@ -1015,18 +838,10 @@ int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sy
     if (nstreams <= 0) return RGBD_OK;
     if (cap_words % 64 || cap_words >= ((int64_t)1 << 31)) return RGBD_EINVAL;
     const size_t lds = (size_t)(t0.nrows > t1.nrows ? t0.nrows : t1.nrows) * sizeof(int3);
-    static const bool v1 = getenv("RGBD_CODER_V1") != nullptr;  // A/B switches: the first- / second-generation loops
-    static const bool v2 = getenv("RGBD_CODER_V2") != nullptr;
+    static const bool v1 = getenv("RGBD_CODER_V1") != nullptr;  // A/B switch: the first-generation loop
     const size_t lds3 = 2 * ((size_t)(ENC_ITEM_CAP + 2) * 32 + (size_t)ENC_ITEM_CAP * 4) + 32 + lds;
-    if (!v1 && !v2 && lds3 <= 64 * 1024) {
+    if (!v1 && lds3 <= 64 * 1024) {
         hipLaunchKernelGGL(rans_encode_kernel3, dim3(nstreams), dim3(128), lds3, s, sym, idx, sym_base, counts, split, t0, t1,
-                           out, cap_words, out_words, err);
-        HIP_TRY(hipGetLastError());
-        return RGBD_OK;
-    }
-    const size_t lds2 = (size_t)(ENC_ITEM_CAP + 2) * 32 + (size_t)ENC_ITEM_CAP * 4 + lds;
-    if (!v1 && lds2 <= 64 * 1024) {
-        hipLaunchKernelGGL(rans_encode_kernel2, dim3(nstreams), dim3(64), lds2, s, sym, idx, sym_base, counts, split, t0, t1,
                            out, cap_words, out_words, err);
         HIP_TRY(hipGetLastError());
         return RGBD_OK;
