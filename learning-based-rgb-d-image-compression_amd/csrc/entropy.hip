@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     uint32_t* pk = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cm) +
                                                (((size_t)(t.total + 64 * t.nrows) * 2 + 15) & ~(size_t)15));  // [nrows][64]
 
-    // Four streams per workgroup, one per wavefront (each on its own SIMD): the ~125 KB of tables in LDS are shared, so a
+    // Four streams per workgroup, one per wavefront (each on its own SIMD): the ~140 KB of tables in LDS are shared, so a
     // decode launch of 16 streams holds 4 CUs' LDS instead of 16 (a conv workgroup cannot co-reside with these tables).
     // (spw = streams per workgroup: 4, or 1 for a call with one or two streams -- a single image -- where sharing the
     // LDS between waves only costs latency)
