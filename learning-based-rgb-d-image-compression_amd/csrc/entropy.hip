@@ -961,6 +961,9 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         return lane >= sh_ ? idx[base + bb * 64 + lane - sh_] : 0;
     };
     int ti_next = load_ti(0);
+    bool pend_ok = false;  // symbols of the batch before, not yet stored
+    int64_t pend_pos = 0;
+    int32_t pend_val = 0;
     for (int64_t b = 0; b < nb; ++b) {
         const int cnt = (int)((count - b * 64) < 64 ? (count - b * 64) : 64);
         const int sh = 64 - cnt;
@@ -975,6 +978,10 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         int j = sh;
         realign();  // before the prefetch below: its wait then only covers loads issued a whole batch ago
         if (b + 1 < nb) ti_next = load_ti(b + 1);  // prefetch
+        // the previous batch's symbols leave HERE, in front of a whole serial walk: the wait at the top of the next batch
+        // (for the index prefetch above, in issue order) then finds the store long done instead of just issued (~0.5 us
+        // per batch when it sat at the end of the loop body)
+        if (pend_ok) sym[pend_pos] = pend_val;
         while (j < 64) {
             // hot loop: symbols the first level resolves.  The word window is loop-invariant here; anything else (a row
             // wider than the lanes, an unusual escape) leaves the loop, is finished below and the loop is re-entered
@@ -1273,8 +1280,11 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         }
         // table offset of each symbol (entropy_models' _offset) added by its own lane, then one coalesced store
         const int off = (int)(int16_t)(rinfo.y & 0xFFFFu);
-        if (lane >= sh) sym[base + b * 64 + lane - sh] = (int32_t)outv + off;
+        pend_ok = lane >= sh;
+        pend_pos = base + b * 64 + lane - sh;
+        pend_val = (int32_t)outv + off;
     }
+    if (pend_ok) sym[pend_pos] = pend_val;
     if (lane == 0) {
         state[2 * s] = x;
         state[2 * s + 1] = (uint64_t)(wpos0 + wi);
