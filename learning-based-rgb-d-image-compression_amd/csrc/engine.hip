@@ -3045,34 +3045,16 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
     pre_leads.clear();
     arena.top = 0;
     rc = 0;
-    std::vector<uint32_t> hwords;
-    std::vector<int64_t> yoff, ylw, zoff, zlw;
-    auto push = [&](const uint8_t* const* arr, const int64_t* len, int n, std::vector<int64_t>& off,
-                    std::vector<int64_t>& ln) -> int {
-        for (int i = 0; i < n; ++i) {
-            if (len[i] < 8 || (len[i] & 3)) return RGBD_EINVAL;
-            off.push_back((int64_t)hwords.size());
-            ln.push_back(len[i] / 4);
-            const size_t o = hwords.size();
-            hwords.resize(o + (size_t)len[i] / 4);
-            memcpy(hwords.data() + o, arr[i], (size_t)len[i]);
-        }
-        return RGBD_OK;
-    };
-    int r = push(ys, ylen, n_y, yoff, ylw);
-    if (!r) r = push(zs, zlen, B, zoff, zlw);
-    if (r) return r;
-    std::vector<int64_t> hmeta;  // y off[n_y], y len[n_y], z off[B], z len[B], y base[B], z base[B]
-    hmeta.insert(hmeta.end(), yoff.begin(), yoff.end());
-    hmeta.insert(hmeta.end(), ylw.begin(), ylw.end());
-    hmeta.insert(hmeta.end(), zoff.begin(), zoff.end());
-    hmeta.insert(hmeta.end(), zlw.begin(), zlw.end());
-    const size_t o_ybase = hmeta.size();
-    for (int b = 0; b < B; ++b) hmeta.push_back(per_image ? (int64_t)b * T : 0);
-    const size_t o_zbase = hmeta.size();
-    for (int b = 0; b < B; ++b) hmeta.push_back((int64_t)b * Tz);
-    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * hmeta.size());
-    uint32_t* words = (uint32_t*)arena.take(sizeof(uint32_t) * (hwords.size() + 4));
+
+    // ==== prologue (never captured): upload the streams, every stream into a slot of the size the encoder may produce for
+    // this shape, so that the workspace layout (and with it a cached graph) does not depend on the stream lengths
+    const int64_t ycount = per_image ? T : T * B;
+    const int64_t ycap = ((5 * ycount + 32 + 704) + 63) & ~(int64_t)63, zcap = ((5 * Tz + 32 + 704) + 63) & ~(int64_t)63;
+    // meta64: y off[n_y], y len[n_y], z off[B], z len[B], y base[B], z base[B]
+    const size_t nmeta = (size_t)2 * n_y + (size_t)4 * B;
+    const size_t o_zoff = (size_t)2 * n_y, o_ybase = (size_t)2 * n_y + 2 * B, o_zbase = o_ybase + B;
+    int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * nmeta);
+    uint32_t* words = (uint32_t*)arena.take(sizeof(uint32_t) * ((size_t)n_y * ycap + (size_t)B * zcap + 4));
     uint64_t* state = (uint64_t*)arena.take(sizeof(uint64_t) * (size_t)(2 * (n_y + B)));
     int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
     int32_t* idx = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
@@ -3086,43 +3068,84 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
         dbg_x = (float*)arena.take(sizeof(float) * (size_t)(B * T));
         dbg_s = (float*)arena.take(sizeof(float) * (size_t)(B * T));
     }
+    for (int i = 0; i < n_y; ++i)
+        if (!ys[i] || ylen[i] < 8 || (ylen[i] & 3) || ylen[i] / 4 > ycap) return RGBD_EINVAL;
+    for (int i = 0; i < B; ++i)
+        if (!zs[i] || zlen[i] < 8 || (zlen[i] & 3) || zlen[i] / 4 > zcap) return RGBD_EINVAL;
     if (!dry()) {
-        HIP_TRY(hipMemcpyAsync(meta64, hmeta.data(), sizeof(int64_t) * hmeta.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(words, hwords.data(), sizeof(uint32_t) * hwords.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        size_t total_words = 0;
+        for (int i = 0; i < n_y; ++i) total_words += (size_t)ylen[i] / 4;
+        for (int i = 0; i < B; ++i) total_words += (size_t)zlen[i] / 4;
+        void* pv = nullptr;
+        if (const int r = pin_take(nmeta * sizeof(int64_t) + total_words * 4, &pv)) return r;
+        int64_t* hmeta = (int64_t*)pv;
+        uint32_t* hw = (uint32_t*)(hmeta + nmeta);
+        size_t used = 0;
+        auto put = [&](const uint8_t* src, int64_t len, size_t slot_off, size_t meta_off, size_t meta_len) -> int {
+            memcpy(hw + used, src, (size_t)len);
+            hmeta[meta_off] = (int64_t)slot_off;
+            hmeta[meta_len] = len / 4;
+            HIP_TRY(hipMemcpyAsync(words + slot_off, hw + used, (size_t)len, hipMemcpyHostToDevice, s));
+            used += (size_t)len / 4;
+            return RGBD_OK;
+        };
+        for (int i = 0; i < n_y; ++i)
+            if (const int r = put(ys[i], ylen[i], (size_t)i * (size_t)ycap, (size_t)i, (size_t)n_y + i)) return r;
+        for (int i = 0; i < B; ++i)
+            if (const int r = put(zs[i], zlen[i], (size_t)n_y * ycap + (size_t)i * (size_t)zcap, o_zoff + i, o_zoff + B + i))
+                return r;
+        for (int b = 0; b < B; ++b) {
+            hmeta[o_ybase + b] = per_image ? (int64_t)b * T : 0;
+            hmeta[o_zbase + b] = (int64_t)b * Tz;
+        }
+        HIP_TRY(hipMemcpyAsync(meta64, hmeta, sizeof(int64_t) * nmeta, hipMemcpyHostToDevice, s));
+        if (const int r = pin_release()) return r;
     }
-    Act zhat = alloc(B, zh, zw, N);
-    float* md = dense_of("entropy_bottleneck.medians");
-    if (!dry() && md) {
-        int q = launch_fill_zero(zhat.p, zhat.elems(), s);
-        if (!q) q = launch_z_quant(zhat.p, zhat.cs, B, zh, zw, N, md, zsym, zidx, s);  // indexes = channel id
-        if (!q)
-            q = launch_rans_decode(words, meta64 + 2 * n_y, meta64 + 2 * n_y + B, B, state + (size_t)2 * n_y, 1, zidx, zsym,
-                                   meta64 + o_zbase, 0, Tz, tables[2].d, s);
-        if (!q) q = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
-        if (q) fail(q);
+
+    // ==== body: captured into / replayed from a HIP graph per call shape ================================================
+    Act xh;
+    if (body_begin()) {
+        Act zhat = alloc(B, zh, zw, N);
+        float* md = dense_of("entropy_bottleneck.medians");
+        if (!dry() && md) {
+            int q = launch_fill_zero(zhat.p, zhat.elems(), s);
+            if (!q) q = launch_z_quant(zhat.p, zhat.cs, B, zh, zw, N, md, zsym, zidx, s);  // indexes = channel id
+            if (!q)
+                q = launch_rans_decode(words, meta64 + o_zoff, meta64 + o_zoff + B, B, state + (size_t)2 * n_y, 1, zidx, zsym,
+                                       meta64 + o_zbase, 0, Tz, tables[2].d, s);
+            if (!q) q = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
+            if (q) fail(q);
+        }
+        named["zhat"] = zhat;
+        Act hyper = h_s1(zhat);
+        named["hyper"] = hyper;
+        Act yhat = alloc(B, h, w, M);
+        named["yhat"] = yhat;
+        Coding cd;
+        cd.encode = false;
+        cd.per_image = per_image;
+        cd.per_image_total = T;
+        cd.sym = sym;
+        cd.idx = idx;
+        cd.stream_base = meta64 + o_ybase;
+        cd.words = words;
+        cd.stream_off = meta64;
+        cd.stream_len = meta64 + n_y;
+        cd.state = state;
+        cd.nstreams = n_y;
+        bicee1(cd, nullptr, hyper, yhat);
+        xh = g_s1(yhat);
+        if (cur_ge && !dry()) cur_ge->out[0] = xh;
+    } else {
+        xh = cur_ge->out[0];
     }
-    named["zhat"] = zhat;
-    Act hyper = h_s1(zhat);
-    named["hyper"] = hyper;
-    Act yhat = alloc(B, h, w, M);
-    named["yhat"] = yhat;
-    Coding cd;
-    cd.encode = false;
-    cd.per_image = per_image;
-    cd.per_image_total = T;
-    cd.sym = sym;
-    cd.idx = idx;
-    cd.stream_base = meta64 + o_ybase;
-    cd.words = words;
-    cd.stream_off = meta64;
-    cd.stream_len = meta64 + n_y;
-    cd.state = state;
-    cd.nstreams = n_y;
-    bicee1(cd, nullptr, hyper, yhat);
-    Act xh = g_s1(yhat);
-    if (rc) return rc;
+    {
+        const int r = body_end();
+        if (rc) return rc;
+        if (r) return r;
+    }
     if (dry()) return RGBD_OK;
+    // ==== epilogue (never captured)
     return launch_nhwc_to_nchw_clamp(xh.p, B, in_ch, H, W, xh.cs, x_out, 0, s);  // elic.py:318-325: not clamped
 }
 
@@ -3784,14 +3807,9 @@ int rgbd_elic_decompress_single(rgbd_elic* m, const uint8_t* const* y, const int
     if (m->variant != 1 || !y || !y_len || !z || !z_len || !x_dev || B <= 0 || zh <= 0 || zw <= 0) return RGBD_EINVAL;
     if (n_y != 1 && n_y != B) return RGBD_EINVAL;
     if (const int ur = m->use_stream(stream)) return ur;
-    m->arena.dry = true;
-    m->arena.top = m->arena.peak = 0;
-    r = m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev);
-    m->arena.dry = false;
-    if (r) return r;
-    r = m->ensure_arena(m->arena.peak);
-    if (r) return r;
-    r = m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev);
+    char key[96];
+    snprintf(key, sizeof(key), "d1|%d|%d|%d|%d", B, zh, zw, n_y);
+    r = run_sized(m, key, [&]() { return m->run_decompress1(y, y_len, n_y, z, z_len, B, zh, zw, x_dev); });
     if (!r) r = m->wait_stream();  // (the work may sit on the engine's own stream: return when x_hat is there)
     if (m->profile && !r) m->profile_collect();
     return r;

@@ -137,9 +137,8 @@ def test_single_modal_eval_forward(net1, orc1):
 
 
 def test_single_modal_graphs_on_a_side_stream(net1):
-    """compress() and forward() of the single-modal model capture their kernel sequence on the second call of a shape and
-    replay it afterwards (decompress() keeps launching eagerly: its workspace follows the stream lengths); eager, captured
-    and replayed calls agree bit for bit."""
+    """compress(), forward() and decompress() of the single-modal model capture their kernel sequence on the second call of
+    a shape and replay it afterwards; eager, captured and replayed calls agree bit for bit."""
     from rgbd_amd import synth
 
     r, _ = synth.synthetic_batch(2, 128, 128, config_id=12)
@@ -151,7 +150,7 @@ def test_single_modal_graphs_on_a_side_stream(net1):
             f = net1(x)
             d = net1.decompress(c["strings"], c["shape"])
             outs.append((c["strings"], f["x_hat"].clone(), f["likelihoods"]["y_likelihoods"].clone(), d["x_hat"].clone()))
-        assert net1.graph_count() >= 2  # compress and forward of this shape
+        assert net1.graph_count() >= 3  # compress, forward and decompress of this shape
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert o[0] == outs[0][0] and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2]) and torch.equal(o[3], outs[0][3])
