@@ -920,8 +920,8 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
 
     // stream words: lane k of wcur holds word wpos0 + k, wnext the following 64 words (already in flight); wi = index
     // of the next unread word inside wcur.  The window is re-aligned (wi = 0) at the start of every 64-symbol batch and
-    // after every escape, so the ordinary symbols of a batch (at most one word each) can never run past lane 63 and
-    // the hot loop reads words with a bare readlane.
+    // behind an escape whose words leave fewer than one per remaining symbol of the batch, so the ordinary symbols (at most
+    // one word each) can never run past lane 63 and the hot loop reads words with a bare readlane.
     int64_t wpos0 = pos;
     int wi = 0;
     uint32_t wcur = (wpos0 + lane < nwords) ? st[wpos0 + lane] : 0u;
