@@ -163,28 +163,12 @@ def test_rows_around_the_lane_count(seed):
     require_gpu()
     from rgbd_amd import ans
 
-    rng = np.random.RandomState(100 + seed)
-    slots = [2, 3, 5, 17, 31, 32, 33, 62, 63, 64, 65, 66, 70]
-    stride = max(slots) + 1
-    cdf = np.zeros((len(slots), stride), np.int32)
-    for r, n in enumerate(slots):
-        f = np.ones(n, np.int64)
-        extra = rng.multinomial(65536 - n, rng.dirichlet(np.full(n, 0.3)))
-        f += extra
-        cdf[r, : n + 1] = np.concatenate([[0], np.cumsum(f)])
-        assert cdf[r, n] == 65536
-    sizes = np.array([n + 1 for n in slots], np.int32)
-    offsets = np.array([-(n // 2) for n in slots], np.int32)
+    from coder_cases import lane_edge_symbols, lane_edge_tables
+
+    cdf, sizes, offsets, rng = lane_edge_tables(seed)
     t, ot = ans.Tables(cdf, sizes, offsets), coder.Tables(cdf, sizes, offsets)
     for n in (1, 63, 64, 65, 4000):
-        idx = rng.randint(0, len(slots), n).astype(np.int32)
-        v = (rng.rand(n) * (sizes[idx] - 2)).astype(np.int64)      # a table slot (escape slot excluded) ...
-        edge = rng.rand(n)
-        v = np.where(edge < 0.15, 0, np.where(edge < 0.3, sizes[idx] - 3, v))
-        sym = v + offsets[idx]
-        esc = rng.rand(n) < 0.1                                     # ... or an escape on either side
-        far = (2.0 ** rng.uniform(0, 20, n)).astype(np.int64)
-        sym = np.where(esc, np.where(rng.rand(n) < 0.5, offsets[idx] - far, offsets[idx] + sizes[idx] - 2 + far), sym).astype(np.int32)
+        idx, sym = lane_edge_symbols(rng, n, sizes, offsets)
         s = ans._encode(t, sym, idx)
         assert s == coder.rans_encode(sym, idx, ot)
         d = ans.RansDecoder()

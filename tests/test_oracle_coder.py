@@ -113,3 +113,28 @@ def test_against_reference_cpp(seed, kat, gc_tables):
         p = rng.rand(m).astype(np.float32) ** 4
         p /= p.sum()
         assert coder.pmf_to_quantized_cdf(p).tolist() == ref["_CXX"].pmf_to_quantized_cdf([float(v) for v in p], 16)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_lane_edge_tables_against_reference_cpp(seed):
+    """The table family of tests/test_gpu_coder.py::test_rows_around_the_lane_count (rows of 2 ... 70 slots, frequency-1
+    symbols, escapes on both sides) through the reference's own C++ coder: pins the oracle on exactly the inputs the GPU
+    decoder's lane-count edges are tested with."""
+    from coder_cases import lane_edge_symbols, lane_edge_tables
+
+    ref = coder.load_reference_coder()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref needs /root/reference)")
+    cdf, sizes, offsets, rng = lane_edge_tables(seed)
+    ot = coder.Tables(cdf, sizes, offsets)
+    cdf_l, sz_l, off_l = cdf.tolist(), sizes.tolist(), offsets.tolist()
+    for n in (1, 63, 64, 65, 4000):
+        idx, sym = lane_edge_symbols(rng, n, sizes, offsets)
+        if n < 2:  # (the reference's flush() under-allocates its output for fewer than two symbols: rans_interface.cpp:171)
+            continue
+        want = ref["ans"].RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf_l, sz_l, off_l)
+        assert coder.rans_encode(sym, idx, ot) == want
+        d_ref = ref["ans"].RansDecoder()
+        d_ref.set_stream(want)
+        assert d_ref.decode_stream(idx.tolist(), cdf_l, sz_l, off_l) == sym.tolist()
+        assert coder.rans_decode(want, idx, ot).tolist() == sym.tolist()
