@@ -945,7 +945,6 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         }
         return rdl(wcur, wi++);
     };
-    typedef __attribute__((address_space(3))) const uint2 lds_u2;
     const uint32_t dsm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm;
     const uint32_t cm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)cm;
     const uint32_t pk_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)pk;
