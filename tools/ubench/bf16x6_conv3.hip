@@ -1,0 +1,238 @@
+// Third stage of the split-bf16 experiment: a whole 3x3 stride-1 layer with the design the second stage pointed at
+// -- 32-channel stages, the fp32 patch split into three bf16 planes ONCE at staging time (every staged element is used by all
+// nine taps), weights split once beforehand, six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product block.
+//   X [N][H][W][C] fp32, Wt [Co][9][C] fp32 (tap = 3 dy + dx, zero padding 1), Y [N][H][W][Co] = relu(conv + bias)
+//   workgroup: 8 x 32 output pixels x 48 output channels, 4 waves (wave w: rows 2w, 2w+1 = four 16-pixel tiles x three
+//   16-channel tiles); LDS: patch 10 x 34 pixels x 3 planes x 64 B + weights 9 taps x 48 x 3 planes x 64 B = 145 KB.
+//   16-byte chunks (8 channels) of a pixel / weight row are XOR-swizzled by ((index >> 2) & 3): conflict-free ds_read_b128.
+//   hipcc --offload-arch=gfx950 -O2 bf16x6_conv3.hip -o bf16x6_conv3 && ./bf16x6_conv3
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __host__ inline unsigned f2u(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
+__device__ __host__ inline float u2f(unsigned u) { float x; memcpy(&x, &u, 4); return x; }
+__device__ __forceinline__ void split3(float v, u16& h, u16& m, u16& l)
+{
+    unsigned u = f2u(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+    h = (u16)(u >> 16);
+    v -= u2f(u);
+    u = f2u(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+    m = (u16)(u >> 16);
+    v -= u2f(u);
+    u = f2u(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    l = (u16)(u >> 16);
+}
+__global__ void split_kernel(const float* __restrict__ x, u16* __restrict__ planes, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        u16 h, m, l;
+        split3(x[i], h, m, l);
+        planes[i] = h;
+        planes[n + i] = m;
+        planes[2 * n + i] = l;
+    }
+}
+
+// weights as the kernel's LDS image, so that staging them is a linear copy by LDS DMA:
+// img[coblk][chunk][plane][row = tap * COT + co][64 B: 8-channel pieces at (kb ^ ((co >> 2) & 3)) * 16]
+__global__ void weight_image_kernel(const float* __restrict__ w, u16* __restrict__ img, int Co, int C)
+{
+    const int nchunk = C / 32, ncb = Co / 48;
+    const size_t total = (size_t)ncb * nchunk * 9 * 48 * 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 32), co = (int)((i / 32) % 48), tap = (int)((i / (32 * 48)) % 9);
+        const int chunk = (int)((i / (32 * 48 * 9)) % nchunk), cb = (int)(i / ((size_t)32 * 48 * 9 * nchunk));
+        u16 p[3];
+        split3(w[((size_t)(cb * 48 + co) * 9 + tap) * C + chunk * 32 + ch], p[0], p[1], p[2]);
+        const int kb = ch >> 3;
+        const size_t row = (size_t)tap * 48 + co;
+        for (int pl = 0; pl < 3; ++pl)
+            img[((((size_t)cb * nchunk + chunk) * 3 + pl) * (9 * 48) + row) * 32 + ((kb ^ ((co >> 2) & 3)) * 8) + (ch & 7)] = p[pl];
+    }
+}
+
+#define TH 8
+#define TW 32
+#define PW (TW + 2)
+#define NPX ((TH + 2) * PW)  // 340 patch pixels
+#define COT 48
+#define PATCH_B (NPX * 64)       // one plane
+#define WTS_B (9 * COT * 64)     // one plane
+__global__ __launch_bounds__(256) void conv3_bf16x6(const float* __restrict__ X, const u16* __restrict__ Wp, const float* __restrict__ bias,
+                                                    float* __restrict__ Y, int N, int H, int W, int C, int Co)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* patch = lds;                 // [3][NPX][64]
+    unsigned char* wts = lds + 3 * PATCH_B;     // [3][9][COT][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int t = blockIdx.x, n = t / (tiles_x * tiles_y), ty = (t / tiles_x) % tiles_y, tx = t % tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW, co0 = blockIdx.y * COT;
+    const size_t nW = (size_t)Co * 9 * C;
+    f32x4 acc[3][4];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // patch staging, fixed per thread for all chunks: item u = (patch pixel, 4-channel piece); global offset (or -1 outside the
+    // image) and LDS offset computed once
+    constexpr int PU = (NPX * 8 + 255) / 256;  // 11
+    int goff[PU], loff[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int f = tid + u * 256;
+        const int c4 = f & 7, ppx = f >> 3, py = ppx / PW, px = ppx % PW;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const bool in = f < NPX * 8 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[u] = in ? (int)((((size_t)n * H + gy) * W + gx) * C + c4 * 4) : -1;
+        loff[u] = f < NPX * 8 ? ppx * 64 + (((c4 >> 1) ^ ((ppx >> 2) & 3)) * 16) + (c4 & 1) * 8 : -1;
+    }
+    f32x4 pre[PU];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) pre[u] = goff[u] >= 0 ? *reinterpret_cast<const f32x4*>(X + goff[u] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    const int nchunk = C / 32;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    gload(0);
+    for (int c0 = 0, chunk = 0; c0 < C; c0 += 32, ++chunk) {
+        __syncthreads();  // the previous chunk's fragments have been read
+        // weights of this chunk: a linear 3 x 27,648-byte copy by LDS DMA (1 KB per wave-load)
+        {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(Wp) + ((size_t)blockIdx.y * nchunk + chunk) * (3 * WTS_B);
+            for (int w = wave_u; w < 3 * WTS_B / 1024; w += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(wts + w * 1024), 16, 0, 0);
+        }
+        // patch of this chunk from the prefetched registers: split into the three planes here, once
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+            if (loff[u] >= 0) {
+                u16x4 h, m, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u16 a, b, c;
+                    split3(pre[u][e], a, b, c);
+                    h[e] = a;
+                    m[e] = b;
+                    l[e] = c;
+                }
+                *reinterpret_cast<u16x4*>(patch + 0 * PATCH_B + loff[u]) = h;
+                *reinterpret_cast<u16x4*>(patch + 1 * PATCH_B + loff[u]) = m;
+                *reinterpret_cast<u16x4*>(patch + 2 * PATCH_B + loff[u]) = l;
+            }
+        if (c0 + 32 < C) gload(c0 + 32);  // the next chunk's patch travels under this chunk's MFMAs
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PU) : "memory");  // the weight DMA (older than the prefetch) has landed
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            bf16x8 a[3][3], b[4][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int co = i * 16 + l15;
+                const int off = (tap * COT + co) * 64 + ((q ^ ((co >> 2) & 3)) * 16);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(wts + pl * WTS_B + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ppx = (2 * wave + (j >> 1) + dy) * PW + (j & 1) * 16 + l15 + dx;
+                const int off = ppx * 64 + ((q ^ ((ppx >> 2) & 3)) * 16);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(patch + pl * PATCH_B + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // D: column = pixel l15 of tile j, rows 4q .. 4q+3 = output channels of tile i
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co0 + i * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 + 2 * wave + (j >> 1), gx = x0 + (j & 1) * 16 + l15;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[i][j][r] + bv[r], 0.f);
+            *reinterpret_cast<f32x4*>(Y + (((size_t)n * H + gy) * W + gx) * Co + co0 + i * 16 + 4 * q) = o;
+        }
+    }
+}
+
+int main()
+{
+    // (H a multiple of 8, W of 32, C of 32, Co of 48: the experiment has no edge tiles)
+    struct { const char* name; int N, H, W, C, Co; } shapes[] = {{"4 x 128x160, 3x3 96 -> 96", 4, 128, 160, 96, 96}, {"4 x 256x320, 3x3 96 -> 96", 4, 256, 320, 96, 96},
+                                                                 {"4 x 64x96, 3x3 96 -> 96", 4, 64, 96, 96, 96},     {"4 x 32x64, 3x3 160 -> 144", 4, 32, 64, 160, 144}};
+    const size_t lds = 3 * PATCH_B + 3 * WTS_B;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    srand(3);
+    for (auto& s : shapes) {
+        const size_t nX = (size_t)s.N * s.H * s.W * s.C, nW = (size_t)s.Co * 9 * s.C, nY = (size_t)s.N * s.H * s.W * s.Co;
+        float *hX = (float*)malloc(nX * 4), *hW = (float*)malloc(nW * 4), *hb = (float*)malloc(s.Co * 4), *hY = (float*)malloc(nY * 4);
+        for (size_t i = 0; i < nX; ++i) hX[i] = (float)((rand() % 2001) - 1000) / 500.f * (1.f + (rand() % 97) * 1e-4f);
+        for (size_t i = 0; i < nW; ++i) hW[i] = (float)((rand() % 2001) - 1000) / 20000.f * (1.f + (rand() % 89) * 1e-4f);
+        for (int i = 0; i < s.Co; ++i) hb[i] = 0.01f * i;
+        float *X, *Wt, *b, *Y;
+        u16* Wp;
+        (void)hipMalloc(&X, nX * 4); (void)hipMalloc(&Wt, nW * 4); (void)hipMalloc(&b, s.Co * 4); (void)hipMalloc(&Y, nY * 4); (void)hipMalloc(&Wp, nW * 6);
+        (void)hipMemcpy(X, hX, nX * 4, hipMemcpyHostToDevice); (void)hipMemcpy(Wt, hW, nW * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(b, hb, s.Co * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(weight_image_kernel, dim3(512), dim3(256), 0, 0, Wt, Wp, s.Co, s.C);
+        const dim3 grid(s.N * (s.H / TH) * (s.W / TW), s.Co / COT);
+        hipLaunchKernelGGL(conv3_bf16x6, grid, dim3(256), lds, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(conv3_bf16x6, grid, dim3(256), lds, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= 10;
+        (void)hipMemcpy(hY, Y, nY * 4, hipMemcpyDeviceToHost);
+        double err = 0;
+        for (int tsm = 0; tsm < 3000; ++tsm) {
+            const int n = rand() % s.N, y = tsm < 200 ? (tsm & 1 ? 0 : s.H - 1) : rand() % s.H, x = tsm < 200 ? (tsm & 2 ? 0 : s.W - 1) : rand() % s.W, co = rand() % s.Co;
+            double ref = hb[co], mag = 0;
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int gy = y + dy - 1, gx = x + dx - 1;
+                    if (gy < 0 || gy >= s.H || gx < 0 || gx >= s.W) continue;
+                    for (int c = 0; c < s.C; ++c) {
+                        const double p = (double)hX[(((size_t)n * s.H + gy) * s.W + gx) * s.C + c] * hW[((size_t)co * 9 + dy * 3 + dx) * s.C + c];
+                        ref += p;
+                        mag += fabs(p);
+                    }
+                }
+            ref = ref > 0 ? ref : 0;
+            err = fmax(err, fabs(hY[(((size_t)n * s.H + y) * s.W + x) * s.Co + co] - ref) / mag);
+        }
+        const double gf = 2.0 * s.N * s.H * s.W * s.Co * 9.0 * s.C / 1e9;
+        printf("%-28s bf16x6: %8.1f us  %6.1f TFLOP/s fp32-equivalent  (max err / sum|x||w| %.1e)\n", s.name, ms * 1e3, gf / ms, err);
+        (void)hipFree(X); (void)hipFree(Wt); (void)hipFree(b); (void)hipFree(Y); (void)hipFree(Wp);
+        free(hX); free(hW); free(hb); free(hY);
+    }
+    return 0;
+}
