@@ -451,6 +451,131 @@ __global__ __launch_bounds__(256) void conv3_bf16x6_v3(const float* __restrict__
     }
 }
 
+
+// ---- fourth cut: the third cut's layout and unrolling with 16-channel stages and tap pairs (second cut), so that TWO workgroups
+// of 80 KB share a CU and overlap each other's start-up, staging and epilogue.  K = 32 of one MFMA step = tap A x 16 channels
+// (lane groups q = 0, 1) + tap B x 16 channels (q = 2, 3); the ninth tap pairs with a tenth, all-zero weight tap.
+#define WR4 7680   // bytes per (plane, kb) region of the weights: 10 taps x 48 channels x 16 B (= 30 x 256)
+__global__ void weight_image4_kernel(const float* __restrict__ w, u16* __restrict__ img, int Co, int C)
+{
+    const int nchunk = C / 16, ncb = Co / 48;
+    const size_t total = (size_t)ncb * nchunk * 10 * 48 * 16;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 16), co = (int)((i / 16) % 48), tap = (int)((i / (16 * 48)) % 10);
+        const int chunk = (int)((i / (16 * 48 * 10)) % nchunk), cb = (int)(i / ((size_t)16 * 48 * 10 * nchunk));
+        u16 p[3] = {0, 0, 0};
+        if (tap < 9) split3(w[((size_t)(cb * 48 + co) * 9 + tap) * C + chunk * 16 + ch], p[0], p[1], p[2]);
+        const int kb = ch >> 3;
+        for (int pl = 0; pl < 3; ++pl)  // image of one (coblk, chunk): [plane][kb][tap * 48 + co][8 bf16]
+            img[(((size_t)cb * nchunk + chunk) * 6 + pl * 2 + kb) * (WR4 / 2) + (size_t)(tap * 48 + co) * 8 + (ch & 7)] = p[pl];
+    }
+}
+__global__ __launch_bounds__(256, 2) void conv3_bf16x6_v4(const float* __restrict__ X, const u16* __restrict__ Wp, const float* __restrict__ bias,
+                                                          float* __restrict__ Y, int N, int H, int W, int C, int Co)
+{
+    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+    unsigned char* patch = lds;             // [3][2][PR3]
+    unsigned char* wts = lds + 6 * PR3;     // [3][2][WR4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4, kb = q & 1, hiq = q >> 1;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int t = blockIdx.x, n = t / (tiles_x * tiles_y), ty = (t / tiles_x) % tiles_y, tx = t % tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW, co0 = blockIdx.y * COT;
+    f32x4 acc[3][4];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int PU = (NPX * 2 + 255) / 256;  // 3: item = (patch pixel, 8-channel block)
+    int goff[PU], loff[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int f = tid + u * 256;
+        const int kbs = f & 1, ppx = f >> 1, py = ppx / PW, px = ppx % PW;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const bool in = f < NPX * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[u] = in ? (int)((((size_t)n * H + gy) * W + gx) * C + kbs * 8) : -1;
+        loff[u] = f < NPX * 2 ? kbs * PR3 + ppx * 16 : -1;
+    }
+    f32x4 pre[PU][2];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            pre[u][0] = goff[u] >= 0 ? *reinterpret_cast<const f32x4*>(X + goff[u] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            pre[u][1] = goff[u] >= 0 ? *reinterpret_cast<const f32x4*>(X + goff[u] + c0 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int nchunk = C / 16;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    // per-lane fragment bases per step: this lane group's tap of the step (2 st + hiq; tap 9 = the zero tap, patch offset 0)
+    const unsigned char *ab[5], *bb[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int tap = 2 * st + hiq, tp = tap < 9 ? tap : 0;
+        ab[st] = wts + kb * WR4 + (tap * COT + l15) * 16;
+        bb[st] = patch + kb * PR3 + ((2 * wave + tp / 3) * PW + (tp % 3) + l15) * 16;
+    }
+    gload(0);
+    for (int c0 = 0, chunk = 0; c0 < C; c0 += 16, ++chunk) {
+        __syncthreads();
+        {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(Wp) + ((size_t)blockIdx.y * nchunk + chunk) * (6 * WR4);
+            for (int w = wave_u; w < 6 * WR4 / 1024; w += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(wts + w * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+            if (loff[u] >= 0) {
+                unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    u16 a0, b0, c0_, a1, b1, c1;
+                    split3(pre[u][e >> 2][e & 3], a0, b0, c0_);
+                    split3(pre[u][e >> 2][(e & 3) + 1], a1, b1, c1);
+                    hw[e >> 1] = (unsigned)a0 | ((unsigned)a1 << 16);
+                    mw[e >> 1] = (unsigned)b0 | ((unsigned)b1 << 16);
+                    lw[e >> 1] = (unsigned)c0_ | ((unsigned)c1 << 16);
+                }
+                *reinterpret_cast<uint4*>(patch + 0 * 2 * PR3 + loff[u]) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                *reinterpret_cast<uint4*>(patch + 1 * 2 * PR3 + loff[u]) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+                *reinterpret_cast<uint4*>(patch + 2 * 2 * PR3 + loff[u]) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            }
+        if (c0 + 16 < C) gload(c0 + 16);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PU) : "memory");
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            bf16x8 a[3][3], b[4][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(ab[st] + pl * 2 * WR4 + i * 16 * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j][pl] = *reinterpret_cast<const bf16x8*>(bb[st] + pl * 2 * PR3 + ((j >> 1) * PW + (j & 1) * 16) * 16);
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[term]], b[j][PB[term]], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co0 + i * 16 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 + 2 * wave + (j >> 1), gx = x0 + (j & 1) * 16 + l15;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[i][j][r] + bv[r], 0.f);
+            *reinterpret_cast<f32x4*>(Y + (((size_t)n * H + gy) * W + gx) * Co + co0 + i * 16 + 4 * q) = o;
+        }
+    }
+}
+
 int main()
 {
     // (H a multiple of 8, W of 32, C of 32, Co of 48: the experiment has no edge tiles)
@@ -460,6 +585,7 @@ int main()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v2), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PATCH16_B + 3 * WTS16_B);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v3), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * PR3 + 12 * WR3);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v4), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PR3 + 6 * WR4);
     srand(3);
     for (auto& s : shapes) {
         const size_t nX = (size_t)s.N * s.H * s.W * s.C, nW = (size_t)s.Co * 9 * s.C, nY = (size_t)s.N * s.H * s.W * s.Co;
@@ -469,22 +595,25 @@ int main()
         for (int i = 0; i < s.Co; ++i) hb[i] = 0.01f * i;
         float *X, *Wt, *b, *Y;
         u16* Wp;
-        (void)hipMalloc(&X, nX * 4); (void)hipMalloc(&Wt, nW * 4); (void)hipMalloc(&b, s.Co * 4); (void)hipMalloc(&Y, nY * 4); (void)hipMalloc(&Wp, nW * 6);
+        (void)hipMalloc(&X, nX * 4); (void)hipMalloc(&Wt, nW * 4); (void)hipMalloc(&b, s.Co * 4); (void)hipMalloc(&Y, nY * 4); (void)hipMalloc(&Wp, nW * 7);
         (void)hipMemcpy(X, hX, nX * 4, hipMemcpyHostToDevice); (void)hipMemcpy(Wt, hW, nW * 4, hipMemcpyHostToDevice);
         (void)hipMemcpy(b, hb, s.Co * 4, hipMemcpyHostToDevice);
         const dim3 grid(s.N * (s.H / TH) * (s.W / TW), s.Co / COT);
         const size_t lds2 = 3 * PATCH16_B + 3 * WTS16_B;
         const size_t lds3 = 12 * PR3 + 12 * WR3;
-        float ms_v[3];
-        double err_v[3];
-        for (int ver = 0; ver < 3; ++ver) {
+        const size_t lds4 = 6 * PR3 + 6 * WR4;
+        float ms_v[4];
+        double err_v[4];
+        for (int ver = 0; ver < 4; ++ver) {
             if (ver == 0) hipLaunchKernelGGL(weight_image_kernel, dim3(512), dim3(256), 0, 0, Wt, Wp, s.Co, s.C);
             else if (ver == 1) hipLaunchKernelGGL(weight_image16_kernel, dim3(512), dim3(256), 0, 0, Wt, Wp, s.Co, s.C);
-            else hipLaunchKernelGGL(weight_image3_kernel, dim3(512), dim3(256), 0, 0, Wt, Wp, s.Co, s.C);
+            else if (ver == 2) hipLaunchKernelGGL(weight_image3_kernel, dim3(512), dim3(256), 0, 0, Wt, Wp, s.Co, s.C);
+            else hipLaunchKernelGGL(weight_image4_kernel, dim3(512), dim3(256), 0, 0, Wt, Wp, s.Co, s.C);
             auto launch = [&]() {
                 if (ver == 0) hipLaunchKernelGGL(conv3_bf16x6, grid, dim3(256), lds, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
                 else if (ver == 1) hipLaunchKernelGGL(conv3_bf16x6_v2, grid, dim3(256), lds2, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
-                else hipLaunchKernelGGL(conv3_bf16x6_v3, grid, dim3(256), lds3, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+                else if (ver == 2) hipLaunchKernelGGL(conv3_bf16x6_v3, grid, dim3(256), lds3, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+                else hipLaunchKernelGGL(conv3_bf16x6_v4, grid, dim3(256), lds4, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
             };
             (void)hipMemset(Y, 0, nY * 4);
             launch();
@@ -519,8 +648,8 @@ int main()
             err_v[ver] = err;
         }
         const double gf = 2.0 * s.N * s.H * s.W * s.Co * 9.0 * s.C / 1e9;
-        printf("%-28s first cut: %7.1f us %6.1f TFLOP/s (err %.1e) | second (16-ch stages, tap pairs, 2 WG/CU): %7.1f us %6.1f (err %.1e) | third (conflict-free layout, unrolled taps, fragment prefetch): %7.1f us %6.1f (err %.1e)\n",
-               s.name, ms_v[0] * 1e3, gf / ms_v[0], err_v[0], ms_v[1] * 1e3, gf / ms_v[1], err_v[1], ms_v[2] * 1e3, gf / ms_v[2], err_v[2]);
+        printf("%-28s first cut: %7.1f us %6.1f TFLOP/s (err %.1e) | second (16-ch stages, tap pairs, 2 WG/CU): %7.1f us %6.1f (err %.1e) | third (conflict-free layout, unrolled taps, fragment prefetch): %7.1f us %6.1f (err %.1e) | fourth (third's layout, 16-ch stages, 2 WG/CU): %7.1f us %6.1f (err %.1e)\n",
+               s.name, ms_v[0] * 1e3, gf / ms_v[0], err_v[0], ms_v[1] * 1e3, gf / ms_v[1], err_v[1], ms_v[2] * 1e3, gf / ms_v[2], err_v[2], ms_v[3] * 1e3, gf / ms_v[3], err_v[3]);
         (void)hipFree(X); (void)hipFree(Wt); (void)hipFree(b); (void)hipFree(Y); (void)hipFree(Wp);
         free(hX); free(hW); free(hb); free(hY);
     }
