@@ -470,6 +470,8 @@ __global__ void weight_image4_kernel(const float* __restrict__ w, u16* __restric
             img[(((size_t)cb * nchunk + chunk) * 6 + pl * 2 + kb) * (WR4 / 2) + (size_t)(tap * 48 + co) * 8 + (ch & 7)] = p[pl];
     }
 }
+template <int KO>  // knock-outs for timing only (results wrong): 1 no split arithmetic, 2 no patch staging after the first chunk,
+                    // 3 no weight DMA after the first chunk, 4 fragments read once per chunk only, 5 = 2 + 3 + 4
 __global__ __launch_bounds__(256, 2) void conv3_bf16x6_v4(const float* __restrict__ X, const u16* __restrict__ Wp, const float* __restrict__ bias,
                                                           float* __restrict__ Y, int N, int H, int W, int C, int Co)
 {
@@ -517,19 +519,25 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16x6_v4(const float* __restric
         __syncthreads();
         {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(Wp) + ((size_t)blockIdx.y * nchunk + chunk) * (6 * WR4);
+            if (!((KO == 3 || KO == 5) && chunk > 0))
             for (int w = wave_u; w < 6 * WR4 / 1024; w += 4)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(wts + w * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u)
-            if (loff[u] >= 0) {
+            if (loff[u] >= 0 && !((KO == 2 || KO == 5) && chunk > 0)) {
                 unsigned hw[4], mw[4], lw[4];
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     u16 a0, b0, c0_, a1, b1, c1;
-                    split3(pre[u][e >> 2][e & 3], a0, b0, c0_);
-                    split3(pre[u][e >> 2][(e & 3) + 1], a1, b1, c1);
+                    if (KO == 1) {
+                        a0 = b0 = c0_ = (u16)(f2u(pre[u][e >> 2][e & 3]) >> 16);
+                        a1 = b1 = c1 = (u16)(f2u(pre[u][e >> 2][(e & 3) + 1]) >> 16);
+                    } else {
+                        split3(pre[u][e >> 2][e & 3], a0, b0, c0_);
+                        split3(pre[u][e >> 2][(e & 3) + 1], a1, b1, c1);
+                    }
                     hw[e >> 1] = (unsigned)a0 | ((unsigned)a1 << 16);
                     mw[e >> 1] = (unsigned)b0 | ((unsigned)b1 << 16);
                     lw[e >> 1] = (unsigned)c0_ | ((unsigned)c1 << 16);
@@ -538,12 +546,13 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16x6_v4(const float* __restric
                 *reinterpret_cast<uint4*>(patch + 1 * 2 * PR3 + loff[u]) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
                 *reinterpret_cast<uint4*>(patch + 2 * 2 * PR3 + loff[u]) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
             }
-        if (c0 + 16 < C) gload(c0 + 16);
+        if (c0 + 16 < C && !(KO == 2 || KO == 5)) gload(c0 + 16);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PU) : "memory");
         __syncthreads();
+        bf16x8 a[3][3], b[4][3];
 #pragma unroll
         for (int st = 0; st < 5; ++st) {
-            bf16x8 a[3][3], b[4][3];
+            if (!((KO == 4 || KO == 5) && st > 0))
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
@@ -585,7 +594,7 @@ int main()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v2), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PATCH16_B + 3 * WTS16_B);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v3), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * PR3 + 12 * WR3);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v4), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PR3 + 6 * WR4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_bf16x6_v4<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PR3 + 6 * WR4);
     srand(3);
     for (auto& s : shapes) {
         const size_t nX = (size_t)s.N * s.H * s.W * s.C, nW = (size_t)s.Co * 9 * s.C, nY = (size_t)s.N * s.H * s.W * s.Co;
@@ -613,7 +622,7 @@ int main()
                 if (ver == 0) hipLaunchKernelGGL(conv3_bf16x6, grid, dim3(256), lds, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
                 else if (ver == 1) hipLaunchKernelGGL(conv3_bf16x6_v2, grid, dim3(256), lds2, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
                 else if (ver == 2) hipLaunchKernelGGL(conv3_bf16x6_v3, grid, dim3(256), lds3, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
-                else hipLaunchKernelGGL(conv3_bf16x6_v4, grid, dim3(256), lds4, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+                else hipLaunchKernelGGL(conv3_bf16x6_v4<0>, grid, dim3(256), lds4, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
             };
             (void)hipMemset(Y, 0, nY * 4);
             launch();
@@ -650,6 +659,27 @@ int main()
         const double gf = 2.0 * s.N * s.H * s.W * s.Co * 9.0 * s.C / 1e9;
         printf("%-28s first cut: %7.1f us %6.1f TFLOP/s (err %.1e) | second (16-ch stages, tap pairs, 2 WG/CU): %7.1f us %6.1f (err %.1e) | third (conflict-free layout, unrolled taps, fragment prefetch): %7.1f us %6.1f (err %.1e) | fourth (third's layout, 16-ch stages, 2 WG/CU): %7.1f us %6.1f (err %.1e)\n",
                s.name, ms_v[0] * 1e3, gf / ms_v[0], err_v[0], ms_v[1] * 1e3, gf / ms_v[1], err_v[1], ms_v[2] * 1e3, gf / ms_v[2], err_v[2], ms_v[3] * 1e3, gf / ms_v[3], err_v[3]);
+        if (s.H == 256) {  // knock-outs of the fourth cut on the large layer: what each part of the loop costs
+            auto tko = [&](auto kern, const char* what) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PR3 + 6 * WR4);
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds4, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+                (void)hipDeviceSynchronize();
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                (void)hipEventRecord(e0);
+                for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, grid, dim3(256), lds4, 0, X, Wp, b, Y, s.N, s.H, s.W, s.C, s.Co);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                printf("    fourth cut, %-62s %7.1f us\n", what, ms * 100);
+            };
+            tko(conv3_bf16x6_v4<0>, "as is");
+            tko(conv3_bf16x6_v4<1>, "without the split arithmetic");
+            tko(conv3_bf16x6_v4<2>, "patch staged for the first chunk only");
+            tko(conv3_bf16x6_v4<3>, "weights staged for the first chunk only");
+            tko(conv3_bf16x6_v4<4>, "fragments read for the first step of a chunk only");
+            tko(conv3_bf16x6_v4<5>, "all three: MFMAs, barriers, prologue and epilogue");
+        }
         (void)hipFree(X); (void)hipFree(Wt); (void)hipFree(b); (void)hipFree(Y); (void)hipFree(Wp);
         free(hX); free(hW); free(hb); free(hY);
     }
