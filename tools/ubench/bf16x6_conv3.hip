@@ -514,6 +514,10 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16x6_v4(const float* __restric
         ab[st] = wts + kb * WR4 + (tap * COT + l15) * 16;
         bb[st] = patch + kb * PR3 + ((2 * wave + tp / 3) * PW + (tp % 3) + l15) * 16;
     }
+    if (KO >= 10) {  // de-phasing experiment: every other workgroup (by bit KO - 10 of its index) starts ~3 us late
+        if ((blockIdx.x >> (KO - 10)) & 1)
+            __builtin_amdgcn_s_sleep(100);  // 6,400 cycles
+    }
     gload(0);
     for (int c0 = 0, chunk = 0; c0 < C; c0 += 16, ++chunk) {
         __syncthreads();
@@ -679,6 +683,12 @@ int main()
             tko(conv3_bf16x6_v4<3>, "weights staged for the first chunk only");
             tko(conv3_bf16x6_v4<4>, "fragments read for the first step of a chunk only");
             tko(conv3_bf16x6_v4<5>, "all three: MFMAs, barriers, prologue and epilogue");
+            tko(conv3_bf16x6_v4<10>, "as is, workgroups with bit 0 of their index set start 2.7 us late");
+            tko(conv3_bf16x6_v4<11>, "... bit 1");
+            tko(conv3_bf16x6_v4<13>, "... bit 3");
+            tko(conv3_bf16x6_v4<14>, "... bit 4");
+            tko(conv3_bf16x6_v4<18>, "... bit 8");
+            tko(conv3_bf16x6_v4<19>, "... bit 9");
         }
         (void)hipFree(X); (void)hipFree(Wt); (void)hipFree(b); (void)hipFree(Y); (void)hipFree(Wp);
         free(hX); free(hW); free(hb); free(hY);
