@@ -28,6 +28,9 @@ int rgbd_abi_version(void);
  * of spinning.  No reference counterpart (the reference drives one image at a time from one thread); a pooled rank
  * keeps 16 host threads waiting on 16 streams, and 8 ranks share one host. */
 int rgbd_set_blocking_sync(int32_t on);
+/* The policy in force on the current device: 1 blocking sync, 0 anything else, negative on error (tests: CodecPool.close()
+ * must give the device its default policy back). */
+int rgbd_get_blocking_sync(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Table construction (host, one-off).

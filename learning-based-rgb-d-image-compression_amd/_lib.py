@@ -34,6 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(csrc, "build")
     hdrs = [os.path.join(csrc, "common.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
     extra = {"conv_mfma.hip": [os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h")]}
+    hdrs.append(os.path.join(csrc, "splitk_table.h"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(objdir, exist_ok=True)
     jobs, objs = [], []
@@ -86,6 +87,7 @@ def lib():
     sig = {
         "rgbd_abi_version": (ctypes.c_int, []),
         "rgbd_set_blocking_sync": (ctypes.c_int, [c_i32]),
+        "rgbd_get_blocking_sync": (ctypes.c_int, []),
         "rgbd_pmf_to_quantized_cdf": (ctypes.c_int, [f32p, c_i32, c_i32, u32p]),
         "rgbd_tables_create": (ctypes.c_int, [i32p, c_i32, i32p, i32p, c_i32, ctypes.POINTER(c_vp)]),
         "rgbd_tables_destroy": (None, [c_vp]),
@@ -150,7 +152,7 @@ def lib():
     return L
 
 
-EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
+EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
            "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
            "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",

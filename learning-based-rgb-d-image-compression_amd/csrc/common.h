@@ -115,8 +115,25 @@ struct ConvArgs {
 // the summation order of every output is the same in the encoder, the decoder and for any batching of the same images
 extern char g_conv_force[64];
 extern int g_fuse_force, g_fuse_lead_off;  // rgbd_debug_force_fuse (conv_mfma.hip)
-static inline int conv_splitk_for(int cin_pad, int taps_per_phase, long out_px_per_image, int nphase)
+// measured exceptions to the rule below (tools/tune_splitk.py): {out_px_per_image, cin_pad, cout_pad, taps per phase, nphase, S}
+struct SplitKEntry {
+    int out_px, cin_pad, cout_pad, ntaps, nphase, s;
+};
+static const SplitKEntry kSplitKTable[] = {
+#include "splitk_table.h"
+    {0, 0, 0, 0, 0, 0}};
+// 0: the layer shape is not in the table
+static inline int conv_splitk_table(int cin_pad, int cout_pad, int taps_per_phase, long out_px_per_image, int nphase)
 {
+    for (const SplitKEntry* e = kSplitKTable; e->out_px; ++e)
+        if (e->out_px == out_px_per_image && e->cin_pad == cin_pad && e->cout_pad == cout_pad && e->ntaps == taps_per_phase &&
+            e->nphase == nphase)
+            return e->s;
+    return 0;
+}
+static inline int conv_splitk_for(int cin_pad, int cout_pad, int taps_per_phase, long out_px_per_image, int nphase)
+{
+    if (const int t = conv_splitk_table(cin_pad, cout_pad, taps_per_phase, out_px_per_image, nphase)) return t;
     const long K = (long)cin_pad * taps_per_phase;
     int s;
     if (nphase == 1 && out_px_per_image <= 512) {

@@ -76,12 +76,25 @@ __device__ __forceinline__ float sigmoid_f32(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2, bool LEAD = false>
+// NB > 2 (DMA, single-tap stride-1 layers only): a ring of NB stage buffers instead of the double buffer.  A 1x1 layer has
+// MT*NT*4 MFMAs per 16-channel stage (0.2 - 0.9 us) -- less than one global round trip, so with one stage in flight the
+// wave waits for memory at every stage and a CU never has more than one (TM + TP) x 64-byte stage per workgroup on the way
+// (measured: ~2.7 TB/s over the chip whatever the tile).  The ring keeps NB - 1 stages in flight: stage s's
+// loads are waited for with s_waitcnt vmcnt(<loads of the NB - 2 stages issued after it>), not vmcnt(0).
+template <int N>
+__device__ __forceinline__ void rgbd_wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2, bool LEAD = false, int NB = 2>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, int tiles_x, int tiles_y, int taps_per_stage,
                                                int tab_f)
 {
     constexpr int TM = 16 * MT * WM;
     constexpr int TP = 16 * NT * WN;
+    constexpr bool RING = NB > 2;
+    static_assert(!RING || (DMA && KC == 16 && G2 == 0 && TP % 64 == 0), "ring staging: DMA, 16-channel stages, whole waves of patch slots");
     constexpr int RS = KC > 16 ? KC + 4 : KC;  // LDS row stride in floats
     constexpr int C4 = KC / 4;                  // 16-byte slots per row
     constexpr int WR = 8;                       // weight float4 per thread per stage (<= 32 KiB of weights per stage)
@@ -144,8 +157,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     const int PW = ((TW << ck) - 1) * a.IS + a.span_x;
     const int patch_f = PH * PW * RS;                         // floats per patch buffer
     const int wl_f = taps_per_stage * TM * RS;                 // floats per weight buffer
-    float* patch = smem;                                       // [DMA ? 2 : 1][PH*PW][RS]
-    float* wl = smem + (size_t)patch_f * (DMA ? 2 : 1);        // [DMA ? 2 : 1][taps_per_stage][TM][RS]
+    constexpr int NBUF = DMA ? NB : 1;
+    float* patch = smem;                                       // [NBUF][PH*PW][RS]
+    float* wl = smem + (size_t)patch_f * NBUF;                 // [NBUF][taps_per_stage][TM][RS]
 
     const int ntaps = a.taps.n[phase];
     // The tap table is int8 data in the kernel-argument segment; indexing it in the loops below would be a *vector* global
@@ -223,6 +237,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             const int iy = iy0 + pr, ix = ix0 + pc;
             const bool ok = f < npatch4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             gp_off[u] = ok ? (iy * a.W + ix) * a.xcs + c4 * 4 : -1;  // inside image n (xn below): fits 32 bits
+            if constexpr (RING)  // single tap, no halo: a slot outside the image belongs to a pixel that is never stored -- it
+                                 // re-reads a valid pixel so that every wave issues the same number of loads per stage
+                gp_off[u] = (min(max(iy, 0), a.H - 1) * a.W + min(max(ix, 0), a.W - 1)) * a.xcs + c4 * 4;
         }
     }
     const int w_lds0 = (tid / C4) * RS + (tid % C4) * 4;  // slot u adds u * (256 / C4) * RS floats
@@ -308,6 +325,64 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     constexpr int EU = TP * S4 / 256;
     const int oy_off = a.nphase > 1 ? (phase >> 1) : 0;
     const int ox_off = a.nphase > 1 ? (phase & 1) : 0;
+    if constexpr (RING) {
+        // loads per stage of this wave: patch TP*4/256 each; weights (TM*4 + 255)/256 for the first waves, one fewer for the rest
+        constexpr int PL = TP * 4 / 256;
+        constexpr int WLO = TM * 4 / 256, WREM = (TM * 4 % 256) / 64;  // waves [0, WREM) issue WLO + 1 weight loads
+        const bool more = wave < WREM;
+        static_assert(PL <= PR && WLO + 1 <= WR, "ring staging slots");
+        const unsigned tapw0 = (unsigned)__builtin_amdgcn_readlane(my_tap_w, 0);
+        const int nst = __builtin_amdgcn_readfirstlane(nstages);  // (wave-uniform; keeps the loop control on the scalar unit)
+        // one stage = this wave's PL patch loads + WLO (+1) weight loads: no predicates, no per-lane branches
+        auto ring_issue = [&](int st, int buf) {
+            const unsigned ci0 = (unsigned)(ci_lo + st * 16);
+            float* lds_p = patch + buf * patch_f + wave_slot0 * 4;
+            float* lds_w = wl + buf * wl_f + wave_slot0 * 4;
+#pragma unroll
+            for (int u = 0; u < PL; ++u)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(xn) + (size_t)(((unsigned)gp_off[u] + ci0) * 4u)),
+                    (__attribute__((address_space(3))) void*)(lds_p + u * 1024), 16, 0, 0);
+#pragma unroll
+            for (int u = 0; u < WLO; ++u)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(gw) + (size_t)(gw_voff[u] + (tapw0 + ci0) * 4u)),
+                    (__attribute__((address_space(3))) void*)(lds_w + u * 1024), 16, 0, 0);
+            if (more)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(gw) + (size_t)(gw_voff[WLO] + (tapw0 + ci0) * 4u)),
+                    (__attribute__((address_space(3))) void*)(lds_w + WLO * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int st = 0; st < NB - 1; ++st)
+            if (st < nst) ring_issue(st, st);
+        for (int stage = 0; stage < nst; ++stage) {
+            // stage's loads have landed once at most the loads of the NB - 2 stages issued after it are outstanding
+            if (stage + NB - 2 < nst) {
+                if (more) rgbd_wait_vmcnt<(NB - 2) * (PL + WLO + 1)>();
+                else rgbd_wait_vmcnt<(NB - 2) * (PL + WLO)>();
+            } else {
+                rgbd_wait_vmcnt<0>();  // tail: fewer stages behind this one
+            }
+            asm volatile("s_barrier" ::: "memory");  // everyone's part of the stage is in LDS; everyone has left stage - 1
+            if (stage + NB - 1 < nst) ring_issue(stage + NB - 1, (stage + NB - 1) % NB);
+            const int buf = stage % NB;
+            const float* cur_w = wl + buf * wl_f;
+            const float* cur_p = patch + buf * patch_f;
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(cur_w + ((wm * MT + i) * 16 + l15) * RS + q * 4);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) bf[k] = *reinterpret_cast<const f32x4*>(cur_p + brow0[k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
+        }
+    } else {
     if (DMA && nstages > 0) {
         dma_p(0, 0);
         dma_w(0, 0);
@@ -378,6 +453,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             }
         }
     }
+    }  // !RING
 
     if constexpr (G2 > 0) {
         // ---- fused trailing 1x1 (ConvArgs::w2) ---------------------------------------------------------------------
@@ -747,11 +823,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
     }
 }
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int NB = 2>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int tw_log2, int tiles_x, int tiles_y,
                                                          int taps_per_stage, int tab_f)
 {
-    conv_mfma_body<WM, WN, MT, NT, KC, DMA, 0>(a, tw_log2, tiles_x, tiles_y, taps_per_stage, tab_f);
+    conv_mfma_body<WM, WN, MT, NT, KC, DMA, 0, false, NB>(a, tw_log2, tiles_x, tiles_y, taps_per_stage, tab_f);
 }
 
 // The fused variants are compiled for two workgroups per CU (256 registers per lane): left alone, the allocator parks the
@@ -767,7 +843,7 @@ namespace {
 
 constexpr int LDS_BUDGET = 78 * 1024;  // two workgroups per CU (160 KiB LDS)
 
-template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2 = 0, bool LEAD = false>
+template <int WM, int WN, int MT, int NT, int KC, bool DMA, int G2 = 0, bool LEAD = false, int NB = 2>
 int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
 {
     const long budget = lds_cap > 0 ? lds_cap : LDS_BUDGET;
@@ -784,8 +860,10 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
     constexpr int PR = TP >= 128 ? 12 : (TP >= 64 ? 6 : 4);
     if ((long)PH * PW * (KC / 4) > PR * 256) return RGBD_ENOSPC;  // patch registers
+    // ring staging (NB > 2): single-tap stride-1 layers without halo, whole waves of patch slots
+    if (NB > 2 && (max_taps != 1 || a.nphase != 1 || a.IS != 1 || a.ckbd || a.span_y != 1 || a.span_x != 1 || TP % 64)) return RGBD_ENOSPC;
     long room = (8 * 256) / ((long)TM * (KC / 4));               // weight slots per stage (WR)
-    if (DMA) {
+    if (DMA && NB == 2) {
         const long lds_room = (budget - 2 * (long)patch_bytes) / (2 * (long)tap_bytes);
         room = room < lds_room ? room : lds_room;
     }
@@ -794,7 +872,7 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     if (KC > 16 && tps < max_taps) return RGBD_ENOSPC;  // would break the canonical accumulation order
     constexpr int EMT = (TP * (16 * WM * MT + 4) * 4 <= 64 * 1024) ? MT : (MT + 1) / 2;
     const size_t epi_bytes = (size_t)TP * (16 * WM * EMT + 4) * sizeof(float);
-    const size_t stage_bytes = (patch_bytes + (size_t)tps * tap_bytes) * (DMA ? 2 : 1);
+    const size_t stage_bytes = (patch_bytes + (size_t)tps * tap_bytes) * (DMA ? NB : 1);
     // fused tail: two weight-group slabs + the output staging tile (it replaces the ordinary epilogue)
     size_t fuse_bytes = G2 > 0 ? (size_t)2 * MT * G2 * 1024 + (size_t)TP * (16 * G2 + 4) * sizeof(float) : 0;
     if (LEAD) {  // + two slices of the third layer's weights; the u tile is staged over everything at the end
@@ -809,7 +887,7 @@ int launch_cfg(const ConvArgs& a, int tw_log2, hipStream_t s, int lds_cap = 0)
     if (G2 > 0 && (lds > (size_t)LDS_BUDGET + 256 || a.cout_pad != TM || a.cout2_pad % (16 * (G2 > 0 ? G2 : 1)))) return RGBD_ENOSPC;
     void (*kern)(ConvArgs, int, int, int, int, int);
     if constexpr (G2 > 0) kern = conv_mfma_kernel_fused<WM, WN, MT, NT, KC, DMA, G2, LEAD>;
-    else kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA>;
+    else kern = conv_mfma_kernel<WM, WN, MT, NT, KC, DMA, NB>;
     if (lds > 64 * 1024) {  // the attribute is per device: one flag per (instantiation, device), set under a lock
         static std::mutex mu;
         static bool configured[64] = {false};
@@ -850,7 +928,24 @@ struct Choice {
     int wm, mt, nt, kc, tw_log2;
     bool dma;
     int lds_cap = 0;  // 0: LDS_BUDGET (two workgroups per CU); else a smaller cap (52 KiB: three per CU, 38 KiB: four)
+    int ring = 0;     // 4 / 3: ring of that many DMA stage buffers (single-tap layers; staging mode 4 / 5 of the tile table)
 };
+
+// single-tap stride-1 layer without halo: eligible for ring staging
+inline bool ring_ok(const ConvArgs& a)
+{
+    int max_taps = 1;
+    for (int p = 0; p < a.nphase; ++p) max_taps = a.taps.n[p] > max_taps ? a.taps.n[p] : max_taps;
+    return max_taps == 1 && a.nphase == 1 && a.IS == 1 && !a.ckbd && a.span_y == 1 && a.span_x == 1;
+}
+
+inline void set_mode(Choice& c, int kc, int dm)
+{
+    c.kc = kc;
+    c.dma = dm != 0 && kc == 16;
+    c.lds_cap = dm == 2 ? 52 * 1024 : (dm == 3 ? 38 * 1024 : 0);
+    c.ring = (kc == 16 && dm == 4) ? 4 : ((kc == 16 && dm == 5) ? 3 : 0);
+}
 
 Choice choose(const ConvArgs& a)
 {
@@ -917,9 +1012,27 @@ Choice choose(const ConvArgs& a)
         const int need = max_taps < 2 ? max_taps : 2;
         best.dma = best.kc == 16 && 2 * patch + 2 * need * tap <= (long)LDS_BUDGET;
     }
+    // 1x1 layers: a ring of four 16-channel stages (three in flight) whenever the tile has whole waves of patch slots
+    {
+        static const bool ring_off = getenv("RGBD_NO_RING") != nullptr;
+        const int tm = 16 * best.mt * best.wm, tp = 16 * best.nt * (best.wm == 2 ? 2 : 4);
+        if (!ring_off && ring_ok(a) && tp % 64 == 0) {
+            const long stage = (long)(tm + tp) * 64;
+            if (4 * stage + 256 <= (long)LDS_BUDGET + 2048) set_mode(best, 16, 4);
+            else if (tp == 256) set_mode(best, 16, 5);
+        }
+    }
     (void)best_blocks;
     return best;
 }
+
+// ring staging: every tile with whole waves of patch slots (TP % 64 == 0); the 256-pixel tiles also with three buffers
+#define RGBD_RING4(WM_, WN_, MT_, NT_)                                             \
+    if (c.ring == 4 && c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                  \
+        return launch_cfg<WM_, WN_, MT_, NT_, 16, true, 0, false, 4>(a, c.tw_log2, s, 160 * 1024);
+#define RGBD_RING3(WM_, WN_, MT_, NT_)                                             \
+    if (c.ring == 3 && c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                  \
+        return launch_cfg<WM_, WN_, MT_, NT_, 16, true, 0, false, 3>(a, c.tw_log2, s, 160 * 1024);
 
 #define RGBD_CASE(WM_, WN_, MT_, NT_)                                              \
     if (c.wm == WM_ && c.mt == MT_ && c.nt == NT_)                                 \
@@ -1111,9 +1224,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.wm = t->wm;
         c.mt = t->mt;
         c.nt = t->nt;
-        c.kc = t->kc;
-        c.dma = t->dma != 0;
-        c.lds_cap = t->dma == 2 ? 52 * 1024 : (t->dma == 3 ? 38 * 1024 : 0);
+        set_mode(c, t->kc, t->dma);
         c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * t->nt * (t->wm == 2 ? 2 : 4));
     }
     if (g_log_on) {
@@ -1131,9 +1242,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
         c.wm = wm;
         c.mt = mt;
         c.nt = nt;
-        c.kc = kc;
-        c.dma = dm != 0 && kc == 16;
-        c.lds_cap = dm == 2 ? 52 * 1024 : (dm == 3 ? 38 * 1024 : 0);
+        set_mode(c, kc, dm);
         c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * nt * (wm == 2 ? 2 : 4));
     }
     static const bool debug = getenv("RGBD_CONV_DEBUG") != nullptr;
@@ -1142,6 +1251,13 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
                 a.GH, a.GW, a.cin_pad, a.cout_pad, a.taps.n[0], a.IS, a.nphase, c.wm, c.mt, c.nt, c.kc, 1 << c.tw_log2, (int)c.dma);
     // 256-pixel tiles (half the weight staging per MFMA, one round of workgroups on the 128x128 maps): reached through
     // measured table entries only, the cost model does not propose them
+    if (c.ring && !ring_ok(a)) return RGBD_ENOSPC;
+    RGBD_RING4(2, 2, 3, 8) RGBD_RING4(2, 2, 2, 8) RGBD_RING4(2, 2, 1, 8) RGBD_RING4(1, 4, 3, 4) RGBD_RING4(1, 4, 2, 4) RGBD_RING4(1, 4, 1, 4)
+    RGBD_RING3(2, 2, 3, 8) RGBD_RING3(2, 2, 2, 8) RGBD_RING3(2, 2, 1, 8) RGBD_RING3(1, 4, 3, 4) RGBD_RING3(1, 4, 2, 4) RGBD_RING3(1, 4, 1, 4)
+    RGBD_RING4(2, 2, 5, 4) RGBD_RING4(2, 2, 4, 4) RGBD_RING4(2, 2, 3, 4) RGBD_RING4(2, 2, 2, 4) RGBD_RING4(2, 2, 1, 4)
+    RGBD_RING4(2, 2, 5, 2) RGBD_RING4(2, 2, 4, 2) RGBD_RING4(2, 2, 3, 2) RGBD_RING4(2, 2, 2, 2) RGBD_RING4(2, 2, 1, 2)
+    RGBD_RING4(1, 4, 3, 2) RGBD_RING4(1, 4, 2, 2) RGBD_RING4(1, 4, 1, 2) RGBD_RING4(1, 4, 3, 1) RGBD_RING4(1, 4, 2, 1) RGBD_RING4(1, 4, 1, 1)
+    if (c.ring) return RGBD_ENOSPC;
     RGBD_CASE(2, 2, 3, 8) RGBD_CASE(2, 2, 2, 8) RGBD_CASE(2, 2, 1, 8) RGBD_CASE(1, 4, 3, 4) RGBD_CASE(1, 4, 2, 4) RGBD_CASE(1, 4, 1, 4)
     RGBD_CASE(2, 2, 5, 4) RGBD_CASE(2, 2, 4, 4) RGBD_CASE(2, 2, 3, 4) RGBD_CASE(2, 2, 2, 4) RGBD_CASE(2, 2, 1, 4)
     RGBD_CASE(2, 2, 5, 2) RGBD_CASE(2, 2, 4, 2) RGBD_CASE(2, 2, 3, 2) RGBD_CASE(2, 2, 2, 2) RGBD_CASE(2, 2, 1, 2)

@@ -557,26 +557,12 @@ struct rgbd_elic {
     hipEvent_t done_ev = nullptr;  // blocking-sync event: the host thread sleeps instead of spinning on the stream
     // The legacy NULL stream cannot be captured: a caller that passes it runs the eager launch path (same results, no
     // graph).  Substituting an engine-owned stream for it was built in round 2 and taken out: with it, host waits inside
-    // the runtime stopped returning once a pool had switched the device to blocking sync (DESIGN.md 3.5 has the analysis:
-    // hipFree -> Device::SyncAllStreams -> HostQueue::finish -> "No HW event ... await command completion" ->
-    // Event::awaitCompletion sleeping on a condition variable nobody signals, GPU idle).  RGBD_NULL_OWN_STREAM=1 brings
-    // the old behaviour back to reproduce that report under RGBD_DEBUG_DESTROY=1; nothing else uses it.  Throughput users
-    // drive their own streams (CodecPool), which do capture.
-    hipStream_t own_s = nullptr;   // RGBD_NULL_OWN_STREAM=1 only (the configuration of the round-2 hang report)
-    hipEvent_t null_ev = nullptr;
+    // the runtime stopped returning once a pool had switched the device to blocking sync (DESIGN.md 3.5 and
+    // profiles/r03_hang_diagnosis.txt have the analysis).  The switch that re-created that configuration is gone from the
+    // product (round 4); throughput users drive their own streams (CodecPool), which do capture.
     int use_stream(void* stream)
     {
-        static const bool own = getenv("RGBD_NULL_OWN_STREAM") != nullptr;
         s = (hipStream_t)stream;
-        if (own && !stream) {
-            if (!own_s) {
-                HIP_TRY(hipStreamCreateWithFlags(&own_s, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&null_ev, hipEventDisableTiming));
-            }
-            HIP_TRY(hipEventRecord(null_ev, nullptr));
-            HIP_TRY(hipStreamWaitEvent(own_s, null_ev, 0));
-            s = own_s;
-        }
         if (g_dbg_destroy) {
             std::lock_guard<std::mutex> g(g_live_mu);
             g_live_streams[this] = s;
@@ -603,15 +589,19 @@ struct rgbd_elic {
         // (the stream is part of the key: a graph is replayed on the stream it was captured on)
         char sk[32];
         snprintf(sk, sizeof(sk), "|%p", (void*)s);
-        const std::string suffix = "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch) + sk;
-        const std::string full = key + suffix;
+        const std::string cfg = "|" + std::to_string(tile_mode) + "|" + std::to_string(g_cfg_epoch) + "|";
+        const std::string full = key + cfg + (sk + 1);
         auto it = graphs.find(full);
         if (it == graphs.end()) {
             // A dataset with many image sizes must not grow this cache without bound: entries of other tile modes / debug
             // epochs can never be replayed again and go first, then the least recently used ones.
             for (auto e = graphs.begin(); e != graphs.end();) {
+                // (an entry captured on ANOTHER stream is not stale: an engine used on two streams keeps both sets, the LRU
+                //  limit below bounds them)
                 const std::string& k = e->first;
-                const bool stale = k.size() < suffix.size() || k.compare(k.size() - suffix.size(), suffix.size(), suffix) != 0;
+                const size_t bar = k.rfind('|');
+                const bool stale = bar == std::string::npos || bar + 1 < cfg.size() ||
+                                   k.compare(bar + 1 - cfg.size(), cfg.size(), cfg) != 0;
                 if (stale) {
                     drop_entry(e->second);
                     e = graphs.erase(e);
@@ -943,13 +933,19 @@ struct rgbd_elic {
                                                      "rgb_channel_context", "depth_channel_context", "rgb_local_context",
                                                      "depth_local_context", "h_s."};
         a.splitk = 1;
-        for (const char* pre : kSplitPrefixes)
-            if (name.rfind(pre, 0) == 0) {
-                int mt = 1;
-                for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
-                a.splitk = g_force_splitk > 0 ? g_force_splitk : conv_splitk_for(a.cin_pad, mt, (long)OH * OW, a.nphase);
-                break;
-            }
+        {
+            int mt = 1;
+            for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
+            bool listed = false;
+            for (const char* pre : kSplitPrefixes) listed = listed || name.rfind(pre, 0) == 0;
+            // a measured entry (csrc/splitk_table.h) applies to any layer of that shape; the rule only to the listed families.
+            // Fused tails, the packed image-facing layers and checkerboard-less sub-pixel forms run unsplit.
+            const bool splittable = !pc2 && !sp;
+            if (g_force_splitk > 0 && listed) a.splitk = g_force_splitk;
+            else if (listed) a.splitk = conv_splitk_for(a.cin_pad, a.cout_pad, mt, (long)OH * OW, a.nphase);
+            else if (splittable && g_force_splitk >= 0)
+                if (const int t = conv_splitk_table(a.cin_pad, a.cout_pad, mt, (long)OH * OW, a.nphase)) a.splitk = t;
+        }
         // split-K partial planes; a GELU layer (STF_united's MLP) also goes through the reducer, with a single plane
         cp.partial_bytes = (a.splitk > 1 || a.act == ACT_GELU) ? (size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float) : 0;
         cp.flops = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
@@ -1282,7 +1278,9 @@ struct rgbd_elic {
             last_name[m] = p[m] + ".branch.4";
             mid[m] = p[m] + ".branch.2";
             lead0[m] = p[m] + ".branch.0";
-            fuse = fuse && fusable(mid[m], last_name[m], x[m], G);
+            // the pair is planned at 2N; should the two plans not share a launch after all (conv2 falls back to two launches
+            // when pairable() fails), each of them is re-planned at N -- so fusing has to be possible at both sizes
+            fuse = fuse && fusable(mid[m], last_name[m], x[m], G) && fusable(mid[m], last_name[m], x[m], 1);
         }
         for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m]);
         Act lead_out[2];
@@ -1334,7 +1332,7 @@ struct rgbd_elic {
             last_name[m] = p[m] + ".conv.4";
             mid[m] = p[m] + ".conv.2";
             lead0[m] = p[m] + ".conv.0";
-            fuse = fuse && fusable(mid[m], last_name[m], x[m], G);
+            fuse = fuse && fusable(mid[m], last_name[m], x[m], G) && fusable(mid[m], last_name[m], x[m], 1);  // (see bottleneck2)
         }
         for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m]);
         Act lead_out[2];
@@ -2332,6 +2330,8 @@ int rgbd_elic::ensure_arena(size_t bytes)
 {
     if (bytes <= arena.cap) return RGBD_OK;
     graphs_invalidate();  // cached graphs have the old workspace addresses baked in
+    dbg_sym = dbg_idx = nullptr;  // (they point into the workspace that is about to go)
+    dbg_x = dbg_s = nullptr;
     std::unique_lock<std::shared_mutex> lk(g_capture_mu);  // hipFree synchronises the device: not while anyone captures
     if (arena.base) {
         HangWatch w("hipStreamSynchronize / hipFree in ensure_arena", 30);
@@ -2553,6 +2553,8 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     pre_leads.clear();
     arena.top = 0;
     rc = 0;
+    dbg_sym = dbg_idx = nullptr;  // forward() keeps no symbols: the last compress()'s are gone with its workspace layout
+    dbg_x = dbg_s = nullptr;
     Act rgb = alloc(B, H, W, 3), depth = alloc(B, H, W, 1);
     if (!dry()) {
         int r = launch_nchw_to_nhwc16(rgb_dev, B, 3, H, W, rgb.p, rgb.cs, s);
@@ -2848,6 +2850,8 @@ int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat
     pre_leads.clear();
     arena.top = 0;
     rc = 0;
+    dbg_sym = dbg_idx = nullptr;  // forward() keeps no symbols: the last compress()'s are gone with its workspace layout
+    dbg_x = dbg_s = nullptr;
     Act x = alloc(B, H, W, in_ch);
     if (!dry()) {
         const int r = launch_nchw_to_nhwc16(x_dev, B, in_ch, H, W, x.p, x.cs, s);
@@ -3198,6 +3202,13 @@ int rgbd_set_blocking_sync(int32_t on)
     return RGBD_OK;
 }
 
+int rgbd_get_blocking_sync(void)
+{
+    unsigned flags = 0;
+    HIP_TRY(hipGetDeviceFlags(&flags));
+    return (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync ? 1 : 0;
+}
+
 // ops.cpp:24-81 restated (host, one-off table construction)
 int rgbd_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, uint32_t* cdf_out)
 {
@@ -3498,7 +3509,19 @@ int rgbd_pointwise_nchw(int32_t op, const float* x_dev, int32_t n, int32_t c, in
     } else if (oh <= 0 || ow <= 0) {
         return RGBD_EINVAL;
     }
-    float *xin = nullptr, *yout = nullptr, *aux = nullptr, *dw0 = nullptr, *dw1 = nullptr;
+    // (test / tool entry point, not the codec path.)  Every buffer is released on every way out.
+    struct Bufs {
+        float *xin = nullptr, *yout = nullptr, *aux = nullptr, *dw0 = nullptr, *dw1 = nullptr;
+        ~Bufs()
+        {
+            (void)hipFree(xin);
+            (void)hipFree(yout);
+            (void)hipFree(aux);
+            (void)hipFree(dw0);
+            (void)hipFree(dw1);
+        }
+    } b;
+    float *&xin = b.xin, *&yout = b.yout, *&aux = b.aux, *&dw0 = b.dw0, *&dw1 = b.dw1;
     HIP_TRY(hipMalloc((void**)&xin, (size_t)n * h * w * cs * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&yout, (size_t)n * oh * ow * cs * sizeof(float)));
     int rc = launch_nchw_to_nhwc16(x_dev, n, c, h, w, xin, cs, s);
@@ -3522,11 +3545,6 @@ int rgbd_pointwise_nchw(int32_t op, const float* x_dev, int32_t n, int32_t c, in
     if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, c, oh, ow, cs, y_dev, 0, s);
     const hipError_t e = hipStreamSynchronize(s);
     if (!rc && e != hipSuccess) rc = RGBD_EHIP;
-    (void)hipFree(xin);
-    (void)hipFree(yout);
-    (void)hipFree(aux);
-    (void)hipFree(dw0);
-    (void)hipFree(dw1);
     return rc;
 }
 
@@ -3664,7 +3682,7 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
         int mt = 1;
         for (int ph = 0; ph < a.nphase; ++ph) mt = std::max(mt, (int)a.taps.n[ph]);
         a.splitk = g_force_splitk > 0 ? std::min(g_force_splitk, pc.cin_pad / 16)
-                                      : (g_force_splitk < 0 ? conv_splitk_for(pc.cin_pad, mt, (long)OH * OW, a.nphase) : 1);
+                                      : (g_force_splitk < 0 ? conv_splitk_for(pc.cin_pad, pc.cout_pad, mt, (long)OH * OW, a.nphase) : 1);
         if (a.splitk > 1) {
             HIP_TRY(hipMalloc((void**)&part, (size_t)a.splitk * yb));
             a.partial = part;
@@ -3859,8 +3877,6 @@ void rgbd_elic_destroy(rgbd_elic* m)
     if (m->res_pin) (void)hipHostFree(m->res_pin);
     if (m->pin_ev) (void)hipEventDestroy(m->pin_ev);
     if (m->done_ev) (void)hipEventDestroy(m->done_ev);
-    if (m->null_ev) (void)hipEventDestroy(m->null_ev);
-    if (m->own_s) (void)hipStreamDestroy(m->own_s);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (dbg) fprintf(stderr, "[destroy %p] events/streams gone\n", (void*)m);
     delete m;
@@ -4242,6 +4258,7 @@ int rgbd_elic_debug_floats(rgbd_elic* m, int32_t modality, float* x, float* scal
 {
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!m || !n || modality < 0 || modality > 1 || !m->dbg_x || !m->dbg_s) return RGBD_EINVAL;
+    if (m->variant == 1 && modality != 0) return RGBD_EINVAL;  // the single-modal model keeps one modality's floats
     *n = m->dbg_per_mod;
     if (!x || !scale) return RGBD_OK;
     if (cap < m->dbg_per_mod) return RGBD_ENOSPC;

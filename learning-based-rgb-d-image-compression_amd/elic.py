@@ -111,6 +111,8 @@ class ELIC(ELIC_united):
         self._ready()
         if self.training:
             raise RuntimeError("forward() is built for eval mode (inference path); call .eval() first")
+        if self.quant != "ste":  # models/elic.py:84-99: any other setting rounds without the mean (and adds noise in training)
+            raise NotImplementedError(f"forward() implements config quant = 'ste' (the reference's model_config); got {self.quant!r}")
         if x.dim() != 4 or x.size(1) != self.channel:
             raise ValueError(f"expected x [B,{self.channel},H,W]")
         B, _, H, W = x.shape
@@ -131,6 +133,3 @@ class ELIC(ELIC_united):
         raise NotImplementedError("ELIC is single-modal")
 
     decompress_united = compress_united
-
-    def clone_shared(self):
-        raise NotImplementedError("CodecPool drives ELIC_united")

@@ -17,8 +17,15 @@ from .sched import balanced_workers  # noqa: F401  (re-exported: rgbd_amd.pool.b
 
 
 class CodecPool:
+    """W engine instances of one model on one GPU.  `model_cls`: ELIC_united (default), STF_united, ELIC_united_R2D -- or the
+    single-modal ELIC (models/elic.py), whose calls take one tensor: roundtrip(x) -> (outs, x_hat), batches = [(x,), ...].
+    Use as a context manager, or call close(): the pool switches the DEVICE to blocking waits and close() switches it back."""
+
     def __init__(self, state_dict, config=None, workers: int = 2, device="cuda", per_image_streams: bool = True,
-                 model_cls=ELIC_united):
+                 model_cls=ELIC_united, channel=None):
+        self.single = getattr(model_cls, "_MODEL", "") == "ELIC"
+        if channel is None:
+            channel = 3 if self.single else 4
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -45,7 +52,7 @@ class CodecPool:
             self._blocking_sync = True
         for i in range(workers):
             if i == 0:
-                net = model_cls(config=config, channel=4).eval()  # ELIC_united or its Swin variant STF_united
+                net = model_cls(config=config, channel=channel).eval()  # ELIC_united, a variant of it, or the single-modal ELIC
                 net.load_state_dict(state_dict)
                 net.update(force=True)
                 net = net.to(self.device)
@@ -60,6 +67,22 @@ class CodecPool:
     @property
     def workers(self):
         return len(self.nets)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def _code(self, net, tensors):
+        """compress() + decompress() of one group on one instance -> (compress output, tuple of reconstructions)."""
+        out = net.compress(*tensors)
+        if self.single:
+            rec = net.decompress(out["strings"], out["shape"])
+            return out, (rec["x_hat"],)
+        rec = net.decompress(out["r_strings"], out["d_strings"], out["shape"])
+        return out, (rec["x_hat"]["r"], rec["x_hat"]["d"])
 
     def close(self):
         """Drop the engine instances and give the device back its default (spinning) wait policy."""
@@ -103,26 +126,23 @@ class CodecPool:
                 raise e
         return res
 
-    def roundtrip(self, rgb: torch.Tensor, depth: torch.Tensor):
-        """compress() + decompress() of every group; returns (list of compress outputs, x_hat_r, x_hat_d)."""
-        parts = self._split(rgb.shape[0])
+    def roundtrip(self, *tensors: torch.Tensor):
+        """compress() + decompress() of every group; returns (list of compress outputs, x_hat_r, x_hat_d) -- for the
+        single-modal model: roundtrip(x) -> (list of compress outputs, x_hat)."""
+        parts = self._split(tensors[0].shape[0])
         torch.cuda.current_stream().synchronize()
 
         def fn(i):
             a, b = parts[i]
-            out = self.nets[i].compress(rgb[a:b], depth[a:b])
-            rec = self.nets[i].decompress(out["r_strings"], out["d_strings"], out["shape"])
-            return out, rec
+            return self._code(self.nets[i], [t[a:b] for t in tensors])
 
         res = self._run(fn, len(parts))
-        xr = torch.cat([r[1]["x_hat"]["r"] for r in res])
-        xd = torch.cat([r[1]["x_hat"]["d"] for r in res])
-        return [r[0] for r in res], xr, xd
+        return ([r[0] for r in res],) + tuple(torch.cat([r[1][j] for r in res]) for j in range(len(res[0][1])))
 
-    def roundtrip_many(self, batches):
+    def roundtrip_many(self, batches, on_done=None):
         """Software pipeline over whole batches: the workers pull batches off a shared counter, so one batch's serial
-        coder phases overlap the other workers' convolutions.  batches: list of (rgb, depth).  Returns
-        [(compress_out, x_hat_r, x_hat_d)] in batch order.
+        coder phases overlap the other workers' convolutions.  batches: list of (rgb, depth) -- (x,) for the single-modal
+        model.  Returns [(compress_out, x_hat_r, x_hat_d)] ([(compress_out, x_hat)]) in batch order.
 
         Workers that start together stay in lock-step (same work, symmetric contention), so a job of K batches takes
         ceil(K / W) rounds and a last round with few workers leaves the chip idle: pick W so that the rounds are full
@@ -133,6 +153,8 @@ class CodecPool:
         other's transforms while each cohort keeps its lock-step): 19.8 / 20.0 / 18.5 / 17.6 Mpx/s against 20.4 without; and
         giving the first half (or quarter) of the instances high-priority streams, so that they run ahead without anybody
         starting late: 20.3-20.4 (20.9) Mpx/s against 21.2-21.4 on the same box."""
+        # on_done(k, compress_out): called from the worker thread as soon as batch k is finished (bench.py hands the
+        # finished streams to its gather thread there, so that the RCCL gather overlaps the other instances' work)
         n = len(batches)
         torch.cuda.current_stream().synchronize()
         W = min(self.workers, n)
@@ -144,18 +166,18 @@ class CodecPool:
             while True:
                 if k >= n:
                     return outs
-                rgb, depth = batches[k]
-                out = self.nets[i].compress(rgb, depth)
-                rec = self.nets[i].decompress(out["r_strings"], out["d_strings"], out["shape"])
-                outs.append((k, out, rec["x_hat"]["r"], rec["x_hat"]["d"]))
+                out, recs = self._code(self.nets[i], batches[k])
+                outs.append((k, out) + recs)
+                if on_done is not None:
+                    on_done(k, out)
                 with lock:
                     k = nxt[0]
                     nxt[0] += 1
 
         res = [None] * n
         for lst in self._run(fn, W):
-            for k, out, xr, xd in lst:
-                res[k] = (out, xr, xd)
+            for item in lst:
+                res[item[0]] = tuple(item[1:])
         return res
 
     def set_profile(self, on: bool):

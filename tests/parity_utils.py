@@ -15,6 +15,7 @@ import numpy as np
 from oracle import coder
 
 FLOORS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_floors.json")
+CONTRACT_DPSNR = 1e-4  # dB; BASELINE.json north_star: "within 1e-4 PSNR for the float reconstruction"
 
 
 def floors():

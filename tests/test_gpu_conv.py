@@ -161,16 +161,20 @@ def test_conv_checkerboard_output(k, cin, cout, h, w, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", ["2,3,8,16,1", "2,2,8,16,0", "1,3,4,16,1", "2,5,4,16,0", "1,1,1,16,1", "2,3,4,64,0"])
+@pytest.mark.parametrize("tile", ["2,3,8,16,1", "2,2,8,16,0", "1,3,4,16,1", "2,5,4,16,0", "1,1,1,16,1", "2,3,4,64,0",
+                                  "2,2,4,16,4", "2,3,4,16,4", "2,5,2,16,4", "1,3,2,16,4", "1,1,1,16,4", "2,2,8,16,5", "1,3,4,16,5"])
 def test_tile_choice_never_changes_a_bit(tile):
     """The determinism contract behind the tile table / cost model: every tile shape, stage depth and
-    staging mode produces the same fp32 bits, so tile selection is a pure speed matter (256-pixel tiles included)."""
+    staging mode produces the same fp32 bits, so tile selection is a pure speed matter (256-pixel tiles included).
+    Staging modes 4 / 5 are the ring of four / three DMA stage buffers of the single-tap layers (round 4); the baseline is
+    a register-staged tile, whatever the cost model would pick."""
     dev = require_gpu()
     from rgbd_amd._lib import check, lib
 
     f32p = ctypes.POINTER(ctypes.c_float)
     shapes = [(2, 96, 32, 48, 96, 3, 1, 1, 0), (1, 192, 40, 24, 96, 1, 1, 0, 0), (1, 64, 16, 24, 96, 5, 2, 2, 1),
-              (1, 64, 33, 47, 80, 3, 1, 1, 0)]
+              (1, 64, 33, 47, 80, 3, 1, 1, 0), (2, 1344, 9, 13, 213, 1, 1, 0, 0), (3, 32, 21, 17, 469, 1, 1, 0, 0),
+              (1, 16, 8, 8, 16, 1, 1, 0, 0)]
     launched = 0
     for n, cin, h, w, cout, k, s, p, tr in shapes:
         g = torch.Generator().manual_seed(n + cin + h + w + cout)
@@ -187,7 +191,11 @@ def test_tile_choice_never_changes_a_bit(tile):
                                         ctypes.c_void_p(y.data_ptr()), None)
             return rc, y.cpu()
 
-        rc0, y0 = run()
+        lib().rgbd_debug_force_tile(b"2,2,2,16,0")
+        try:
+            rc0, y0 = run()
+        finally:
+            lib().rgbd_debug_force_tile(b"")
         check(rc0, "conv2d")
         lib().rgbd_debug_force_tile(tile.encode())
         try:

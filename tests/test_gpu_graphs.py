@@ -225,13 +225,69 @@ def test_null_stream_caller_next_to_replaying_side_streams_then_destroy(synth_sd
         assert got == want == list(one["r_strings"][0]) and torch.equal(xr, rec["x_hat"]["r"])
     assert all(n.graph_count() >= 2 for n in pool.nets) and lone.graph_count() == 0
     nets = list(pool.nets)
-    del pool
+    pool.nets = []
     while nets:                          # destroy a clone, use the survivors, destroy the next ...
         n = nets.pop()
         del n
         gc.collect()
         one = lone.compress(r, d)
         assert list(one["r_strings"][0]) == want
+    pool.close()                         # (the device-wide wait policy goes back to its default)
+    del lone
+    gc.collect()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_caller_side_stream_next_to_pool_then_destroy_and_close(synth_sd):
+    """VERDICT r3 (weak 5b): the located trigger of the round-2 hang was "a stream the caller's thread drives next to the pool's
+    threads under blocking sync".  The NULL-stream case is the test above; this is the other one -- the caller's OWN
+    torch.cuda.Stream() on the main thread, capturing and replaying graphs like the pool's instances do, then the same
+    destroy-one-use-the-rest sequence, then CodecPool.close(), which must hand the device its default wait policy back.
+    Run once under the per-test timeout; a wait inside the runtime fails it (profiles/r03_hang_diagnosis.txt tells where to
+    look -- do not loop it)."""
+    import gc
+
+    import rgbd_amd
+    from rgbd_amd._lib import lib
+
+    require_gpu()
+    assert lib().rgbd_get_blocking_sync() == 0, "an earlier test left the device in blocking-sync mode (a pool without close())"
+    pool = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=3, device="cuda", per_image_streams=True)
+    assert lib().rgbd_get_blocking_sync() == 1
+    lone = pool.nets[0].clone_shared()
+    lone.per_image_streams = True
+    side = torch.cuda.Stream()
+    r, d = _pair(3, 128, 192, 83)
+    torch.cuda.synchronize()
+    want = None
+    for rnd in range(4):                 # eager, capture, replay, replay -- on the pool's streams AND on the caller's
+        outs, xr, xd = pool.roundtrip(r, d)
+        with torch.cuda.stream(side):
+            one = lone.compress(r, d)
+            rec = lone.decompress(one["r_strings"], one["d_strings"], one["shape"])
+        side.synchronize()
+        got = [s for o in outs for s in o["r_strings"][0]]
+        want = want or got
+        assert got == want == list(one["r_strings"][0]) and torch.equal(xr, rec["x_hat"]["r"])
+    assert all(n.graph_count() >= 2 for n in pool.nets) and lone.graph_count() >= 2
+    nets = list(pool.nets)
+    while nets:                          # destroy a clone, use the survivor on the caller's stream, destroy the next ...
+        n = nets.pop()
+        pool.nets.remove(n)
+        del n
+        gc.collect()
+        with torch.cuda.stream(side):
+            one = lone.compress(r, d)
+        side.synchronize()
+        assert list(one["r_strings"][0]) == want
+    pool.close()
+    pool.close()                         # idempotent
+    assert lib().rgbd_get_blocking_sync() == 0 and pool.nets == []
+    with torch.cuda.stream(side):        # and the survivor works under the default policy
+        one = lone.compress(r, d)
+    side.synchronize()
+    assert list(one["r_strings"][0]) == want
     del lone
     gc.collect()
     torch.cuda.synchronize()

@@ -191,6 +191,7 @@ def test_pool_matches_single_instance(net, synth_sd):
         assert out["r_strings"] == want["r_strings"] and out["d_strings"] == want["d_strings"], k
         assert torch.equal(mxr, want_rec["x_hat"]["r"]) and torch.equal(mxd, want_rec["x_hat"]["d"]), k
     assert all(n.graph_count() >= 2 for n in pool.nets)
+    pool.close()
 
 
 def test_tester_single_on_files(tmp_path, monkeypatch):

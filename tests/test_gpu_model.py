@@ -221,11 +221,18 @@ def test_roundtrip_256_and_container(net, orc):
     assert abs(eo.psnr(xr, r) - eo.psnr(oxr, r)) < 1e-4
     bpp = [len(eo.container_bytes(256, 256, out["shape"], out[k])) * 8.0 / (256 * 256) for k in ("r_strings", "d_strings")]
     print("bpp gpu", bpp, "golden", g["bpp"].tolist(), "psnr gpu", eo.psnr(xr, r), "golden", g["psnr"][0])
-    # against the reference's golden run: one depth z symbol sits on a rounding boundary here, which changes the depth
-    # hyper parameters and with them later contexts -- the rates stay within 5e-3 bpp (of 11), the PSNR within 5e-4 dB
-    # (tests/test_gpu_parity_pinned.py pins the cases that are bit-identical to the reference)
-    assert abs(bpp[0] - g["bpp"][0]) <= 5e-3 and abs(bpp[1] - g["bpp"][1]) <= 5e-3
-    assert abs(eo.psnr(xr, r) - g["psnr"][0]) < 5e-4 and abs(eo.psnr(xd, d) - g["psnr"][1]) < 5e-4
+    # against the reference's golden run: d_256x256 is a KNOWN exceedance of the contract (tests/golden/parity_floors.json
+    # lists the clauses and their ceilings: one depth z symbol sits on a rounding boundary, every later context differs).
+    # What is enforced here is that entry -- not a tolerance of this test's own: a clause the entry does not list must
+    # meet the contract (bpp identical, |dPSNR| <= 1e-4 dB), a listed one its recorded ceiling.
+    from parity_utils import CONTRACT_DPSNR, floors
+
+    fl = floors()["d_256x256"]
+    ex = set(fl.get("exceeds", []))
+    for k, v in (("dbpp_r", abs(bpp[0] - g["bpp"][0])), ("dbpp_d", abs(bpp[1] - g["bpp"][1]))):
+        assert v <= (fl[k] if "dbpp" in ex else 0.0), (k, v)
+    for k, v in (("dpsnr_r", abs(eo.psnr(xr, r) - g["psnr"][0])), ("dpsnr_d", abs(eo.psnr(xd, d) - g["psnr"][1]))):
+        assert v <= (fl[k] if k in ex else CONTRACT_DPSNR), (k, v)
 
 
 def test_errors(net):
@@ -233,6 +240,56 @@ def test_errors(net):
         net.compress(torch.zeros(1, 3, 100, 128).cuda(), torch.zeros(1, 1, 100, 128).cuda())
     with pytest.raises(ValueError):
         net.compress(torch.zeros(1, 3, 128, 128).cuda(), torch.zeros(2, 1, 128, 128).cuda())
+
+
+def test_malformed_streams_are_an_error_or_garbage_never_a_fault(net):
+    """The reference's decoder is undefined behaviour on a damaged stream (rans_interface.cpp:278-351 reads past the end
+    of its vector).  Here it is defined: a stream that cannot be a rANS stream (empty, shorter than the 8-byte final
+    state, not a multiple of 4 bytes, longer than the encoder can produce for the shape) is refused with an error; any
+    other damage -- truncation, flipped bits, another image's stream -- decodes to SOME pixels: reads past the end of a
+    stream return zero words (entropy.hip: every stream read is bounded by the stream's length), decoded symbols are
+    never used as addresses, and a NaN scale selects table row 0.  Afterwards the engine still codes correctly."""
+    from rgbd_amd import RgbdError
+
+    r, d, rp, dp = _inputs(1, 128, 192, 7)
+    good = net.compress(rp.cuda(), dp.cuda())
+    ref = net.decompress(good["r_strings"], good["d_strings"], good["shape"])
+    ry, rz = good["r_strings"][0][0], good["r_strings"][1][0]
+    dy, dz = good["d_strings"][0][0], good["d_strings"][1][0]
+
+    def dec(ry_=ry, rz_=rz, dy_=dy, dz_=dz):
+        out = net.decompress([[ry_], [rz_]], [[dy_], [dz_]], good["shape"])
+        torch.cuda.synchronize()
+        x = out["x_hat"]["r"]
+        assert x.shape == ref["x_hat"]["r"].shape
+        return out
+
+    def flip(b, positions):
+        a = bytearray(b)
+        for p in positions:
+            a[p % len(a)] ^= 0x5A
+        return bytes(a)
+
+    for bad in (b"", ry[:4], ry[:6], ry + b"\x00"):  # not a stream at all
+        with pytest.raises((ValueError, RgbdError)):
+            dec(ry_=bad)
+        with pytest.raises((ValueError, RgbdError)):
+            dec(dz_=bad)
+    with pytest.raises((ValueError, RgbdError)):
+        dec(ry_=ry + bytes(8 * len(ry)))  # longer than any stream of this shape
+    # damaged but well-formed: garbage pixels, no fault
+    dec(ry_=ry[:8])                                  # only the final state: every later read is past the end
+    dec(ry_=ry[:len(ry) // 2 & ~3])                  # truncated
+    dec(dy_=dy[:8], ry_=ry[:12])
+    dec(rz_=rz[:8])                                  # truncated z: garbage hyper parameters (NaN / inf scales included)
+    dec(dz_=flip(dz, range(0, len(dz), 7)))
+    dec(ry_=flip(ry, range(3, len(ry), 11)), dy_=flip(dy, (0, 1, 2, 3, 4, 5, 6, 7)))  # flipped payload / flipped final state
+    dec(ry_=dy, dy_=ry)                              # the other modality's stream
+    dec(ry_=bytes(len(ry)), rz_=bytes(len(rz)))      # all zero words
+    dec(ry_=b"\xff" * len(ry), dz_=b"\xff" * len(dz))
+    # and the engine is unharmed
+    again = dec()
+    assert torch.equal(again["x_hat"]["r"], ref["x_hat"]["r"]) and torch.equal(again["x_hat"]["d"], ref["x_hat"]["d"])
 
 
 def test_eval_forward(net, orc):

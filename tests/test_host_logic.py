@@ -173,7 +173,11 @@ def test_tile_table_is_well_formed(table):
         key, (wm, mt, nt, kc, dma) = tuple(v[:9]), v[9:]
         assert key not in keys, ln
         keys.add(key)
-        assert (wm, mt, nt) in tiles and kc in (16, 64) and dma in (0, 1, 2, 3) and not (dma and kc == 64), ln
+        # staging modes: 0 registers, 1 / 2 / 3 direct-to-LDS double buffer (78 / 52 / 38 KiB cap), 4 / 5 ring of four / three
+        # direct-to-LDS stages (single-tap layers; needs whole waves of patch slots: 64 | pixels per tile)
+        assert (wm, mt, nt) in tiles and kc in (16, 64) and dma in (0, 1, 2, 3, 4, 5) and not (dma and kc == 64), ln
+        if dma >= 4:
+            assert key[5] == 1 and key[6] == 1 and key[7] == 1 and (16 * nt * (2 if wm == 2 else 4)) % 64 == 0, ln
         assert all(x > 0 for x in key) and key[3] % 16 == 0 and key[4] % 16 == 0 and key[7] in (1, 4, 11, 21), ln  # 11 / 21: checkerboard-output launches (nphase + 10 * ckbd)
     assert keys
 

@@ -46,7 +46,7 @@ net.per_image_streams = True
 
 TILES = ([(2, m, 8) for m in (3, 2, 1)] + [(2, m, n) for n in (4, 2, 1) for m in (5, 4, 3, 2, 1)] +
          [(1, m, n) for n in (4, 2, 1) for m in (3, 2, 1)])
-MODES = ((16, 1), (16, 2), (16, 3), (16, 0), (64, 0))  # dma 2 / 3 = direct-to-LDS inside a 52 / 38 KiB cap (3 / 4 workgroups per CU)
+MODES = ((16, 1), (16, 2), (16, 3), (16, 0), (64, 0), (16, 4), (16, 5))  # 4 / 5: ring of 4 / 3 DMA stages (single-tap layers)  # dma 2 / 3 = direct-to-LDS inside a 52 / 38 KiB cap (3 / 4 workgroups per CU)
 
 
 def shapes(B, H, W):
