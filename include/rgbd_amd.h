@@ -232,6 +232,10 @@ int rgbd_elic_profile_dump(rgbd_elic* m, const char* path);
 /* Measurement hook (bench.py): when on, every convolution launch is bracketed by HIP events on the launch stream.
  * profile_read returns the summed kernel time (ms), the launch count and the algorithmic FLOPs (2*MACs, unpadded)
  * accumulated since set_profile(). */
+/* Bytes of HBM workspace this engine instance holds (grows with the largest call shape seen, never shrinks); the packed
+ * weights, shared by all instances of a pool, are not included.  bench.py reports it as config.hbm_workspace_gib. */
+int64_t rgbd_elic_workspace_bytes(const rgbd_elic* m);
+
 /* Number of call shapes whose kernel sequence is currently cached as a HIP graph (tests / diagnostics). */
 int rgbd_elic_graph_count(const rgbd_elic* m);
 /* Test hook: the next n graph captures are treated as lost (as if another library's device-wide call had invalidated

@@ -451,17 +451,38 @@ const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerbo
 // ------------------------------------------------------------------------------------------------
 // the model
 // ------------------------------------------------------------------------------------------------
+// Workspace of one engine instance: a two-ended stack.  `top` is the fill of the ACTIVE end (the low end grows up from the
+// base, the high end down from base + cap), `other` the fill of the other one.  Blocks allocate and release stack-style on
+// the active end (`mark = top ... top = mark`); the stage loops of the big transforms alternate the ends (flip), so that a
+// stage's output and temporaries go to the end that holds nothing live any more -- the input of the previous stage -- and
+// the workspace holds two consecutive stages instead of the whole transform (round 4: 6.0 -> 2.9 GiB per c3 instance).
+// Addresses are a function of the call shape and of cap; a re-allocation (new cap) drops the cached graphs.
 struct Arena {
     unsigned char* base = nullptr;
-    size_t cap = 0, top = 0, peak = 0;
+    size_t cap = 0, top = 0, other = 0, peak = 0;
+    bool hi = false;
     bool dry = false;
     void* take(size_t bytes)
     {
         bytes = (bytes + 255) & ~(size_t)255;
-        void* p = dry ? (void*)(uintptr_t)(0x1000 + top) : (void*)(base + top);
+        void* p;
+        if (dry) p = (void*)(uintptr_t)(0x1000 + top);
+        else p = hi ? (void*)(base + cap - top - bytes) : (void*)(base + top);
         top += bytes;
-        peak = std::max(peak, top);
+        peak = std::max(peak, top + other);
         return p;
+    }
+    void reset()
+    {
+        top = other = 0;
+        hi = false;
+    }
+    // make the other end the active one, emptied down to `floor` (what is below belongs to somebody who is still alive)
+    void flip(size_t floor)
+    {
+        std::swap(top, other);
+        hi = !hi;
+        top = floor;
     }
 };
 
@@ -772,6 +793,37 @@ struct rgbd_elic {
         a.p = (float*)arena.take(a.elems() * sizeof(float));
         return a;
     }
+    // ---- two-ended workspace (Arena): the stage loops of g_a / g_s -------------------------------------------------
+    // A stage reads tensors on one end and puts its output and temporaries on the other, which is emptied first: what it
+    // held -- the previous stage's input -- is dead by then.  `cur_hi`: the end the stage's input lives on.  A fusion stage
+    // (its inputs ARE its outputs: the concat buffers) only puts its temporaries there.
+    struct Ends {
+        size_t lo_floor = 0;  // low-end fill at the transform's entry: everything below belongs to the caller
+        bool cur_hi = false;
+    };
+    Ends ends_begin()
+    {
+        Ends e;
+        if (arena.hi) arena.flip(arena.other);  // (never: transforms are entered on the low end)
+        e.lo_floor = arena.top;
+        return e;
+    }
+    void ends_stage(Ends& e, bool output_moves)
+    {
+        static const bool off = getenv("RGBD_NO_WS_REUSE") != nullptr;  // A/B switch: one-ended workspace as in rounds 1-3
+        if (off) return;
+        const bool want_hi = !e.cur_hi;
+        if (arena.hi != want_hi) arena.flip(want_hi ? 0 : e.lo_floor);
+        else arena.top = want_hi ? 0 : e.lo_floor;
+        if (output_moves) e.cur_hi = want_hi;
+    }
+    // back on the low end; the transform's results stay protected on whichever end they are until ends_release()
+    void ends_finish(Ends& e)
+    {
+        if (arena.hi) arena.flip(e.cur_hi ? e.lo_floor : arena.other);
+    }
+    void ends_release() { arena.other = 0; }
+
     static Act view(const Act& a, int c0, int c)
     {
         Act v = a;
@@ -855,9 +907,9 @@ struct rgbd_elic {
             fail(RGBD_EINVAL);
             return cp;
         }
-        // split-K scratch: the sizing pass books the upper bound (8 partial planes) per layer of a launch
-        cp.partial_bytes = (size_t)8 * x.n * OH * OW * pc->cout_pad * sizeof(float);
-        if (dry() || rc) return cp;
+        if (rc) return cp;
+        // (the sizing pass runs through the same planning -- pointers are placeholders there -- so that it books exactly the
+        //  split-K planes the launch will use: a flat "8 planes per layer" used to be most of the workspace, 2 GB per big-map layer)
         ConvArgs& a = cp.a;
         a.x = x.p;
         a.N = x.n;
@@ -953,7 +1005,7 @@ struct rgbd_elic {
                    (pc2 ? 2.0 * (double)x.n * OH * OW * (double)pc2->cout * pc2->cin : 0.0) +
                    (pc3 ? 2.0 * (double)x.n * OH * OW * (double)pc3->cout * pc3->cin : 0.0);
         cp.fused = pc2 != nullptr;
-        cp.ok = true;
+        cp.ok = !dry();
         return cp;
     }
 
@@ -1573,9 +1625,11 @@ struct rgbd_elic {
                                         "attn", "spf", "conv", "rb", "rb", "rb", "spf", "conv", "attn"};
         const std::string pr = "g_a.rgb_analysis_transform.", pd = "g_a.depth_analysis_transform.";
         Act r = rgb_in, d = depth_in;
+        Ends ends = ends_begin();
         for (int i = 0; i < 18; ++i) {
             const std::string k = kinds[i], si = std::to_string(i);
             const bool next_spf = (i + 1 < 18) && std::string(kinds[i + 1]) == "spf";
+            ends_stage(ends, k != "spf");
             Act rdst, ddst;
             const Act *pr_dst = nullptr, *pd_dst = nullptr;
             Act rcat, dcat;
@@ -1619,6 +1673,7 @@ struct rgbd_elic {
                 bi_spf(pr + si, view(r, 0, N), view(d, 0, N), view(r, N, N), view(d, N, N));
             }
         }
+        ends_finish(ends);
         *y_r = r;
         *y_d = d;
     }
@@ -1630,9 +1685,11 @@ struct rgbd_elic {
                                         "rb", "rb", "rb", "deconv", "spf", "rb", "rb", "rb", "deconv"};
         const std::string pr = "g_s.rgb_synthesis_transform.", pd = "g_s.depth_synthesis_transform.";
         Act r = yr, d = yd;
+        Ends ends = ends_begin();
         for (int i = 0; i < 18; ++i) {
             const std::string k = kinds[i], si = std::to_string(i);
             const bool next_spf = (i + 1 < 18) && std::string(kinds[i + 1]) == "spf";
+            ends_stage(ends, k != "spf");
             if (k == "spf") {
                 bi_spf(pr + si, view(r, 0, N), view(d, 0, N), view(r, N, N), view(d, N, N));
                 continue;
@@ -1670,6 +1727,7 @@ struct rgbd_elic {
                 d = dcat;
             }
         }
+        ends_finish(ends);
         *xr = r;
         *xd = d;
     }
@@ -2341,6 +2399,7 @@ int rgbd_elic::ensure_arena(size_t bytes)
         arena.cap = 0;
     }
     bytes += bytes / 16;
+    bytes = (bytes + 255) & ~(size_t)255;  // (the high end of the two-ended stack allocates down from base + cap)
     HIP_TRY(hipMalloc((void**)&arena.base, bytes));
     arena.cap = bytes;
 
@@ -2357,7 +2416,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     const int ny = per_image ? B : 1;
     named.clear();
     pre_leads.clear();
-    arena.top = 0;
+    arena.reset();
     rc = 0;
 
     // ==== prologue (never captured): workspace of the call, upload of the stream geometry, input layout conversion ====
@@ -2444,6 +2503,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
                 copy_ch(yr_t, y_r);
                 copy_ch(yd_t, y_d);
                 arena.top = mark;
+                ends_release();
             }
             h_a(y_r, y_d, &z_r, &z_d);
             named["z_r"] = z_r;
@@ -2551,7 +2611,7 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
     named.clear();
     pre_leads.clear();
-    arena.top = 0;
+    arena.reset();
     rc = 0;
     dbg_sym = dbg_idx = nullptr;  // forward() keeps no symbols: the last compress()'s are gone with its workspace layout
     dbg_x = dbg_s = nullptr;
@@ -2576,6 +2636,7 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
             copy_ch(yr_t, y_r);
             copy_ch(yd_t, y_d);
             arena.top = mark;
+            ends_release();
         }
         h_a(y_r, y_d, &z_r, &z_d);
         Act zh_r = alloc(B, zh, zw, N), zh_d = alloc(B, zh, zw, N);
@@ -2663,7 +2724,7 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     if (per_image < 0) return RGBD_EINVAL;
     named.clear();
     pre_leads.clear();
-    arena.top = 0;
+    arena.reset();
     rc = 0;
 
     // ==== prologue (never captured): upload the streams ================================================================
@@ -2848,7 +2909,7 @@ int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
     named.clear();
     pre_leads.clear();
-    arena.top = 0;
+    arena.reset();
     rc = 0;
     dbg_sym = dbg_idx = nullptr;  // forward() keeps no symbols: the last compress()'s are gone with its workspace layout
     dbg_x = dbg_s = nullptr;
@@ -2920,7 +2981,7 @@ int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_im
     const int ny = per_image ? B : 1;
     named.clear();
     pre_leads.clear();
-    arena.top = 0;
+    arena.reset();
     rc = 0;
     int64_t* meta64 = (int64_t*)arena.take(sizeof(int64_t) * (size_t)(8 * B + 64));
     int32_t* sym = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(B * T));
@@ -3047,7 +3108,7 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
     const int per_image = (n_y == B) ? 1 : 0;
     named.clear();
     pre_leads.clear();
-    arena.top = 0;
+    arena.reset();
     rc = 0;
 
     // ==== prologue (never captured): upload the streams, every stream into a slot of the size the encoder may produce for
@@ -3162,7 +3223,8 @@ static int run_sized(rgbd_elic* m, const std::string& key, F&& run)
     if (!(ge && ge->exec)) {
         m->cur_ge = nullptr;
         m->arena.dry = true;
-        m->arena.top = m->arena.peak = 0;
+        m->arena.reset();
+        m->arena.peak = 0;
         int r = run();
         m->arena.dry = false;
         if (r) return r;
@@ -4177,6 +4239,8 @@ int rgbd_elic_decompress_united(rgbd_elic* m, const uint8_t* const* y_rgb, const
     if (m->profile && !r) m->profile_collect();
     return r;
 }
+
+int64_t rgbd_elic_workspace_bytes(const rgbd_elic* m) { return m ? (int64_t)m->arena.cap : -1; }
 
 int rgbd_elic_graph_count(const rgbd_elic* m)
 {

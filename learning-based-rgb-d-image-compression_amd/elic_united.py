@@ -448,6 +448,10 @@ class ELIC_united:
         """Call shapes whose launch sequence is cached as a HIP graph on this engine instance."""
         return int(lib().rgbd_elic_graph_count(self._h))
 
+    def workspace_bytes(self) -> int:
+        """HBM workspace of this engine instance (not the packed weights, which the instances of a pool share)."""
+        return int(lib().rgbd_elic_workspace_bytes(self._h))
+
     def set_profile(self, on: bool):
         check(lib().rgbd_elic_set_profile(self._h, 1 if on else 0), "set_profile")
 

@@ -45,7 +45,17 @@ def test_single_rank_line_has_the_contract_fields():
     assert abs(lat["value"] - 480 * 640 / ((lat["enc_ms_per_image"] + lat["dec_ms_per_image"]) * 1e-3) / 1e6) < 0.02 * lat["value"]
     assert r["latency_trained_like"]["value"] > lat["value"] * 0.8
     assert r["vs_cpu"]["throughput"] > r["vs_cpu"]["latency_tester_semantics"] > 1.0
-    assert [w["workload"] for w in r["workloads"]] == ["c3_4x480x640", "c2_8x256x256"]
+    assert [w["workload"] for w in r["workloads"]] == ["c3_4x480x640", "c2_8x256x256", "c5_stf_1x512x512", "c5_stf_4x512x512"]
+    for w in r["workloads"][2:]:  # BASELINE config 5 rides along with its own roofline and CPU baseline
+        assert w["value"] > 1.0 and 0.05 < w["roofline"]["frac"] < 1.0 and w["cpu_baseline"]["kind"] == "port" and w["vs_cpu"] > 1.0
+    # what the line costs and what it was measured under (round-3 review)
+    assert r["config"]["pairs_in_flight"] == 16 and 0.1 < r["config"]["hbm_workspace_gib_per_instance"] <= 3.0
+    assert abs(r["config"]["hbm_workspace_gib"] - 4 * r["config"]["hbm_workspace_gib_per_instance"]) < 0.05
+    sus = r["sustained"]
+    assert sus["steps"] == 12 and len(sus["ms_per_step_by_round"]) == 3 and sus["value"] > 0.5 * r["value"]
+    par = r["parity"]
+    assert par["of"] == 13 and 0 < par["goldens_identical"] <= 13 and "f_480x640_stress" in par["operating_point"]
+    assert "BATCH THROUGHPUT" in r["vs_cpu"]["note"]
 
 
 @pytest.mark.timeout(900)

@@ -275,8 +275,9 @@ def test_malformed_streams_are_an_error_or_garbage_never_a_fault(net):
             dec(ry_=bad)
         with pytest.raises((ValueError, RgbdError)):
             dec(dz_=bad)
+    T = 320 * (rp.shape[-2] // 16) * (rp.shape[-1] // 16)  # symbols per stream; the encoder's worst case is 5 words per symbol
     with pytest.raises((ValueError, RgbdError)):
-        dec(ry_=ry + bytes(8 * len(ry)))  # longer than any stream of this shape
+        dec(ry_=ry + bytes(4 * (5 * T + 1024)))  # longer than any stream of this shape
     # damaged but well-formed: garbage pixels, no fault
     dec(ry_=ry[:8])                                  # only the final state: every later read is past the end
     dec(ry_=ry[:len(ry) // 2 & ~3])                  # truncated
