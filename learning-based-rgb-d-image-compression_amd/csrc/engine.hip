@@ -1227,7 +1227,7 @@ struct rgbd_elic {
         Act t1 = take_lead(p + ".branch.0", x);
         Epi e;
         Act idn = x;
-        if (convs.count(p + ".skip.weight")) idn = conv(p + ".skip", x, 1, 0);
+        if (convs.count(p + ".skip.weight")) idn = conv(p + ".skip", x, 1, 0, Epi(), &out);  // (in place: see bottleneck2)
         e.res1 = &idn;
         if (lead) {
             conv(p + ".branch.2", t1, 1, 1, e, &out, &last_name, &next_lead, &lead_out);
@@ -1344,9 +1344,12 @@ struct rgbd_elic {
         take_lead2(lead0, x, t1);
         Act idn[2] = {x[0], x[1]};
         if (skip) {
+            // the skip path lands in the block's output buffer and the last layer adds to it in place (each element is read
+            // and written by the one thread that owns it): no 2 x 252 MB identity tensor at the workspace's peak stage
             const std::string sk[2] = {p[0] + ".skip", p[1] + ".skip"};
             const Epi none[2];
-            conv2(sk, x, 1, 0, none, nullptr, idn);
+            const Act* sdst[2] = {&out[0], &out[1]};
+            conv2(sk, x, 1, 0, none, sdst, idn);
         } else if (convs.count(p[0] + ".skip.weight") || convs.count(p[1] + ".skip.weight")) {
             fail(RGBD_EINVAL);  // (the two branches are built alike)
             return;
