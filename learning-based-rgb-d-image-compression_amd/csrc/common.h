@@ -184,10 +184,13 @@ int launch_fill_zero(float* p, size_t n, hipStream_t s);
 // packed input of the first analysis conv: y[n][oy][ox][KP], see im2col5s2_kernel
 int launch_im2col5s2(const float* x, int N, int H, int W, int cs, int C, float* y, int OH, int OW, int KP, hipStream_t s);
 // swin.hip (STF_united)
+// x1 / w1 / b1 / y1 (all or none): a second tensor of the same shape with its own weights in the same launch (the other modality)
 int launch_layernorm(const float* x, size_t ntok, int C, int xcs, const float* w, const float* b, float* y, int ycs,
-                     hipStream_t s);
+                     hipStream_t s, const float* x1 = nullptr, const float* w1 = nullptr, const float* b1 = nullptr,
+                     float* y1 = nullptr);
 int launch_window_attention(const float* qkv, int B, int H, int W, int C, int qcs, int heads, int shift, const float* rpb,
-                            float* out, int ocs, hipStream_t s);
+                            float* out, int ocs, hipStream_t s, const float* qkv1 = nullptr, const float* rpb1 = nullptr,
+                            float* out1 = nullptr);
 int launch_patch_merge_gather(const float* x, int B, int H, int W, int C, int xcs, float* y, int ycs, hipStream_t s);
 int launch_pixel_shuffle2(const float* x, int B, int H, int W, int Co, int xcs, float* y, int ycs, hipStream_t s);
 

@@ -2025,57 +2025,120 @@ struct rgbd_elic {
         if (r) fail(r);
         return y;
     }
-    // stf_united.py:118-214: x + proj(attn(norm1(x))), then + mlp(norm2(.)); GELU and both adds are conv epilogues
-    Act swin_block(const std::string& p, const Act& x, int shift, int heads)
+    // stf_united.py:118-214: x + proj(attn(norm1(x))), then + mlp(norm2(.)); GELU and both adds are conv epilogues -- for both
+    // modalities at once (round 4): the RGB and the depth stack of STF_united run the same layer shapes
+    // on independent data between two fusions, so every Linear is one grouped conv launch (conv2) and every LayerNorm /
+    // window attention one launch over both tensors -- half the launches of a model whose launches are too small to fill the
+    // chip (35 us on average at one 512x512 pair).  Each output keeps its arithmetic: bit-identical to the one-by-one form.
+    void layernorm2(const std::string p[2], const Act x[2], Act y[2])
     {
-        Act out = alloc(x.n, x.h, x.w, x.c);
+        float *w[2], *b[2];
+        for (int m = 0; m < 2; ++m) {
+            y[m] = alloc(x[m].n, x[m].h, x[m].w, x[m].c);
+            w[m] = dense_of(p[m] + ".weight");
+            b[m] = dense_of(p[m] + ".bias");
+        }
+        if (dry() || rc || !w[0] || !b[0] || !w[1] || !b[1]) return;
+        const bool same = g_pair && x[0].n == x[1].n && x[0].h == x[1].h && x[0].w == x[1].w && x[0].c == x[1].c &&
+                          x[0].cs == x[1].cs && y[0].cs == y[1].cs;
+        const size_t ntok = (size_t)x[0].n * x[0].h * x[0].w;
+        int r = launch_layernorm(x[0].p, ntok, x[0].c, x[0].cs, w[0], b[0], y[0].p, y[0].cs, s, same ? x[1].p : nullptr,
+                                 same ? w[1] : nullptr, same ? b[1] : nullptr, same ? y[1].p : nullptr);
+        if (!r && !same)
+            r = launch_layernorm(x[1].p, (size_t)x[1].n * x[1].h * x[1].w, x[1].c, x[1].cs, w[1], b[1], y[1].p, y[1].cs, s);
+        if (r) fail(r);
+    }
+    void swin_block2(const std::string p[2], const Act x[2], int shift, int heads, Act out[2])
+    {
+        for (int m = 0; m < 2; ++m) out[m] = alloc(x[m].n, x[m].h, x[m].w, x[m].c);
         const size_t mark = arena.top;
-        Act t = layernorm(p + ".norm1", x);
-        Act qkv = conv(p + ".attn.qkv", t, 1, 0);
-        Act a = alloc(x.n, x.h, x.w, x.c);
-        float* rpb = dense_of(p + ".attn.relative_position_bias_table");
-        if (!dry() && !rc && rpb) {
-            const int r = launch_window_attention(qkv.p, x.n, x.h, x.w, x.c, qkv.cs, heads, shift, rpb, a.p, a.cs, s);
+        auto names = [&](const char* suf, std::string n[2]) {
+            n[0] = p[0] + suf;
+            n[1] = p[1] + suf;
+        };
+        std::string n[2];
+        const Epi none[2];
+        Act t[2], qkv[2], a[2], x1[2], t2[2], hdn[2], o[2];
+        names(".norm1", n);
+        layernorm2(n, x, t);
+        names(".attn.qkv", n);
+        conv2(n, t, 1, 0, none, nullptr, qkv);
+        float* rpb[2];
+        for (int m = 0; m < 2; ++m) {
+            a[m] = alloc(x[m].n, x[m].h, x[m].w, x[m].c);
+            rpb[m] = dense_of(p[m] + ".attn.relative_position_bias_table");
+        }
+        if (!dry() && !rc && rpb[0] && rpb[1]) {
+            const bool same = g_pair && x[0].n == x[1].n && x[0].h == x[1].h && x[0].w == x[1].w && x[0].c == x[1].c &&
+                              qkv[0].cs == qkv[1].cs && a[0].cs == a[1].cs;
+            int r = launch_window_attention(qkv[0].p, x[0].n, x[0].h, x[0].w, x[0].c, qkv[0].cs, heads, shift, rpb[0], a[0].p, a[0].cs,
+                                            s, same ? qkv[1].p : nullptr, same ? rpb[1] : nullptr, same ? a[1].p : nullptr);
+            if (!r && !same)
+                r = launch_window_attention(qkv[1].p, x[1].n, x[1].h, x[1].w, x[1].c, qkv[1].cs, heads, shift, rpb[1], a[1].p,
+                                            a[1].cs, s);
             if (r) fail(r);
         }
-        Epi e1;
-        e1.res1 = &x;
-        Act x1 = conv(p + ".attn.proj", a, 1, 0, e1);
-        Act t2 = layernorm(p + ".norm2", x1);
-        Epi g;
-        g.act = ACT_GELU;
-        Act hdn = conv(p + ".mlp.fc1", t2, 1, 0, g);
-        Epi e2;
-        e2.res1 = &x1;
-        conv(p + ".mlp.fc2", hdn, 1, 0, e2, &out);
+        Epi e1[2];
+        e1[0].res1 = &x[0];
+        e1[1].res1 = &x[1];
+        names(".attn.proj", n);
+        conv2(n, a, 1, 0, e1, nullptr, x1);
+        names(".norm2", n);
+        layernorm2(n, x1, t2);
+        Epi g[2];
+        g[0].act = g[1].act = ACT_GELU;
+        names(".mlp.fc1", n);
+        conv2(n, t2, 1, 0, g, nullptr, hdn);
+        Epi e2[2];
+        e2[0].res1 = &x1[0];
+        e2[1].res1 = &x1[1];
+        const Act* odst[2] = {&out[0], &out[1]};
+        names(".mlp.fc2", n);
+        conv2(n, hdn, 1, 0, e2, odst, o);
         arena.top = mark;
-        return out;
     }
-    // stf_united.py:270-366; down: 0 none, 1 PatchMerging (:217-249), 2 PatchSplit (:252-267)
-    Act basic_layer(const std::string& p, const Act& x_in, int depth, int heads, int down)
+    // stf_united.py:270-366 for both modalities; down: 0 none, 1 PatchMerging (:217-249), 2 PatchSplit (:252-267)
+    void basic_layer2(const std::string p[2], const Act x_in[2], int depth, int heads, int down, Act out[2])
     {
-        Act x = x_in;
-        for (int k = 0; k < depth; ++k) x = swin_block(p + ".blocks." + std::to_string(k), x, (k & 1) ? 2 : 0, heads);
+        Act x[2] = {x_in[0], x_in[1]};
+        for (int k = 0; k < depth; ++k) {
+            const std::string pb[2] = {p[0] + ".blocks." + std::to_string(k), p[1] + ".blocks." + std::to_string(k)};
+            Act o[2];
+            swin_block2(pb, x, (k & 1) ? 2 : 0, heads, o);
+            x[0] = o[0];
+            x[1] = o[1];
+        }
+        const std::string pn[2] = {p[0] + ".downsample.norm", p[1] + ".downsample.norm"};
+        const std::string prd[2] = {p[0] + ".downsample.reduction", p[1] + ".downsample.reduction"};
+        const Epi none[2];
         if (down == 1) {
-            Act g4 = alloc(x.n, x.h / 2, x.w / 2, 4 * x.c);
-            if (!dry() && !rc) {
-                const int r = launch_patch_merge_gather(x.p, x.n, x.h, x.w, x.c, x.cs, g4.p, g4.cs, s);
-                if (r) fail(r);
+            Act g4[2], t[2];
+            for (int m = 0; m < 2; ++m) {
+                g4[m] = alloc(x[m].n, x[m].h / 2, x[m].w / 2, 4 * x[m].c);
+                if (!dry() && !rc) {
+                    const int r = launch_patch_merge_gather(x[m].p, x[m].n, x[m].h, x[m].w, x[m].c, x[m].cs, g4[m].p, g4[m].cs, s);
+                    if (r) fail(r);
+                }
             }
-            Act t = layernorm(p + ".downsample.norm", g4);
-            return conv(p + ".downsample.reduction", t, 1, 0);
+            layernorm2(pn, g4, t);
+            conv2(prd, t, 1, 0, none, nullptr, out);
+            return;
         }
         if (down == 2) {
-            Act t = layernorm(p + ".downsample.norm", x);
-            Act r2 = conv(p + ".downsample.reduction", t, 1, 0);
-            Act y = alloc(x.n, 2 * x.h, 2 * x.w, x.c / 2);
-            if (!dry() && !rc) {
-                const int r = launch_pixel_shuffle2(r2.p, x.n, x.h, x.w, x.c / 2, r2.cs, y.p, y.cs, s);
-                if (r) fail(r);
+            Act t[2], r2[2];
+            layernorm2(pn, x, t);
+            conv2(prd, t, 1, 0, none, nullptr, r2);
+            for (int m = 0; m < 2; ++m) {
+                out[m] = alloc(x[m].n, 2 * x[m].h, 2 * x[m].w, x[m].c / 2);
+                if (!dry() && !rc) {
+                    const int r = launch_pixel_shuffle2(r2[m].p, x[m].n, x[m].h, x[m].w, x[m].c / 2, r2[m].cs, out[m].p, out[m].cs, s);
+                    if (r) fail(r);
+                }
             }
-            return y;
+            return;
         }
-        return x;
+        out[0] = x[0];
+        out[1] = x[1];
     }
     void stf_stack(const std::string& root, const char* kind, const Act& r_in, const Act& d_in, const int* depths,
                    const int* heads, int down, Act* r_out, Act* d_out)
@@ -2084,10 +2147,13 @@ struct rgbd_elic {
         int li = 0;
         for (int i = 0; i < 4; ++i) {
             const int dn = i < 3 ? down : 0;
-            const std::string pr = root + ".rgb_" + kind + "_layers." + std::to_string(li);
-            const std::string pd = root + ".depth_" + kind + "_layers." + std::to_string(li);
-            r = basic_layer(pr, r, depths[i], heads[i], dn);
-            d = basic_layer(pd, d, depths[i], heads[i], dn);
+            const std::string pl[2] = {root + ".rgb_" + kind + "_layers." + std::to_string(li),
+                                       root + ".depth_" + kind + "_layers." + std::to_string(li)};
+            const Act xin[2] = {r, d};
+            Act o[2];
+            basic_layer2(pl, xin, depths[i], heads[i], dn, o);
+            r = o[0];
+            d = o[1];
             ++li;
             if (i < 3) {  // Bi-CPT fusion added to the streams (stf_united.py:481-489 / 581-589)
                 Act r2 = alloc(r.n, r.h, r.w, r.c), d2 = alloc(d.n, d.h, d.w, d.c);
@@ -2112,18 +2178,21 @@ struct rgbd_elic {
         static const int depths[4] = {2, 6, 2, 2}, heads[4] = {24, 12, 6, 3};
         Act r, d;
         stf_stack("g_s", "syn", yr, yd, depths, heads, 2, &r, &d);
+        // stf_united.py:550-559; the first end conv has the same shape in both modalities (one grouped launch), the last differs
+        const std::string n0[2] = {"g_s.rgb_end_conv.0", "g_s.depth_end_conv.0"};
+        const Act in[2] = {r, d};
+        const Epi none[2];
+        Act t[2];
+        conv2(n0, in, 1, 2, none, nullptr, t);
         const char* mods[2] = {"rgb", "depth"};
-        const Act* in[2] = {&r, &d};
         Act* out[2] = {xr, xd};
-        for (int m = 0; m < 2; ++m) {  // stf_united.py:550-559
-            const std::string p = std::string("g_s.") + mods[m] + "_end_conv.";
-            Act t = conv(p + "0", *in[m], 1, 2);
-            Act u = alloc(t.n, 2 * t.h, 2 * t.w, t.c / 4);
+        for (int m = 0; m < 2; ++m) {
+            Act u = alloc(t[m].n, 2 * t[m].h, 2 * t[m].w, t[m].c / 4);
             if (!dry() && !rc) {
-                const int q = launch_pixel_shuffle2(t.p, t.n, t.h, t.w, t.c / 4, t.cs, u.p, u.cs, s);
+                const int q = launch_pixel_shuffle2(t[m].p, t[m].n, t[m].h, t[m].w, t[m].c / 4, t[m].cs, u.p, u.cs, s);
                 if (q) fail(q);
             }
-            *out[m] = conv(p + "2", u, 1, 1);
+            *out[m] = conv(std::string("g_s.") + mods[m] + "_end_conv.2", u, 1, 1);
         }
     }
 

@@ -42,6 +42,12 @@ def _ssim_cs(x, y, g, data_range):
 
 
 def ms_ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> float:
+    return float(ms_ssim_tensor(x, y, data_range).item())
+
+
+def ms_ssim_tensor(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """The value as a 0-d tensor on x's device (no host synchronisation: the pipelined harness fetches all of an image's
+    metrics with one copy)."""
     if min(x.shape[-2:]) <= (11 - 1) * 2 ** 4:
         raise ValueError("image too small for 5-scale MS-SSIM (needs a side > 160)")
     g = _gauss(device=x.device)
@@ -55,7 +61,7 @@ def ms_ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> float:
             x = F.avg_pool2d(x, 2, padding=pad)
             y = F.avg_pool2d(y, 2, padding=pad)
     vals = torch.stack(mcs + [torch.relu(s)], dim=0)
-    return float(torch.prod(vals ** w.view(-1, 1, 1), dim=0).mean().item())
+    return torch.prod(vals ** w.view(-1, 1, 1), dim=0).mean()
 
 
 def compute_metrics(a, b, max_val: float = 1.0):
@@ -66,6 +72,22 @@ def compute_metrics(a, b, max_val: float = 1.0):
     except ValueError:
         m = float("nan")
     return p, m
+
+
+def metrics_tensor(a, b, max_val: float = 1.0) -> torch.Tensor:
+    """[mse, ms_ssim (nan when the image is too small)] of the clamped tensors as one device tensor; `finish_metrics` turns
+    the fetched pair into compute_metrics()'s (psnr, ms_ssim) with the same host arithmetic."""
+    a, b = a.clamp(0, 1), b.clamp(0, 1)
+    mse = torch.mean((a - b) ** 2)
+    try:
+        m = ms_ssim_tensor(a.float(), b.float(), data_range=max_val)
+    except ValueError:
+        m = torch.full_like(mse, float("nan"))
+    return torch.stack([mse, m])
+
+
+def finish_metrics(mse: float, m: float, max_val: float = 1.0):
+    return float(20 * np.log10(max_val) - 10 * np.log10(mse)), float(m)
 
 
 class AverageMeter:

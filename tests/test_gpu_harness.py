@@ -131,22 +131,25 @@ def test_tester_united_images_in_flight(net, tmp_path, monkeypatch):
         Image.fromarray((r.transpose(1, 2, 0) * 255).astype(np.uint8)).save(root / "rgb" / f"{i:04d}.png")
         Image.fromarray((d[0] * 9000).astype(np.uint16)).save(root / "depth" / f"{i:04d}.png")
     monkeypatch.chdir(tmp_path)
+    from rgbd_amd._lib import lib
+
     res = {}
     for exp, workers in (("seq", 1), ("par", 3)):
         args = types.SimpleNamespace(channel=4, debug=False, experiment=exp, dataset=str(root), model="ELIC_united",
                                      quality="2_2", checkpoint=None)
         t = rgbd_amd.TesterUnited(args, rgbd_amd.model_config(), net=net)
-        t.save_reconstructions = False
-        rows, meters = t.test_model(padding_mode="replicate0", padding=True, workers=workers)
+        t.save_reconstructions = True  # (round 4: the pipelined path converts the reconstructions on the GPU and encodes
+        rows, meters = t.test_model(padding_mode="replicate0", padding=True, workers=workers)  # the PNGs in writer threads)
         rec_dir = t.get_rec_dir(padding=True, padding_mode="replicate0")
         files = {}
-        for sub in ("depth_bin", "rgb_bin"):
+        for sub in ("depth_bin", "rgb_bin", "rgb_rec", "depth_rec"):
             for fn in sorted(os.listdir(os.path.join(rec_dir, sub))):
                 files[sub + "/" + fn] = open(os.path.join(rec_dir, sub, fn), "rb").read()
         res[exp] = (rows, meters, files)
         assert t.job_mpx_per_s > 0
+        assert lib().rgbd_get_blocking_sync() == 0  # the pipelined path hands the device its default wait policy back
     (r0, m0, f0), (r1, m1, f1) = res["seq"], res["par"]
-    assert f0 == f1 and len(f0) == 2 * len(sizes)
+    assert f0 == f1 and len(f0) == 5 * len(sizes)  # 2 containers + rgb PNG + 8- and 16-bit depth PNG per image
     for a, b in zip(r0, r1):
         assert a["name"] == b["name"]
         for k in ("rgb_bpp", "depth_bpp", "rgb_psnr", "depth_psnr"):
