@@ -576,7 +576,7 @@ def main():
                                       "conv_ms_per_step": round(prof_lat["conv_ms"] / 2, 3), "conv_tiles": "latency",
                                       "note": "HIP events around every conv launch on its stream, single engine instance, "
                                               "no concurrent kernels, separate pass after the timed region, latency tiles "
-                                              "(what a lone instance runs); profiles/r03_bench_w1_summary.txt"},
+                                              "(what a lone instance runs); profiles/r04_bench_w1_summary.txt"},
                          "isolated_timed_tiles": {"achieved": round(iso_tp_tflops, 3),
                                                   "frac": round(iso_tp_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                                                   "conv_ms_per_step": round(prof1["conv_ms"] / 2, 3), "conv_tiles": tile_mode,

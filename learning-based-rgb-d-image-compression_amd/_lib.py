@@ -55,23 +55,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return _SO
 
 
-def build_experiment_x6() -> str:
-    """EXPERIMENT build, never loaded by default: librgbd_amd_x6.so = the same sources with conv_mfma.hip compiled
-    -DRGBD_CONV_BF16X6 (every fp32 MFMA group replaced by six bf16 MFMAs on split operands).  Select it for a
-    process with RGBD_AMD_LIB=<path>; tools/x6_parity.sh runs the reference-golden parity cases on it."""
-    build()
-    csrc = os.path.join(_HERE, "csrc")
-    objdir = os.path.join(csrc, "build")
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    obj = os.path.join(objdir, "conv_mfma.x6.o")
-    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-DRGBD_CONV_BF16X6", "-c",
-                           os.path.join(csrc, "conv_mfma.hip"), "-o", obj])
-    objs = [os.path.join(objdir, n + ".o") for n in _SRCS if n != "conv_mfma.hip"] + [obj]
-    so = os.path.join(_HERE, "librgbd_amd_x6.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", so])
-    return so
-
-
 def lib():
     global _LIB
     if _LIB is not None:

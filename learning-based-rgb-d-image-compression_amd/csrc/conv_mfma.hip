@@ -24,44 +24,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- experiment build (-DRGBD_CONV_BF16X6, never the shipped library): every group of four fp32 MFMAs over 16
-// channels becomes six v_mfma_f32_16x16x16bf16_1k on operands split into three bf16 parts (x = h + m + l; products hh, hm,
-// mh, hl, lh, mm, smallest first).  A lane's f32x4 fragment holds channels 4q .. 4q+3 of its row, which is exactly the
-// k-block a lane supplies to the 16x16x16 instruction, so the substitution is local.  The split runs in registers at every
-// use -- slow, and meant to be: this build exists to count decision flips and PSNR differences, not to be timed.
-#ifdef RGBD_CONV_BF16X6
-typedef __bf16 rgbd_bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void rgbd_split3(const f32x4& v, rgbd_bf16x4 p[3])
-{
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float x = v[e];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            unsigned u = __float_as_uint(x);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            u &= 0xFFFF0000u;
-            const float h = __uint_as_float(u);
-            unsigned short hb = (unsigned short)(u >> 16);
-            __bf16 b;
-            __builtin_memcpy(&b, &hb, 2);
-            p[t][e] = b;
-            x -= h;
-        }
-    }
-}
-__device__ __forceinline__ f32x4 rgbd_mma16_x6(const rgbd_bf16x4 a[3], const rgbd_bf16x4 b[3], f32x4 acc)
-{
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], acc, 0, 0, 0);
-    return acc;
-}
-#endif
-
 // KC = channels per LDS stage (16 or 64).  LDS rows are padded by one 16-byte slot when KC > 16 so that the 16 rows a
 // ds_read_b128 lane group touches fall on different banks (row stride 272 B instead of 256 B).
 // DMA (KC == 16 only): operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a
@@ -428,20 +390,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
                     af[i] = *reinterpret_cast<const f32x4*>(cur_w + (j * TM + (wm * MT + i) * 16 + l15) * RS + kk * 16 + q * 4);
 #pragma unroll
                 for (int k = 0; k < NT; ++k) bf[k] = *reinterpret_cast<const f32x4*>(cur_p + brow0[k] + toff);
-#ifdef RGBD_CONV_BF16X6
-                {
-                    rgbd_bf16x4 bp[NT][3];
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) rgbd_split3(bf[k], bp[k]);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        rgbd_bf16x4 ap[3];
-                        rgbd_split3(af[i], ap);
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) acc[i][k] = rgbd_mma16_x6(ap, bp[k], acc[i][k]);
-                    }
-                }
-#else
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -449,7 +397,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                         for (int k = 0; k < NT; ++k)
                             acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[k][e], acc[i][k], 0, 0, 0);
-#endif
             }
         }
     }
@@ -590,20 +537,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                 for (int i = 0; i < G2; ++i)
                     af2[i] = *reinterpret_cast<const f32x4*>(cw + ((c * G2 + i) * 16 + l15) * 16 + q * 4);
-#ifdef RGBD_CONV_BF16X6
-                {
-                    rgbd_bf16x4 bp[NT][3];
-#pragma unroll
-                    for (int k = 0; k < NT; ++k) rgbd_split3(acc[c][k], bp[k]);
-#pragma unroll
-                    for (int i = 0; i < G2; ++i) {
-                        rgbd_bf16x4 ap[3];
-                        rgbd_split3(af2[i], ap);
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) acc2[i][k] = rgbd_mma16_x6(ap, bp[k], acc2[i][k]);
-                    }
-                }
-#else
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -611,7 +544,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                         for (int k = 0; k < NT; ++k)
                             acc2[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af2[i][e], acc[c][k][e], acc2[i][k], 0, 0, 0);
-#endif
             }
             if (g > 0) __syncthreads();  // everyone has read the previous group out of the staging tile
 #pragma unroll
@@ -684,20 +616,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                     for (int k = 0; k < NT; ++k)
                         bf3[k] = *reinterpret_cast<const f32x4*>(est + ((wn * NT + k) * 16 + l15) * SW2 + c * 16 + q * 4);
-#ifdef RGBD_CONV_BF16X6
-                    {
-                        rgbd_bf16x4 bp[NT][3];
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) rgbd_split3(bf3[k], bp[k]);
-#pragma unroll
-                        for (int i = 0; i < MT; ++i) {
-                            rgbd_bf16x4 ap[3];
-                            rgbd_split3(af3[i], ap);
-#pragma unroll
-                            for (int k = 0; k < NT; ++k) uacc[i][k] = rgbd_mma16_x6(ap, bp[k], uacc[i][k]);
-                        }
-                    }
-#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -705,7 +623,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                             for (int k = 0; k < NT; ++k)
                                 uacc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(af3[i][e], bf3[k][e], uacc[i][k], 0, 0, 0);
-#endif
                 }
             }
         }

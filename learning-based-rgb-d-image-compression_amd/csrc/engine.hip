@@ -1592,16 +1592,17 @@ struct rgbd_elic {
     }
 
     // modules/transform/attention.py:63-67 -- returns the per-(n,c) sigmoid weights
-    float* se_weights(const std::string& p, const Act& x)
+    // means / mstride: the channel means of x when somebody holds them already (Bi-CEE: SliceMeans), else they are computed
+    float* se_weights(const std::string& p, const Act& x, const float* means = nullptr, int mstride = 0)
     {
         float* w0 = dense_of(p + ".fc.0.weight");
         float* w1 = dense_of(p + ".fc.2.weight");
-        float* mean = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
+        float* mean = means ? nullptr : (float*)arena.take((size_t)x.n * x.c * sizeof(float));
         float* sc = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
         float* hid = (float*)arena.take((size_t)x.n * (x.c / 16 + 1) * sizeof(float));
         if (dry() || rc || !w0 || !w1) return sc;
-        int r = launch_channel_mean(x.p, x.n, x.h * x.w, x.cs, x.c, mean, s);
-        if (!r) r = launch_se_fc(mean, x.n, x.c, x.c / 16, w0, w1, hid, sc, s);
+        int r = means ? RGBD_OK : launch_channel_mean(x.p, x.n, x.h * x.w, x.cs, x.c, mean, s);
+        if (!r) r = launch_se_fc(means ? means : mean, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0);
         if (r) fail(r);
         return sc;
     }
@@ -1841,14 +1842,15 @@ struct rgbd_elic {
     // rescaled copy the 1x1 conv reads (params + se(params), keeping the reference's association).
     // `part` (1 anchor / 2 non-anchor): the caller only reads that checkerboard half of (scales, means)
     // (ckbd.py:83-125), so the last -- and largest -- conv computes just that half; the values are those of the full conv.
-    Act entropy_params(const std::string& p, const Act& ctx, int part, const Act* dst = nullptr)
+    Act entropy_params(const std::string& p, const Act& ctx, int part, const Act* dst = nullptr, const float* means = nullptr,
+                       int mstride = 0)
     {
         const PackedConv* last = conv_of(p + ".fusion.4.weight");
         if (!last) return Act();
         Act out = dst ? *dst : alloc(ctx.n, ctx.h, ctx.w, last->cout);
         const size_t mark = arena.top;
         Act cat = alloc(ctx.n, ctx.h, ctx.w, ctx.c);
-        float* sc = se_weights(p + ".se", ctx);
+        float* sc = se_weights(p + ".se", ctx, means, mstride);
         scale_to(ctx, sc, 1, cat);
         Epi relu;
         relu.act = ACT_RELU;
@@ -1962,7 +1964,22 @@ struct rgbd_elic {
         int c0 = 0;
         int64_t part_off = 0;
         const int B = hyp_r.n, h = hyp_r.h, w = hyp_r.w;
-        (void)B;
+        // SE gates of the entropy-parameter nets (entropy.py:75) need the channel means of their whole input -- 1280 ... 2816
+        // channels, of which 2 x 2M are the hyper parameters, the same tensor for all 20 nets of a call.  A mean is a function
+        // of its own channel only (channel_mean_kernel: one fixed chain per channel), so the means are kept per segment of
+        // the context buffer and only what changed is recomputed: the hyper parameters' once per call, the channel contexts'
+        // once per slice, the local contexts' (2C channels) per part -- the same floats as a pass over the whole input, for
+        // 1/10 of the traffic (round 4; 1.6 GB per c3 step).  hm: [B][2 HC] hyper means; sm: [B][wide] in ctx layout.
+        static const bool mean_cache = getenv("RGBD_NO_MEAN_CACHE") == nullptr;  // A/B switch
+        const int HC2 = 2 * hyp_r.c;
+        float* hm = (float*)arena.take((size_t)B * HC2 * sizeof(float));
+        auto means_of = [&](const Act& t, float* dstm, int stride) {
+            if (dry() || rc || !mean_cache) return;
+            const int r = launch_channel_mean_strided(t.p, t.n, t.h * t.w, t.cs, t.c, dstm, stride, s);
+            if (r) fail(r);
+        };
+        means_of(hyp_r, hm, HC2);
+        means_of(hyp_d, hm + hyp_r.c, HC2);
         for (size_t i = 0; i < slice_ch.size(); ++i) {
             const int C = slice_ch[i];
             const size_t mark = arena.top;
@@ -1971,24 +1988,33 @@ struct rgbd_elic {
             const int HC = hyp_r.c;  // 2M
             const int wide = 4 * C + 2 * HC + (i ? 4 * C : 0);
             Act ctx = alloc(hyp_r.n, h, w, wide);
+            float* sm = (float*)arena.take((size_t)B * wide * sizeof(float));
             copy_ch(hyp_r, view(ctx, 4 * C, HC));
             copy_ch(hyp_d, view(ctx, 4 * C + HC, HC));
+            if (!dry() && !rc && mean_cache) {
+                const int r = launch_copy_channels(hm, HC2, sm + 4 * C, wide, B, HC2, s);
+                if (r) fail(r);
+            }
             if (i) {
                 const Act cr = view(ctx, 4 * C + 2 * HC, 2 * C), cdv = view(ctx, 6 * C + 2 * HC, 2 * C);
                 const std::string cn[2] = {"rgb_channel_context." + si, "depth_channel_context." + si};
                 const Act cx[2] = {view(yhat_r, 0, c0), view(yhat_d, 0, c0)};
                 const Act cdst[2] = {cr, cdv};
                 channel_context2(cn, cx, cdst);
+                means_of(view(ctx, 4 * C + 2 * HC, 4 * C), sm + 4 * C + 2 * HC, wide);  // both channel contexts: adjacent
             }
+            const float* smc = mean_cache ? sm : nullptr;
             const Act yr = y_r ? view(*y_r, c0, C) : Act();
             const Act yd = y_d ? view(*y_d, c0, C) : Act();
             const Act hr = view(yhat_r, c0, C), hd = view(yhat_d, c0, C);
             const int64_t part_syms = (int64_t)C * h * (w / 2);
             const Act r_loc = view(ctx, 0, 2 * C), d_loc = view(ctx, 2 * C, 2 * C);
             // rgb anchor: [hyper, ch ctx]
-            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(ctx, 4 * C, wide - 4 * C), 1);
+            Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(ctx, 4 * C, wide - 4 * C), 1, nullptr,
+                                      smc ? smc + 4 * C : nullptr, wide);
             code_part(cd, 0, 1, p_ra, yr, hr, part_off);
             conv("rgb_local_context." + si, hr, 1, 2, Epi(), &r_loc);
+            means_of(r_loc, sm, wide);
             // depth anchor: [r_loc, hyper, ch ctx] -- d_loc's slot sits between them, so this one input is gathered
             Act p_da = alloc(hyp_r.n, h, w, 2 * C);
             {
@@ -1996,17 +2022,25 @@ struct rgbd_elic {
                 Act in = alloc(hyp_r.n, h, w, wide - 2 * C);
                 copy_ch(r_loc, view(in, 0, 2 * C));
                 copy_ch(view(ctx, 4 * C, wide - 4 * C), view(in, 2 * C, wide - 4 * C));
-                entropy_params("depth_entropy_parameters_anchor." + si, in, 1, &p_da);
+                float* im = (float*)arena.take((size_t)B * (wide - 2 * C) * sizeof(float));  // the gathered input's means, gathered alike
+                if (!dry() && !rc && mean_cache) {
+                    int r = launch_copy_channels(sm, wide, im, wide - 2 * C, B, 2 * C, s);
+                    if (!r) r = launch_copy_channels(sm + 4 * C, wide, im + 2 * C, wide - 2 * C, B, wide - 4 * C, s);
+                    if (r) fail(r);
+                }
+                entropy_params("depth_entropy_parameters_anchor." + si, in, 1, &p_da, mean_cache ? im : nullptr, wide - 2 * C);
                 arena.top = m2;
             }
             code_part(cd, 1, 1, p_da, yd, hd, part_off);
             conv("depth_local_context." + si, hd, 1, 2, Epi(), &d_loc);
+            means_of(d_loc, sm + 2 * C, wide);
             // rgb non-anchor: the whole buffer
-            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, ctx, 2);
+            Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, ctx, 2, nullptr, smc, wide);
             code_part(cd, 0, 0, p_rn, yr, hr, part_off + part_syms);
             conv("rgb_local_context_anchor_with_nonanchor." + si, hr, 1, 2, Epi(), &r_loc);  // replaces r_loc
+            means_of(r_loc, sm, wide);
             // depth non-anchor
-            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, ctx, 2);
+            Act p_dn = entropy_params("depth_entropy_parameters_nonanchor." + si, ctx, 2, nullptr, smc, wide);
             code_part(cd, 1, 0, p_dn, yd, hd, part_off + part_syms);
             part_off += 2 * part_syms;
             c0 += C;

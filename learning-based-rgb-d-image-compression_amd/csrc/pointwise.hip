@@ -209,13 +209,13 @@ int launch_channel_mean_strided(const float* x, int N, int HW, int cs, int C, fl
 // so both passes read weights with consecutive lanes on consecutive addresses.
 // pass 1: one wavefront per (hidden unit, image); lanes stride the dot product, fixed shuffle-tree reduction.
 __global__ __launch_bounds__(64) void se_hidden_kernel(const float* __restrict__ mean, int C, int hidden,
-                                                       const float* __restrict__ w0, float* __restrict__ hid)
+                                                       const float* __restrict__ w0, float* __restrict__ hid, int mstride)
 {
     const int j = blockIdx.x;
     const size_t n = blockIdx.y;
     const int lane = threadIdx.x;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], mean[n * C + c], s);
+    for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], mean[n * mstride + c], s);
 #pragma unroll
     for (int off = 32; off; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) hid[n * hidden + j] = fmaxf(s, 0.f);
@@ -240,9 +240,9 @@ __global__ void se_gate_kernel(const float* __restrict__ hid, int C, int hidden,
 // and measured: at B = 1 the 4 waves of a workgroup walk 44 hidden units each, one memory round trip after the other, and
 // an SE gate took ~100 us instead of 2 x 14 us; the two-launch form below stays.)
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
-                 float* scale, hipStream_t s)
+                 float* scale, hipStream_t s, int mstride)
 {
-    hipLaunchKernelGGL(se_hidden_kernel, dim3(hidden, N), dim3(64), 0, s, mean, C, hidden, w0, hid);
+    hipLaunchKernelGGL(se_hidden_kernel, dim3(hidden, N), dim3(64), 0, s, mean, C, hidden, w0, hid, mstride > 0 ? mstride : C);
     hipLaunchKernelGGL(se_gate_kernel, dim3((C + 255) / 256, N), dim3(256), (size_t)hidden * sizeof(float), s, hid, C,
                        hidden, w1t, scale);
     HIP_TRY(hipGetLastError());

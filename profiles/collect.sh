@@ -4,10 +4,12 @@
 #   2. kernel trace + stats of a single engine instance with its own (latency) tiles  -> <tag>_bench_w1_summary.txt (= roofline.isolated)
 #   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)                              -> <tag>_c3_pmc_*.{csv,json}
 #   4. PMC pass for MFMA utilisation (own run, kernel trace only for the durations)  -> <tag>_mfma_by_kernel.csv
+#   5. phase table of the timed round (conv phases / coder-only / transitions)      -> <tag>_phase_table.txt
+#   6. per-layer conv profile of one instance (tools/layer_profile.py)               -> <tag>_layer_profile_c3.txt
 # Counter passes run the eager launch path (RGBD_NO_GRAPH=1): every dispatch is then an ordinary kernel launch.
-# Usage: bash profiles/collect.sh r03
+# Usage: bash profiles/collect.sh r04
 set -e -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 bench_args=${BENCH_ARGS:---steps 20 --warmup 5}  # the command line the round-end driver uses (BENCH_r01.json)
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
@@ -36,4 +38,8 @@ algo=$(python3 -c "import json,sys;j=json.loads([l for l in open('$out/stats.log
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_default_kernel_stats.csv"
 python3 profiles/pmc_traffic.py "$out/fetch_c3" "$out/write_c3" "$out/${tag}_c3" "$algo" "--workload c3_4x480x640 (RGBD_NO_GRAPH=1)"
 python3 profiles/mfma_util.py "$out/mfma" "$out/${tag}_mfma_by_kernel.csv"
+python3 profiles/phase_table.py "$out/stats" "$out/stats.log" > "$out/${tag}_phase_table.txt"
+LAYER_RAW="entropy_param|channel_context|local_context" python3 tools/layer_profile.py 4 512 640 > "$out/${tag}_layer_profile_c3.txt" 2>&1
+# the raw traces are large: keep the summaries
+rm -rf "$out/stats" "$out/stats_w1" "$out/fetch_c3" "$out/write_c3" "$out/mfma"
 ls "$out"

@@ -155,3 +155,32 @@ def test_single_modal_graphs_on_a_side_stream(net1):
     for o in outs[1:]:
         assert o[0] == outs[0][0] and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2]) and torch.equal(o[3], outs[0][3])
     assert torch.equal(outs[0][1], outs[0][3])  # forward() == decompress(compress())
+
+
+def test_single_modal_pool_matches_single_instance(net1, sd1):
+    """CodecPool for the single-modal model (round-3 review, missing 6; reference models/elic.py:172-325): W engine instances
+    with shared weights code groups of a batch / whole batches concurrently; per-image streams and x_hat are those of one
+    instance coding the images itself, graphs replay on the pool's side streams, and close() restores the wait policy."""
+    import rgbd_amd
+    from rgbd_amd import synth
+    from rgbd_amd._lib import lib
+
+    r, _ = synth.synthetic_batch(4, 128, 192, config_id=41)
+    x = torch.from_numpy(r).cuda()
+    net1.per_image_streams = True
+    try:
+        ref = net1.compress(x)
+        ref_rec = net1.decompress(ref["strings"], ref["shape"])
+    finally:
+        net1.per_image_streams = False
+    with rgbd_amd.CodecPool(sd1, config=rgbd_amd.model_config(), workers=2, device="cuda", per_image_streams=True,
+                            model_cls=rgbd_amd.modelZoo["ELIC"]) as pool:
+        assert pool.single and lib().rgbd_get_blocking_sync() == 1
+        outs, xh = pool.roundtrip(x)  # two groups of two images on two streams
+        assert [s for o in outs for s in o["strings"][0]] == list(ref["strings"][0])
+        assert [s for o in outs for s in o["strings"][1]] == list(ref["strings"][1])
+        assert torch.equal(xh, ref_rec["x_hat"])
+        for out, mx in pool.roundtrip_many([(x,)] * 5):  # eager, captured, replayed on the pool's side streams
+            assert out["strings"] == ref["strings"] and torch.equal(mx, ref_rec["x_hat"])
+        assert all(n.graph_count() >= 2 for n in pool.nets)
+    assert lib().rgbd_get_blocking_sync() == 0 and pool.nets == []
