@@ -232,6 +232,19 @@ int rgbd_elic_profile_dump(rgbd_elic* m, const char* path);
 /* Measurement hook (bench.py): when on, every convolution launch is bracketed by HIP events on the launch stream.
  * profile_read returns the summed kernel time (ms), the launch count and the algorithmic FLOPs (2*MACs, unpadded)
  * accumulated since set_profile(). */
+/* ---------------------------------------------------------------------------------------------------------------
+ * Harness metric: MS-SSIM statistics on the GPU.
+ * Replaces the pytorch_msssim.ms_ssim call of utils/metrics.py:8-14 (testing/tester_united.py:92-96) -- 11-tap Gaussian
+ * (sigma 1.5) "valid" filtering, SSIM and contrast-structure maps, five dyadic scales with 2x2 average pooling.
+ * x, y: device [P][H][W] fp32 planes (P = N * C, contiguous); out: device [P][5][2] = mean SSIM / mean CS per plane and
+ * scale, combined by the caller (relu, the five weights, product over scales, mean over channels: rgbd_amd/metrics.py).
+ * taps11: the 11 filter taps (host); clamp01: clamp both inputs to [0, 1] first (metrics.py:9-10).  min(H, W) > 160.
+ * workspace: device scratch of at least rgbd_msssim_workspace_bytes(P, H, W) bytes.  Deterministic (no atomics).
+ * ------------------------------------------------------------------------------------------------------------- */
+int64_t rgbd_msssim_workspace_bytes(int32_t P, int32_t H, int32_t W);
+int rgbd_msssim_stats(const float* x, const float* y, int32_t P, int32_t H, int32_t W, const float* taps11, float data_range,
+                      int32_t clamp01, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Bytes of HBM workspace this engine instance holds (grows with the largest call shape seen, never shrinks); the packed
  * weights, shared by all instances of a pool, are not included.  bench.py reports it as config.hbm_workspace_gib. */
 int64_t rgbd_elic_workspace_bytes(const rgbd_elic* m);

@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librgbd_amd.so")
 _SO = os.environ.get("RGBD_AMD_LIB", _SO)  # A/B builds: point at another librgbd_amd.so
-_SRCS = ["conv_mfma.hip", "pointwise.hip", "swin.hip", "entropy.hip", "engine.hip"]
+_SRCS = ["conv_mfma.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "engine.hip"]
 _LIB = None
 
 ERRORS = {-22: "invalid argument", -12: "out of memory", -5: "HIP runtime error", -28: "buffer too small",
@@ -112,6 +112,8 @@ def lib():
         "rgbd_elic_debug_floats": (ctypes.c_int, [c_vp, c_i32, f32p, f32p, c_i64, i64p]),
         "rgbd_elic_graph_count": (ctypes.c_int, [c_vp]),
         "rgbd_elic_workspace_bytes": (c_i64, [c_vp]),
+        "rgbd_msssim_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+        "rgbd_msssim_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, f32p, ctypes.c_float, c_i32, c_vp, c_vp, c_i64, c_vp]),
         "rgbd_debug_force_splitk": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_ckbd": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_fuse": (ctypes.c_int, [c_i32]),
@@ -141,6 +143,6 @@ EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync
            "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
-           "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes",
+           "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats",
            "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]

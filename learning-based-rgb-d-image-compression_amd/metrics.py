@@ -45,9 +45,43 @@ def ms_ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> float:
     return float(ms_ssim_tensor(x, y, data_range).item())
 
 
+def ms_ssim_gpu(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0, clamp01: bool = False) -> torch.Tensor:
+    """MS-SSIM per image of a batch, [N] on the device, through the HIP library (csrc/metrics.hip: one call does the five
+    scales of all N * C planes; the torch form below is ~60 small launches per image enqueued under the GIL, which was
+    most of the pipelined harness's wall time).  Same definition; agrees with the torch form / the fp64 statement to
+    < 2e-5 (tests/test_gpu_harness.py)."""
+    import ctypes
+
+    from ._lib import check, lib
+
+    if min(x.shape[-2:]) <= (11 - 1) * 2 ** 4:
+        raise ValueError("image too small for 5-scale MS-SSIM (needs a side > 160)")
+    x, y = x.float().contiguous(), y.float().contiguous()
+    N, C, H, W = x.shape
+    P = N * C
+    L = lib()
+    nbytes = int(L.rgbd_msssim_workspace_bytes(P, H, W))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty((N, C, 5, 2), dtype=torch.float32, device=x.device)
+    taps = _gauss().numpy()  # (CPU, the same eleven floats the torch form filters with)
+    check(L.rgbd_msssim_stats(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), P, H, W,
+                              taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), float(data_range), 1 if clamp01 else 0,
+                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                              ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "msssim_stats")
+    w = torch.tensor(_MS_WEIGHTS, device=x.device)
+    vals = torch.cat([torch.relu(out[:, :, :4, 1]), torch.relu(out[:, :, 4:, 0])], dim=2)  # cs of scales 0-3, ssim of scale 4
+    return torch.prod(vals ** w, dim=2).mean(dim=1)
+
+
 def ms_ssim_tensor(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
     """The value as a 0-d tensor on x's device (no host synchronisation: the pipelined harness fetches all of an image's
-    metrics with one copy)."""
+    metrics with one copy).  CUDA tensors go through the HIP kernel (ms_ssim_gpu), CPU tensors through the torch form."""
+    if x.is_cuda:
+        return ms_ssim_gpu(x, y, data_range).mean() if x.shape[0] == 1 else _ms_ssim_torch(x, y, data_range)
+    return _ms_ssim_torch(x, y, data_range)
+
+
+def _ms_ssim_torch(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
     if min(x.shape[-2:]) <= (11 - 1) * 2 ** 4:
         raise ValueError("image too small for 5-scale MS-SSIM (needs a side > 160)")
     g = _gauss(device=x.device)
@@ -72,6 +106,19 @@ def compute_metrics(a, b, max_val: float = 1.0):
     except ValueError:
         m = float("nan")
     return p, m
+
+
+def metrics_batch(a, b, max_val: float = 1.0) -> torch.Tensor:
+    """[N, 2] = per image [mse, ms_ssim (nan when the images are too small)] of the clamped tensors on the device: two tensor
+    ops for the mse and ONE library call for MS-SSIM (the pipelined harness: a group of images per call)."""
+    a, b = a.clamp(0, 1), b.clamp(0, 1)
+    mse = torch.stack([torch.mean((a[i:i + 1] - b[i:i + 1]) ** 2) for i in range(a.shape[0])])  # (per image, as psnr() does)
+    try:
+        m = ms_ssim_gpu(a, b, max_val) if a.is_cuda else torch.stack([_ms_ssim_torch(a[i:i + 1].float(), b[i:i + 1].float(), max_val)
+                                                                       for i in range(a.shape[0])])
+    except ValueError:
+        m = torch.full_like(mse, float("nan"))
+    return torch.stack([mse, m], dim=1)
 
 
 def metrics_tensor(a, b, max_val: float = 1.0) -> torch.Tensor:

@@ -18,7 +18,7 @@ from .arch import model_config
 from .datautils import crop0, crop1, pad
 from .elic_united import modelZoo
 from .ioutils import filesize, read_body, read_uints, write_body, write_uints
-from .metrics import AverageMeter, compute_metrics, finish_metrics, metrics_tensor
+from .metrics import AverageMeter, compute_metrics, finish_metrics, metrics_batch
 
 
 def save_image(x, path):
@@ -51,12 +51,6 @@ def load_image(path, mode):
         mx = float(t.max())
         t = t / (10000.0 if 255 < mx < 10000 else (100000.0 if mx > 10000 else 255.0))
     return t
-
-
-# MS-SSIM's Gaussian filters are torch convolutions, i.e. MIOpen: its first use of a configuration (kernel search / compile)
-# from several threads at once does not come back (seen with four workers' first images, round 4).  The enqueue of an image's
-# metric kernels (~3 ms of host time; they run asynchronously on the worker's stream) is therefore serialised.
-_METRICS_LOCK = threading.Lock()
 
 
 class ImageFolderUnited:
@@ -310,9 +304,11 @@ class TesterUnited:
                         ts = tick(w, "decompress", ts)
                         cropper = crop0 if padding_mode.find("0") != -1 else crop1
                         xr, xd = cropper(rec["x_hat"]["r"], original_size), cropper(rec["x_hat"]["d"], original_size)
-                        with _METRICS_LOCK:
-                            mt = torch.stack([torch.cat([metrics_tensor(xr[j:j + 1], rgb[j:j + 1]),
-                                                         metrics_tensor(xd[j:j + 1], depth[j:j + 1])]) for j in range(k)])
+                        # [k, 4] = mse, MS-SSIM of rgb then depth: two tensor ops and one library call per modality for the group
+                        # (MS-SSIM used to be ~60 torch launches per image and modality -- MIOpen convolutions, whose first
+                        # use from several threads at once did not come back, and whose enqueue under the GIL was most of
+                        # the wall time with 8 - 16 workers)
+                        mt = torch.cat([metrics_batch(xr, rgb), metrics_batch(xd, depth)], dim=1)
                         if save:  # utils/IOutils.py:101-104, tester_united.py:98-109: the conversions on the GPU, the encoding in a writer
                             r8 = xr.clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).contiguous().cpu().numpy()
                             d8 = xd.clamp(0, 1).mul(255).byte()[:, 0].contiguous().cpu().numpy()

@@ -157,6 +157,40 @@ def test_tester_united_images_in_flight(net, tmp_path, monkeypatch):
     assert m0["avg_rgb_bpp"].avg == m1["avg_rgb_bpp"].avg and m0["avg_depth_psnr"].avg == m1["avg_depth_psnr"].avg
 
 
+def test_ms_ssim_kernel_against_the_definition():
+    """csrc/metrics.hip (one call: five scales of all planes of a batch) against the torch restatement on the CPU and the
+    independent fp64 statement of the published definition (oracle/msssim_ref.py): even and odd sizes (the pooling pads odd
+    sides), three- and one-channel images, a batch, values outside [0, 1] with the clamp the harness applies."""
+    import numpy as np
+
+    from oracle import msssim_ref
+    from rgbd_amd import metrics, synth
+
+    require_gpu()
+    for (n, ch, h, w, cid, noise) in ((1, 3, 176, 208, 3, 0.05), (2, 1, 161, 193, 4, 0.2), (3, 3, 480, 640, 5, 0.02), (1, 1, 163, 400, 6, 0.4)):
+        xs, ys = [], []
+        for i in range(n):
+            r, d = synth.synthetic_pair(cid + i, h, w, config_id=cid, smooth=True)
+            a = torch.from_numpy(r if ch == 3 else d)[None].float()
+            rng = np.random.RandomState(cid + i)
+            xs.append(a)
+            ys.append(a + noise * torch.from_numpy(rng.standard_normal(a.shape).astype(np.float32)))  # (leaves [0, 1])
+        x, y = torch.cat(xs), torch.cat(ys)
+        got = metrics.ms_ssim_gpu(x.cuda(), y.cuda(), 1.0, clamp01=True).cpu()
+        xc, yc = x.clamp(0, 1), y.clamp(0, 1)
+        for i in range(n):
+            want_t = float(metrics._ms_ssim_torch(xc[i:i + 1], yc[i:i + 1], 1.0))
+            want_64 = msssim_ref.ms_ssim(xc[i:i + 1].numpy(), yc[i:i + 1].numpy(), 1.0)
+            assert abs(float(got[i]) - want_t) < 2e-5 and abs(float(got[i]) - want_64) < 2e-5, (n, ch, h, w, i, float(got[i]), want_t, want_64)
+        # compute_metrics() on device tensors takes the same kernel (one image), and metrics_batch() the batch
+        p, m = metrics.compute_metrics(y[:1].cuda(), x[:1].cuda())
+        assert abs(m - float(got[0])) < 1e-6
+        mb = metrics.metrics_batch(y.cuda(), x.cuda()).cpu()
+        assert torch.allclose(mb[:, 1], got, atol=1e-6) and abs(metrics.finish_metrics(float(mb[0, 0]), 0.0)[0] - p) < 1e-9
+    with pytest.raises(ValueError):
+        metrics.ms_ssim_gpu(torch.zeros(1, 3, 160, 300).cuda(), torch.zeros(1, 3, 160, 300).cuda())
+
+
 def test_pool_matches_single_instance(net, synth_sd):
     import rgbd_amd
     from rgbd_amd import synth
