@@ -1120,6 +1120,43 @@ struct rgbd_elic {
         return cp.y;
     }
 
+    // A stride-1 k x k conv whose INPUT is non-zero at the anchor positions only ((row + col) odd: the slice right after its
+    // anchor pass, utils/ckbd.py:37-48 -- what the local-context convs read, elic_united.py:296,309).  An output pixel of
+    // parity q then only meets non-zero inputs under the taps with (dy + dx) & 1 == 1 - q: the anchor outputs need the 13
+    // taps with dy + dx even, the other outputs the 12 with dy + dx odd.  Two checkerboard-output launches (ConvArgs::ckbd
+    // 1 / 2), each with its half of the tap table: half the MFMA work, and every output keeps its fma chain minus terms
+    // that are exact zeros (round 4; RGBD_NO_ANCHOR_TAPS=1 runs the full conv).  Worth it for the 192-channel slice only
+    // (368 -> 255 us at c3); at 64 channels two launches cost more than the taps they save (71 -> 86 us).
+    void conv_anchor_in(const std::string& name, const Act& x, int pad, const Act& dst)
+    {
+        static const bool off = getenv("RGBD_NO_ANCHOR_TAPS") != nullptr;
+        ConvPlan cp = conv_plan(name, x, 1, pad, Epi(), &dst);
+        if (off || g_force_ckbd || x.c < 128 || (!dry() && (!cp.ok || cp.a.nphase != 1 || cp.a.IS != 1 || cp.a.subpix))) {
+            conv_issue(cp);
+            return;
+        }
+        for (int par = 1; par <= 2; ++par) {
+            ConvPlan h = cp;
+            if (!dry()) {
+                TapTable& t = h.a.taps;
+                int n = 0;
+                for (int k = 0; k < cp.a.taps.n[0]; ++k) {
+                    const int odd = (cp.a.taps.dy[0][k] + cp.a.taps.dx[0][k]) & 1;
+                    if (odd != (par == 1 ? 0 : 1)) continue;  // anchor outputs (parity 1): dy + dx even
+                    t.dy[0][n] = cp.a.taps.dy[0][k];
+                    t.dx[0][n] = cp.a.taps.dx[0][k];
+                    t.wt[0][n] = cp.a.taps.wt[0][k];
+                    ++n;
+                }
+                for (int k = n; k < 25; ++k) t.dy[0][k] = t.dx[0][k] = t.wt[0][k] = 0;
+                t.n[0] = (int8_t)n;
+                h.a.ckbd = par;
+                h.flops = cp.flops * 0.5;
+            }
+            conv_issue(h);
+        }
+    }
+
     // The same layer kind for both modalities (names n[0] / n[1]: RGB / depth branch): one grouped launch when the two
     // plans agree in every shape, otherwise (first / last image-facing layers: 3 vs 1 channels) two launches.
     void conv2(const std::string n[2], const Act x[2], int stride, int pad, const Epi ep[2], const Act* const dst[2], Act out[2],
@@ -2013,7 +2050,7 @@ struct rgbd_elic {
             Act p_ra = entropy_params("rgb_entropy_parameters_anchor." + si, view(ctx, 4 * C, wide - 4 * C), 1, nullptr,
                                       smc ? smc + 4 * C : nullptr, wide);
             code_part(cd, 0, 1, p_ra, yr, hr, part_off);
-            conv("rgb_local_context." + si, hr, 1, 2, Epi(), &r_loc);
+            conv_anchor_in("rgb_local_context." + si, hr, 2, r_loc);  // (hr holds the anchor half only so far)
             means_of(r_loc, sm, wide);
             // depth anchor: [r_loc, hyper, ch ctx] -- d_loc's slot sits between them, so this one input is gathered
             Act p_da = alloc(hyp_r.n, h, w, 2 * C);
@@ -2032,7 +2069,7 @@ struct rgbd_elic {
                 arena.top = m2;
             }
             code_part(cd, 1, 1, p_da, yd, hd, part_off);
-            conv("depth_local_context." + si, hd, 1, 2, Epi(), &d_loc);
+            conv_anchor_in("depth_local_context." + si, hd, 2, d_loc);
             means_of(d_loc, sm + 2 * C, wide);
             // rgb non-anchor: the whole buffer
             Act p_rn = entropy_params("rgb_entropy_parameters_nonanchor." + si, ctx, 2, nullptr, smc, wide);
