@@ -3,7 +3,7 @@
 stage depth / staging mode for each distinct shape (kernel-only, rgbd_conv_bench) and writes the winners to
 csrc/tile_table.h (a pure performance database: tile choice never changes results).
 
-    python tools/tune_tiles.py [--write] [--only-ckbd] [--model STF_united] B,H,W [B,H,W ...]
+    python tools/tune_tiles.py [--write] [--only-ckbd] [--only-1x1] [--streams S] [--model STF_united] B,H,W [B,H,W ...]
                                                       (default: 8,256,256 4,512,640 1,256,256 1,512,640, ELIC_united)
 Entries already in tile_table.h for other shapes are kept (the table is merged, not rebuilt).
 """
@@ -32,6 +32,7 @@ if "--streams" in argv:
 args = [a for a in argv if not a.startswith("--")]
 WRITE = "--write" in sys.argv
 ONLY_CKBD = "--only-ckbd" in sys.argv  # only the checkerboard-output launches (key field nphase >= 10)
+ONLY_1X1 = "--only-1x1" in sys.argv    # only the single-tap layers (the ring staging modes 4 / 5 apply to them)
 WORKLOADS = [tuple(int(v) for v in a.split(",")) for a in args] or [(8, 256, 256), (4, 512, 640), (1, 256, 256), (1, 512, 640)]
 L = lib()
 L.rgbd_debug_bench_streams(STREAMS)
@@ -81,6 +82,8 @@ for B, H, W in WORKLOADS:
     for row in rows:
         key, cnt = row[:9], row[9]
         if ONLY_CKBD and key[7] < 10:
+            continue
+        if ONLY_1X1 and key[5] != 1:
             continue
         measured.add(key)
         L.rgbd_debug_force_splitk(key[8])
