@@ -245,6 +245,17 @@ int64_t rgbd_msssim_workspace_bytes(int32_t P, int32_t H, int32_t W);
 int rgbd_msssim_stats(const float* x, const float* y, int32_t P, int32_t H, int32_t W, const float* taps11, float data_range,
                       int32_t clamp01, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * STF_united operator: nn.LayerNorm(C, eps = 1e-5) over the channels of a token (models/stf_united.py:143,155,225,263,
+ * 387-391).  x: device [ntok][xcs] fp32 (the first C of xcs channels are the token), w / b: device [C], y: device
+ * [ntok][ycs] (channels C .. ycs - 1 are zeroed).  Biased variance, two passes, fixed summation tree.
+ * rgbd_debug_force_layernorm_form: -1 by shape (default), 0 one wavefront per token, 1 sixteen lanes per token (C % 4 == 0)
+ * -- the two forms are bit-identical (tests).
+ * ------------------------------------------------------------------------------------------------------------- */
+int rgbd_layernorm(const float* x, int64_t ntok, int32_t C, int32_t xcs, const float* w, const float* b, float* y, int32_t ycs,
+                   void* stream);
+void rgbd_debug_force_layernorm_form(int32_t form);
+
 /* Bytes of HBM workspace this engine instance holds (grows with the largest call shape seen, never shrinks); the packed
  * weights, shared by all instances of a pool, are not included.  bench.py reports it as config.hbm_workspace_gib. */
 int64_t rgbd_elic_workspace_bytes(const rgbd_elic* m);

@@ -118,6 +118,8 @@ def lib():
         "rgbd_debug_force_ckbd": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_fuse": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_subpix": (ctypes.c_int, [c_i32]),
+        "rgbd_layernorm": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+        "rgbd_debug_force_layernorm_form": (None, [c_i32]),
         "rgbd_debug_force_pair": (ctypes.c_int, [c_i32]),
         "rgbd_debug_fail_captures": (ctypes.c_int, [c_i32]),
         "rgbd_debug_bench_streams": (ctypes.c_int, [c_i32]),
@@ -143,6 +145,17 @@ EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync
            "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
-           "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats",
+           "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats", "rgbd_layernorm", "rgbd_debug_force_layernorm_form",
            "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]
+
+
+def set_blocking_sync(on: bool) -> None:
+    """Switch the wait policy of this process's GPU (hipDeviceScheduleBlockingSync on / off) at a clean point: engine
+    instances that are already garbage are destroyed FIRST -- under the policy they ran with -- and the library drains the
+    device before the flag changes.  (An engine that had run under the spinning policy and was garbage-collected right
+    after a CodecPool had switched to the blocking one is what the round-4 `hipFree never returns` record shows.)"""
+    import gc
+
+    gc.collect()
+    check(lib().rgbd_set_blocking_sync(1 if on else 0), "set_blocking_sync")

@@ -176,8 +176,6 @@ int launch_channel_scale_to_strided(const float* x, int N, int HW, int xcs, int 
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
                  float* scale, hipStream_t s, int mstride = 0);
 // mode 0: y = x*s ; mode 1: y = x + x*s   (s per (n, c))
-int launch_channel_scale(const float* x, int N, int HW, int cs, int C, const float* scale, int mode, float* y,
-                         hipStream_t s);
 int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const float* scale, int mode, float* y, int ycs,
                             hipStream_t s);
 int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s);

@@ -382,9 +382,9 @@ struct HangWatch {
     std::mutex mu;
     std::condition_variable cv;
     bool done = false;
-    HangWatch(const char* what, int secs)
+    HangWatch(const char* what, int secs, bool always = false)
     {
-        if (!g_dbg_destroy) return;
+        if (!g_dbg_destroy && !always) return;
         th = std::thread([this, what, secs] {
             std::unique_lock<std::mutex> lk(mu);
             if (cv.wait_for(lk, std::chrono::seconds(secs), [this] { return done; })) return;
@@ -1628,33 +1628,44 @@ struct rgbd_elic {
         arena.top = mark;
     }
 
-    // modules/transform/attention.py:63-67 -- returns the per-(n,c) sigmoid weights
-    // means / mstride: the channel means of x when somebody holds them already (Bi-CEE: SliceMeans), else they are computed
-    float* se_weights(const std::string& p, const Act& x, const float* means = nullptr, int mstride = 0)
+    // modules/transform/attention.py:63-67: y = x * g (mode 0) or x + x * g (mode 1), g = the per-(n,c) sigmoid weights of x
+    // means / mstride: the channel means of x when somebody holds them already (Bi-CEE: SliceMeans), else they are computed.
+    void se_scale_to(const std::string& p, const Act& x, int mode, const Act& y, const float* means = nullptr, int mstride = 0)
     {
         float* w0 = dense_of(p + ".fc.0.weight");
         float* w1 = dense_of(p + ".fc.2.weight");
         float* mean = means ? nullptr : (float*)arena.take((size_t)x.n * x.c * sizeof(float));
         float* sc = (float*)arena.take((size_t)x.n * x.c * sizeof(float));
         float* hid = (float*)arena.take((size_t)x.n * (x.c / 16 + 1) * sizeof(float));
-        if (dry() || rc || !w0 || !w1) return sc;
-        int r = means ? RGBD_OK : launch_channel_mean(x.p, x.n, x.h * x.w, x.cs, x.c, mean, s);
-        if (!r) r = launch_se_fc(means ? means : mean, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0);
-        if (r) fail(r);
-        return sc;
-    }
-
-    void scale_inplace(const Act& x, const float* sc, int mode)
-    {
-        if (dry() || rc) return;
-        const int r = launch_channel_scale(x.p, x.n, x.h * x.w, x.cs, x.c, sc, mode, x.p, s);
+        if (dry() || rc || !w0 || !w1) return;
+        const int HW = x.h * x.w;
+        int r = means ? RGBD_OK : launch_channel_mean(x.p, x.n, HW, x.cs, x.c, mean, s);
+        const float* mu = means ? means : mean;
+        if (!r) r = launch_se_fc(mu, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0);
+        if (!r) r = launch_channel_scale_to(x.p, x.n, HW, x.cs, x.c, sc, mode, y.p, y.cs, s);
         if (r) fail(r);
     }
 
-    void scale_to(const Act& x, const float* sc, int mode, const Act& y)
+    // the SE of cat(own, other) written into the two halves of f (synthesis.py:345-362): means side by side, one gate
+    void se_cat_to(const std::string& p, const Act& own, const Act& other, const Act& f)
     {
-        if (dry() || rc) return;
-        const int r = launch_channel_scale_to(x.p, x.n, x.h * x.w, x.cs, x.c, sc, mode, y.p, y.cs, s);
+        const int C = own.c + other.c;
+        float* w0 = dense_of(p + ".fc.0.weight");
+        float* w1 = dense_of(p + ".fc.2.weight");
+        float* mean = (float*)arena.take((size_t)own.n * C * sizeof(float));
+        float* sc = (float*)arena.take((size_t)own.n * C * sizeof(float));
+        float* hid = (float*)arena.take((size_t)own.n * (C / 16 + 1) * sizeof(float));
+        if (C % 16 || own.c % 4) {
+            fail(RGBD_EINVAL);
+            return;
+        }
+        if (dry() || rc || !w0 || !w1) return;
+        const int HW = own.h * own.w;
+        int r = launch_channel_mean_strided(own.p, own.n, HW, own.cs, own.c, mean, C, s);
+        if (!r) r = launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
+        if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s);
+        if (!r) r = launch_channel_scale_to_strided(own.p, own.n, HW, own.cs, own.c, sc, C, 0, f.p, f.cs, s);
+        if (!r) r = launch_channel_scale_to_strided(other.p, other.n, HW, other.cs, other.c, sc + own.c, C, 0, f.p + own.c, f.cs, s);
         if (r) fail(r);
     }
 
@@ -1798,26 +1809,8 @@ struct rgbd_elic {
     // gate is computed from them, and each input is scaled straight into its half of the deconv's input buffer
     Act hs_block(const std::string& p, const Act& own, const Act& other, bool last)
     {
-        const int C = own.c + other.c;
-        Act f = alloc(own.n, own.h, own.w, C);
-        float* w0 = dense_of(p + ".se.fc.0.weight");
-        float* w1 = dense_of(p + ".se.fc.2.weight");
-        float* mean = (float*)arena.take((size_t)own.n * C * sizeof(float));
-        float* sc = (float*)arena.take((size_t)own.n * C * sizeof(float));
-        float* hid = (float*)arena.take((size_t)own.n * (C / 16 + 1) * sizeof(float));
-        if (C % 16 || own.c % 4) {
-            fail(RGBD_EINVAL);
-            return f;
-        }
-        if (!dry() && !rc && w0 && w1) {
-            const int HW = own.h * own.w;
-            int r = launch_channel_mean_strided(own.p, own.n, HW, own.cs, own.c, mean, C, s);
-            if (!r) r = launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
-            if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s);
-            if (!r) r = launch_channel_scale_to_strided(own.p, own.n, HW, own.cs, own.c, sc, C, 0, f.p, f.cs, s);
-            if (!r) r = launch_channel_scale_to_strided(other.p, other.n, HW, other.cs, other.c, sc + own.c, C, 0, f.p + own.c, f.cs, s);
-            if (r) fail(r);
-        }
+        Act f = alloc(own.n, own.h, own.w, own.c + other.c);
+        se_cat_to(p + ".se", own, other, f);
         Epi e;
         e.act = last ? ACT_NONE : ACT_LEAKY;
         return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
@@ -1828,28 +1821,9 @@ struct rgbd_elic {
     {
         Act f[2];
         for (int m = 0; m < 2; ++m) {
-            const int C = own[m].c + other[m].c;
-            f[m] = alloc(own[m].n, own[m].h, own[m].w, C);
-            float* w0 = dense_of(p[m] + ".se.fc.0.weight");
-            float* w1 = dense_of(p[m] + ".se.fc.2.weight");
-            float* mean = (float*)arena.take((size_t)own[m].n * C * sizeof(float));
-            float* sc = (float*)arena.take((size_t)own[m].n * C * sizeof(float));
-            float* hid = (float*)arena.take((size_t)own[m].n * (C / 16 + 1) * sizeof(float));
-            if (C % 16 || own[m].c % 4) {
-                fail(RGBD_EINVAL);
-                return;
-            }
-            if (!dry() && !rc && w0 && w1) {
-                const int HW = own[m].h * own[m].w;
-                int r = launch_channel_mean_strided(own[m].p, own[m].n, HW, own[m].cs, own[m].c, mean, C, s);
-                if (!r) r = launch_channel_mean_strided(other[m].p, other[m].n, HW, other[m].cs, other[m].c, mean + own[m].c, C, s);
-                if (!r) r = launch_se_fc(mean, own[m].n, C, C / 16, w0, w1, hid, sc, s);
-                if (!r) r = launch_channel_scale_to_strided(own[m].p, own[m].n, HW, own[m].cs, own[m].c, sc, C, 0, f[m].p, f[m].cs, s);
-                if (!r)
-                    r = launch_channel_scale_to_strided(other[m].p, other[m].n, HW, other[m].cs, other[m].c, sc + own[m].c, C, 0,
-                                                        f[m].p + own[m].c, f[m].cs, s);
-                if (r) fail(r);
-            }
+            f[m] = alloc(own[m].n, own[m].h, own[m].w, own[m].c + other[m].c);
+            se_cat_to(p[m] + ".se", own[m], other[m], f[m]);
+            if (rc) return;
         }
         Epi e[2];
         e[0].act = e[1].act = last ? ACT_NONE : ACT_LEAKY;
@@ -1887,8 +1861,7 @@ struct rgbd_elic {
         Act out = dst ? *dst : alloc(ctx.n, ctx.h, ctx.w, last->cout);
         const size_t mark = arena.top;
         Act cat = alloc(ctx.n, ctx.h, ctx.w, ctx.c);
-        float* sc = se_weights(p + ".se", ctx, means, mstride);
-        scale_to(ctx, sc, 1, cat);
+        se_scale_to(p + ".se", ctx, 1, cat, means, mstride);
         Epi relu;
         relu.act = ACT_RELU;
         Act t = conv(p + ".fusion.0", cat, 1, 0, relu);
@@ -2335,8 +2308,7 @@ struct rgbd_elic {
     Act hs_block_single(const std::string& p, const Act& x, bool last)
     {
         Act f = alloc(x.n, x.h, x.w, x.c);
-        float* sc = se_weights(p + ".se", x);
-        scale_to(x, sc, 0, f);
+        se_scale_to(p + ".se", x, 0, f);
         Epi e;
         e.act = last ? ACT_NONE : ACT_LEAKY;
         return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
@@ -3401,8 +3373,15 @@ extern "C" {
 int rgbd_abi_version(void) { return RGBD_AMD_ABI_VERSION; }
 
 // Host threads that wait for the GPU sleep instead of spinning (hipDeviceScheduleBlockingSync for the current device).
+// The policy is a device flag of the process.  Work submitted under one policy and awaited under the other is what the two
+// "hipFree never returns" records have in common (profiles/r03_hang_diagnosis.txt; round 4: an engine that had run under
+// the spinning policy was garbage-collected -- rgbd_elic_destroy -> hipFree -> every stream of the device -- right after a
+// CodecPool had switched the policy): so the device is drained under the OLD policy before the flag changes, and the Python
+// side collects garbage engines first (pool.py).  (Measured and dropped: switching to the spinning policy around every
+// hipFree -- with a pool's other threads launching in that window it produced exactly such mixed waits, and the suite hung.)
 int rgbd_set_blocking_sync(int32_t on)
 {
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto));
     return RGBD_OK;
 }
@@ -4074,7 +4053,7 @@ void rgbd_elic_destroy(rgbd_elic* m)
         g_live_streams.erase(m);
     }
     {
-        HangWatch w("hipFree(arena) in rgbd_elic_destroy", 20);
+        HangWatch w("hipFree(arena) in rgbd_elic_destroy", 20, true);
         if (m->arena.base) (void)hipFree(m->arena.base);
     }
     if (dbg) fprintf(stderr, "[destroy %p] arena freed\n", (void*)m);

@@ -236,46 +236,19 @@ __global__ void se_gate_kernel(const float* __restrict__ hid, int C, int hidden,
     scale[n * C + c] = 1.0f / (1.0f + expf(-s));
 }
 
-// (A single-launch variant -- every workgroup recomputing the hidden layer into LDS, then gating its channels -- was built
-// and measured: at B = 1 the 4 waves of a workgroup walk 44 hidden units each, one memory round trip after the other, and
-// an SE gate took ~100 us instead of 2 x 14 us; the two-launch form below stays.)
+// (Single-launch variants were built and measured twice.  Round 2: every workgroup recomputing the hidden layer into LDS, then
+// gating its channels -- at B = 1 the 4 waves of a workgroup walk 44 hidden units each, one memory round trip after the
+// other: ~100 us instead of 2 x 14 us.  Round 4: hidden layer + gate + rescale in one launch behind the means (eight waves,
+// two units in flight each; bit-identical): the entropy-parameter nets' SE blocks have 1280 ... 2816 channels, so every one
+// of the ~1,000 workgroups that rescale a tensor re-reads up to 2 MB of fc.0 weights -- 62.3 vs 56.6 ms per c3 step on the
+// same box.  Each SE stage reduces over a different axis (pixels, channels, hidden units, then back out); fusing
+// neighbours trades a ~4 us launch for recomputation that costs more.  The launches below stay.)
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
                  float* scale, hipStream_t s, int mstride)
 {
     hipLaunchKernelGGL(se_hidden_kernel, dim3(hidden, N), dim3(64), 0, s, mean, C, hidden, w0, hid, mstride > 0 ? mstride : C);
     hipLaunchKernelGGL(se_gate_kernel, dim3((C + 255) / 256, N), dim3(256), (size_t)hidden * sizeof(float), s, hid, C,
                        hidden, w1t, scale);
-    HIP_TRY(hipGetLastError());
-    return RGBD_OK;
-}
-
-__global__ void channel_scale_kernel(const float* __restrict__ x, int HW, int cs, int C, const float* __restrict__ scale,
-                                     int mode, float* __restrict__ y, size_t total4)
-{
-    const int c4n = cs / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        const size_t pix = i / c4n;
-        const size_t n = pix / HW;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * cs + c4 * 4);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c4 * 4 + e;
-            const float sc = c < C ? scale[n * C + c] : 0.f;
-            const float t = __fmul_rn(v[e], sc);
-            o[e] = mode ? __fadd_rn(v[e], t) : t;
-        }
-        *reinterpret_cast<f32x4*>(y + pix * cs + c4 * 4) = o;
-    }
-}
-
-int launch_channel_scale(const float* x, int N, int HW, int cs, int C, const float* scale, int mode, float* y,
-                         hipStream_t s)
-{
-    const size_t total4 = (size_t)N * HW * (cs / 4);
-    hipLaunchKernelGGL(channel_scale_kernel, dim3(grid_for(total4)), dim3(256), 0, s, x, HW, cs, C, scale, mode, y,
-                       total4);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnSet s0, LnSet s1, size
         for (int k = 0; k < 24; ++k) {
             const int c = lane + 64 * k;
             const float d = c < C ? v[k] - mean : 0.f;
-            sq += d * d;
+            sq = __fmaf_rn(d, d, sq);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -54,22 +54,120 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnSet s0, LnSet s1, size
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
             const int c = lane + 64 * k;
-            if (c < C) yp[c] = (v[k] - mean) * rstd * w[c] + b[c];
+            if (c < C) yp[c] = __fmaf_rn(__fmul_rn(v[k] - mean, rstd), w[c], b[c]);
             else if (c < ycs) yp[c] = 0.f;
         }
     }
 }
 
+// The same LayerNorm with 16 lanes per token and one float4 per lane and pass of 64 channels (lane i of a token's 16 holds
+// channels 64 r + 4 i .. + 3 in pass r): a wave covers four tokens with 256-byte contiguous segments per load instead of one
+// token with 4-byte lanes, and runs ceil(C / 64) passes instead of 24 predicated ones -- the one-wave-per-token form above
+// reached 0.7 TB/s on STF_united's 48- and 96-channel stages (profiles/r04_c5_stf_4x512x512_w1_summary.txt: the largest
+// kernel of config 5 after the coder).  SAME sums: the leaf of channel c0 < 64 is x[c0] + x[c0 + 64] + ... in order, and the
+// xor-butterfly over lanes 32, 16, 8, 4, 2, 1 of the form above is, in this layout, lanes ^8, ^4, ^2, ^1 and then the
+// components (0 + 2) + (1 + 3) -- bit-identical (tests/test_gpu_stf.py::test_layernorm_forms_same_bits).  C % 4 == 0.
+template <int R>
+__global__ __launch_bounds__(256) void layernorm4_kernel(LnSet s0, LnSet s1, size_t ntok, int C, int xcs, int ycs)
+{
+    const LnSet st = blockIdx.y ? s1 : s0;
+    const float* __restrict__ x = st.x;
+    const float* __restrict__ w = st.w;
+    const float* __restrict__ b = st.b;
+    float* __restrict__ y = st.y;
+    const int sub = threadIdx.x & 15;
+    const size_t grp = (blockIdx.x * (size_t)256 + threadIdx.x) >> 4;
+    const size_t ngrp = (size_t)gridDim.x * 16;
+    const float fc = (float)C;
+    for (size_t t = grp; t < ntok; t += ngrp) {
+        const float* xp = x + t * xcs;
+        f32x4 v[R];
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c = 64 * r + 4 * sub;
+            v[r] = c < C ? *reinterpret_cast<const f32x4*>(xp + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += v[r][j];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], o);
+        const float mean = ((s[0] + s[2]) + (s[1] + s[3])) / fc;
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c = 64 * r + 4 * sub;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = c < C ? v[r][j] - mean : 0.f;
+                q[j] = __fmaf_rn(d, d, q[j]);  // (explicit: left to the compiler, a lone product fuses with the tree's first add)
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = __fadd_rn(q[j], __shfl_xor(q[j], o));
+        const float sq = __fadd_rn(__fadd_rn(q[0], q[2]), __fadd_rn(q[1], q[3]));
+        const float rstd = 1.0f / sqrtf(sq / fc + 1e-5f);
+        float* yp = y + t * ycs;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c = 64 * r + 4 * sub;
+            if (c < C) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __fmaf_rn(__fmul_rn(v[r][j] - mean, rstd), wv[j], bv[j]);
+                *reinterpret_cast<f32x4*>(yp + c) = o;
+            } else if (c < ycs) {
+                *reinterpret_cast<f32x4*>(yp + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+static int g_ln_form = -1;  // -1: by shape; 0: one wave per token; 1: 16 lanes per token (tests)
+extern "C" void rgbd_debug_force_layernorm_form(int32_t form) { g_ln_form = form; }
+
 int launch_layernorm(const float* x, size_t ntok, int C, int xcs, const float* w, const float* b, float* y, int ycs,
                      hipStream_t s, const float* x1, const float* w1, const float* b1, float* y1)
 {
     if (C > 1536 || ycs > 1536 || C <= 0) return RGBD_EINVAL;
+    const LnSet s0{x, w, b, y}, s1{x1, w1, b1, y1};
+    const auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec_ok = C % 4 == 0 && xcs % 4 == 0 && ycs % 4 == 0 && al16(x) && al16(w) && al16(b) && al16(y) &&
+                        (!x1 || (al16(x1) && al16(w1) && al16(b1) && al16(y1)));
+    if (g_ln_form == 1 && !vec_ok) return RGBD_EINVAL;
+    if (vec_ok && g_ln_form != 0) {
+        const int passes = (std::max(C, ycs) + 63) / 64;  // (the zero fill of y's pad channels rides on the passes too)
+        size_t g = (ntok + 15) / 16;
+        if (g > 8192) g = 8192;
+        const dim3 grid((unsigned)g, x1 ? 2 : 1);
+#define RGBD_LN4(R_)                                                                                          \
+    if (passes <= R_) {                                                                                       \
+        hipLaunchKernelGGL(layernorm4_kernel<R_>, grid, dim3(256), 0, s, s0, s1, ntok, C, xcs, ycs);          \
+        HIP_TRY(hipGetLastError());                                                                           \
+        return RGBD_OK;                                                                                       \
+    }
+        RGBD_LN4(1) RGBD_LN4(2) RGBD_LN4(3) RGBD_LN4(4) RGBD_LN4(6) RGBD_LN4(8) RGBD_LN4(12) RGBD_LN4(16) RGBD_LN4(24)
+#undef RGBD_LN4
+    }
     size_t g = (ntok + 3) / 4;
     if (g > 4096) g = 4096;
-    const LnSet s0{x, w, b, y}, s1{x1, w1, b1, y1};
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)g, x1 ? 2 : 1), dim3(256), 0, s, s0, s1, ntok, C, xcs, ycs);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
+}
+
+// Stand-alone LayerNorm over the last dimension of a [ntok][xcs] fp32 device tensor (nn.LayerNorm(C, eps = 1e-5),
+// stf_united.py:143,155,225,263,387-391) -- the operator boundary the tests use.
+extern "C" int rgbd_layernorm(const float* x, int64_t ntok, int32_t C, int32_t xcs, const float* w, const float* b, float* y,
+                              int32_t ycs, void* stream)
+{
+    if (!x || !w || !b || !y || ntok <= 0 || xcs < C || ycs < C) return RGBD_EINVAL;
+    return launch_layernorm(x, (size_t)ntok, C, xcs, w, b, y, ycs, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

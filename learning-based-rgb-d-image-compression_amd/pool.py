@@ -45,10 +45,10 @@ class CodecPool:
         # GPU, also outside the pool (a B = 1 latency pass in the same process runs under it: ~1 of 190 ms), until close().
         self._blocking_sync = False
         if workers > 1 and os.environ.get("RGBD_BLOCKING_SYNC", "1") != "0":
-            from ._lib import check, lib
+            from ._lib import set_blocking_sync
 
             torch.cuda.set_device(self.device)
-            check(lib().rgbd_set_blocking_sync(1), "set_blocking_sync")
+            set_blocking_sync(True)
             self._blocking_sync = True
         for i in range(workers):
             if i == 0:
@@ -88,10 +88,10 @@ class CodecPool:
         """Drop the engine instances and give the device back its default (spinning) wait policy."""
         self.nets, self.streams = [], []
         if self._blocking_sync:
-            from ._lib import check, lib
+            from ._lib import set_blocking_sync
 
             torch.cuda.set_device(self.device)
-            check(lib().rgbd_set_blocking_sync(0), "set_blocking_sync")
+            set_blocking_sync(False)  # (the instances dropped above are destroyed by now: under the policy they ran with)
             self._blocking_sync = False
 
     def _split(self, B):

@@ -209,9 +209,9 @@ class TesterUnited:
         nets = pool[:W]
         blocking = W > 1 and os.environ.get("RGBD_BLOCKING_SYNC", "1") != "0"  # W host threads wait on W streams: sleep, do not spin
         if blocking:
-            from ._lib import check, lib
+            from ._lib import set_blocking_sync
 
-            check(lib().rgbd_set_blocking_sync(1), "set_blocking_sync")
+            set_blocking_sync(True)
         was_per_image = self.net.per_image_streams
         for nt in nets:
             nt.per_image_streams = True
@@ -349,9 +349,9 @@ class TesterUnited:
         if W >= 4:
             self.net.set_tile_mode("latency")
         if blocking:
-            from ._lib import check, lib
+            from ._lib import set_blocking_sync
 
-            check(lib().rgbd_set_blocking_sync(0), "set_blocking_sync")
+            set_blocking_sync(False)
         for e in errs + [werr]:
             if e is not None:
                 raise e

@@ -52,4 +52,4 @@ def pytest_collection_modifyitems(config, items):
     one (method "thread": a wait inside the HIP runtime never returns to the interpreter, so a signal would not fire)."""
     for it in items:
         if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
-            it.add_marker(pytest.mark.timeout(420, method="thread"))
+            it.add_marker(pytest.mark.timeout(300, method="thread"))

@@ -130,3 +130,34 @@ def test_config5_full_size_512(net5, orc5):
     assert torch.equal(fw["x_hat"]["r"].clamp(0, 1), rec["x_hat"]["r"]) and torch.equal(fw["x_hat"]["d"].clamp(0, 1), rec["x_hat"]["d"])
     bpp = sum(len(s) for k in ("r_strings", "d_strings") for lst in out[k] for s in lst) * 8.0 / (512 * 512)
     assert np.isfinite(bpp) and bpp > 0
+
+
+@pytest.mark.parametrize("C,xcs,ycs", [(48, 48, 48), (48, 48, 64), (96, 96, 96), (192, 192, 192), (384, 384, 384),
+                                       (768, 768, 768), (20, 32, 32), (1536, 1536, 1536)])
+def test_layernorm_forms_same_bits(C, xcs, ycs):
+    """nn.LayerNorm (stf_united.py:143,155): the 16-lanes-per-token kernel and the one-wave-per-token kernel produce the same
+    bits (same leaves, same tree), both within fp32 rounding of torch's LayerNorm; pad channels of y are zeroed."""
+    require_gpu()
+    from rgbd_amd import _lib
+
+    L = _lib.lib()
+    ntok = 1003
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(ntok, xcs, generator=g) * 3 + torch.randn(ntok, 1, generator=g) * 5).cuda()
+    w, b = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    ys = []
+    try:
+        for form in (0, 1):
+            L.rgbd_debug_force_layernorm_form(form)
+            y = torch.full((ntok, ycs), 7.0, device="cuda")
+            rc = L.rgbd_layernorm(x.data_ptr(), ntok, C, xcs, w.data_ptr(), b.data_ptr(), y.data_ptr(), ycs,
+                                  torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+            ys.append(y.cpu())
+    finally:
+        L.rgbd_debug_force_layernorm_form(-1)
+    assert torch.equal(ys[0].view(torch.int32), ys[1].view(torch.int32))
+    assert (ys[1][:, C:] == 0).all()
+    ref = torch.nn.functional.layer_norm(x[:, :C].double().cpu(), (C,), w.double().cpu(), b.double().cpu(), 1e-5)
+    assert (ys[1][:, :C].double() - ref).abs().max() <= 2e-5 * ref.abs().max()
