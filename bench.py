@@ -422,7 +422,7 @@ def main():
     launches_step = prof1["launches"] // 2
 
     extras = world == 1 and not args.no_extras
-    latency = latency_tl = None
+    latency = latency_tl = latency_hr = None
 
     def tester_latency(one, n_img=8):
         """The reference tester's calling pattern: one image per call, one engine instance, synchronised windows."""
@@ -466,6 +466,16 @@ def main():
             latency_tl = tester_latency(tl)
             latency_tl["weights"] = "synthetic seed 0 (trained_like recipe)"
             del tl
+            # ... and where a high-quality checkpoint works: scales of 10 ... 100, i.e. scale-table rows of 300 ... 3000 entries
+            # (sigma-index 40 ... 57 of 64), which the decoder searches in two hops (coarse first level + one probe)
+            hr = rgbd_amd.modelZoo[model](config=rgbd_amd.model_config(), channel=4).eval()
+            hr.load_state_dict(synth.synthetic_state_dict(0, model=model, recipe="high_rate"))
+            hr.update(force=True)
+            hr = hr.to(dev)
+            hr.per_image_streams = True
+            latency_hr = tester_latency(hr, n_img=4)
+            latency_hr["weights"] = "synthetic seed 0 (high_rate recipe: 98 % of the symbols on CDF rows of 300 ... 3000 entries)"
+            del hr
 
     second = None
     others = []
@@ -593,6 +603,8 @@ def main():
             res["latency"] = latency
         if latency_tl is not None:
             res["latency_trained_like"] = latency_tl
+        if latency_hr is not None:
+            res["latency_high_rate"] = latency_hr
         if second is not None:
             res["workloads"] = [{"workload": args.workload, "value": res["value"], "unit": "Mpx/s",
                                  "ms_per_step": res["ms_per_step"], "images_per_gpu": B, "image": [H, W]}, second] + others

@@ -211,6 +211,12 @@ struct DevTables {  // packed CDF rows for the device coder
     const uint16_t* cm;
     // decoder, first level: [nrows][64] slots {0xFFFF - cdf[i] << 16 | 0x10000 - cdf[i + 1]} (low half 0: not resolved here)
     const uint32_t* pk;
+    // decoder, coarse first level of the rows with 129 ... 4032 slots (at most 255 of them): [ncoarse][64] slots, slot j = the
+    // block of stride = ceil(slots / 64) symbols from j * stride on, {cdf[first] << 16 | 0x10000 - cdf[end]}; coarse[r] =
+    // the row's index in pkc or -1
+    const uint32_t* pkc;
+    const int32_t* coarse;
+    int ncoarse;
 };
 
 struct PartGeom {

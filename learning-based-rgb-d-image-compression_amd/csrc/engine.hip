@@ -137,13 +137,33 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
             pk[(size_t)r * 64 + j] = ((0xFFFFu - (uint32_t)row[j]) << 16) | (0x10000u - (uint32_t)row[j + 1]);
         }
     }
+    // coarse first level of the rows with 129 ... 4032 slots (the decoder's loop for batches with several symbols on such
+    // rows): slot j = the block of `stride` symbols from j * stride on, {cdf[first] << 16 | 0x10000 - cdf[end]} (the same
+    // 16-bit compare that resolves a narrow symbol yields the block; blocks behind the row's end never compare), followed
+    // in the decoder by ONE 64-wide probe of the block in the cdf - 1 array above.  Narrower wide rows stay with the bucket
+    // table: it resolves them in one hop.
+    std::vector<int32_t> coarse(nrows, -1);
+    std::vector<uint32_t> pkc;
+    for (int r = 0; r < nrows; ++r) {
+        const int32_t* row = cdf + (size_t)r * stride;
+        const int n = sizes[r] - 1;
+        if (n <= 128 || n > 4032 || pkc.size() / 64 >= 255) continue;
+        coarse[r] = (int32_t)(pkc.size() / 64);
+        pkc.resize(pkc.size() + 64, 0u);
+        const int st = (n + 63) / 64;
+        for (int j = 0; j < 64 && j * st < n; ++j) {
+            const int s0 = j * st, e = std::min(s0 + st, n);
+            pkc[(size_t)coarse[r] * 64 + j] = ((uint32_t)row[s0] << 16) | ((0x10000u - (uint32_t)row[e]) & 0xFFFFu);
+        }
+    }
     const size_t b_cm = (cm.size() * 2 + 15) & ~(size_t)15;
     const size_t b_pk = pk.size() * 4;
+    const size_t b_pkc = pkc.size() * 4;
     const size_t b_enc = (size_t)total * 16;
     const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
     const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
     const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
-    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk;
+    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk + b_pkc + b_i32;
     ts->blob = nullptr;  // a previous blob stays with its owner (TableSet::hold / rgbd_tables_destroy)
     ts->ready = false;
     HIP_TRY(hipMalloc(&ts->blob, bytes));
@@ -157,6 +177,8 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     memcpy(p + b_cdf + b_lut + 3 * b_i32, enc.data(), b_enc);
     memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc, cm.data(), cm.size() * 2);
     memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm, pk.data(), b_pk);
+    if (b_pkc) memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk, pkc.data(), b_pkc);
+    memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk + b_pkc, coarse.data(), (size_t)nrows * 4);
     HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
     unsigned char* dp = (unsigned char*)ts->blob;
     ts->d.cdf = (const uint16_t*)dp;
@@ -168,6 +190,9 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     ts->d.enc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32);
     ts->d.cm = (const uint16_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc);
     ts->d.pk = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm);
+    ts->d.pkc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk);
+    ts->d.coarse = (const int32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk + b_pkc);
+    ts->d.ncoarse = (int)(pkc.size() / 64);
     ts->d.nrows = nrows;
     ts->d.total = total;
     ts->ready = true;

@@ -853,6 +853,274 @@ int launch_rans_encode(const int32_t* sym, const int32_t* idx, const int64_t* sy
     return RGBD_OK;
 }
 
+// The decoder loops in ISA, cut into pieces so that the two loops below (batches of narrow rows only / batches that contain
+// rows wider than the 64 lanes) share them.  See rans_decode_kernel for what each piece does and why it is written this way.
+#define RANS_DEC_PROLOGUE \
+    "s_mov_b64 s[84:85], %[x]\n" \
+    "s_mov_b32 %[m0s], m0\n" \
+    "s_sub_u32 m0, %[j], 64\n" /* lane - 64 (lane selects use the low six bits) */ \
+    "v_readlane_b32 %[lb], %[pkrow], m0\n" \
+    "v_add_u32 v60, %[lb], %[lane4]\n" \
+    "ds_read_b32 v58, v60\n"
+
+#define RANS_DEC_BODY \
+    "s_waitcnt lgkmcnt(0)\n" /* v58: this symbol's row slots (loaded one symbol ahead) */ \
+    "s_andn2_b32 %[cum], 0xffff, s84\n" /* cumc = 0xFFFF - cum */ \
+    "v_cmp_lt_u16 vcc, %[cum], v58\n" /* low halves: cumc < 0x10000 - cdf[i+1]  <=>  cdf[i+1] <= cum */ \
+    "s_lshr_b64 s[86:87], s[84:85], 16\n" /* x >> 16 for the update below */ \
+    "s_bcnt1_i32_b64 %[a], vcc\n" /* = symbol index, <= 63 (a low half of 0 never compares) */ \
+    "v_readlane_b32 %[t1], v58, %[a]\n" /* {0xFFFF - cdf[a] << 16 | 0x10000 - cdf[a+1]} */ \
+    /* the row slots are dead from here on: the next symbol's row goes straight into v58 (lane 63's */ \
+    /* successor is lane 0: a valid row, value unused), its LDS hop overlaps the state update below */ \
+    "v_readlane_b32 %[lb], %[pkn], m0\n" \
+    "v_readlane_b32 %[wn], %[wcur], %[wi]\n" /* next unread word (lane 64 wraps: never used then) */ \
+    "v_writelane_b32 %[outv], %[a], m0\n" /* (an escape's value is written over it) */ \
+    "v_add_u32 v60, %[lb], %[lane4]\n" \
+    "ds_read_b32 v58, v60\n" \
+    "s_lshr_b32 %[start], %[t1], 16\n" \
+    "s_and_b32 %[e0], %[t1], 0xffff\n" /* 0: not resolved here (escape slot / wide row) */ \
+    "s_min_u32 %[lb], %[e0], 1\n" /* ... as 0 / 1 for the loop test */ \
+    "s_sub_u32 %[freq], %[start], %[e0]\n" \
+    "s_add_u32 %[freq], %[freq], 1\n" \
+    "s_sub_u32 %[t0], %[start], %[cum]\n" /* cum - cdf[a] */ \
+    "s_mul_i32 %[t1], s87, %[freq]\n" /* x = freq * (x >> 16) + (cum - start) */ \
+    "s_mul_hi_u32 s85, s86, %[freq]\n" \
+    "s_mul_i32 s84, s86, %[freq]\n" \
+    "s_add_u32 %[t1], %[t1], s85\n" \
+    "s_add_u32 s84, s84, %[t0]\n" \
+    "s_addc_u32 s85, %[t1], 0\n" \
+    "s_lshr_b64 s[86:87], s[84:85], 31\n" /* SCC = (x >= 2^31): keep; else x = x << 32 | next word */ \
+    "s_cselect_b32 s85, s85, s84\n" \
+    "s_cselect_b32 s84, s84, %[wn]\n" \
+    "s_subb_u32 %[wi], %[wi], -1\n" /* consumed (SCC = 0): advance */ \
+    "s_add_u32 m0, m0, 1\n" /* carries out of lane 63: batch done */ \
+    "s_subb_u32 %[lb], %[lb], 1\n" /* borrows (0 - 1, or 1 - 1 - carry) when either holds: leave */ \
+    "s_cbranch_scc0 1b\n"
+
+#define RANS_DEC_DISPATCH63 \
+    /* the loop has been left behind symbol m0 - 1: batch done, escape slot, or slot 63 of a wider row */ \
+    "63:\n" \
+    "s_cmp_lg_u32 %[e0], 0\n" \
+    "s_cbranch_scc1 3f\n" \
+    "s_cmp_eq_u32 %[start], 0xffff\n" \
+    "s_cbranch_scc1 60f\n"
+
+#define RANS_DEC_ESCAPE \
+    /* escape (rans_interface.cpp:323-345): a = the escape slot; its table step is done.  The nibbles are */ \
+    /* worked on a copy of the state (s[88:89], word index in lb, %[cum] = the next unread word) that is */ \
+    /* committed at the end; a count nibble of 15 (more than 8 payload nibbles follow) or a nearly used-up */ \
+    /* word window leaves to the C++ path with the committed state untouched.  Straight-line: every */ \
+    /* renormalisation is a pair of selects on the SCC of the s_lshr_b64 that tests it.  The nn <= 8 payload */ \
+    /* nibbles are taken in two steps at most, because the state can run dry only once in between: after */ \
+    /* k = (bits(x) - 28) >> 2 nibbles it is below 2^31 and takes in a word w, and the other nn - k <= 7 */ \
+    /* nibbles are then w's low bits, which cannot bring it (>= 2^59 after the word) below 2^31 again. */ \
+    /* Step A takes min(k, nn) nibbles and renormalises if needed, step B the rest. */ \
+    "64:\n" \
+    "s_cmp_gt_u32 %[wi], 56\n" \
+    "s_cbranch_scc1 9f\n" \
+    "v_readlane_b32 %[cum], %[wcur], %[wi]\n" \
+    "s_mov_b64 s[88:89], s[84:85]\n" \
+    "s_and_b32 %[e0], s88, 15\n" /* count nibble nn */ \
+    "s_lshr_b64 s[88:89], s[88:89], 4\n" \
+    "s_lshr_b64 s[86:87], s[88:89], 31\n" \
+    "s_cselect_b32 s89, s89, s88\n" \
+    "s_cselect_b32 s88, s88, %[cum]\n" \
+    "s_subb_u32 %[lb], %[wi], -1\n" \
+    "s_cmp_gt_u32 %[e0], 8\n" \
+    "s_cbranch_scc1 9f\n" /* a longer count: C++ path */ \
+    "v_readlane_b32 %[cum], %[wcur], %[lb]\n" \
+    "s_flbit_i32_b64 %[t0], s[88:89]\n" /* leading zeros (<= 32) */ \
+    "s_sub_u32 %[t0], 36, %[t0]\n" \
+    "s_lshr_b32 %[t0], %[t0], 2\n" /* k */ \
+    "s_min_u32 %[t0], %[t0], %[e0]\n" /* step A: k' = min(k, nn) nibbles */ \
+    "s_lshl_b32 %[t1], %[t0], 2\n" \
+    "s_bfm_b64 s[86:87], %[t1], 0\n" \
+    "s_and_b32 %[start], s88, s86\n" /* raw, low part */ \
+    "s_lshr_b64 s[88:89], s[88:89], %[t1]\n" \
+    "s_lshr_b64 s[86:87], s[88:89], 31\n" \
+    "s_cselect_b32 s89, s89, s88\n" \
+    "s_cselect_b32 s88, s88, %[cum]\n" \
+    "s_subb_u32 %[lb], %[lb], -1\n" \
+    "s_sub_u32 %[e0], %[e0], %[t0]\n" /* step B: the other nn - k' (<= 7; 0 unless A renormalised) */ \
+    "s_lshl_b32 %[e0], %[e0], 2\n" \
+    "s_bfm_b32 %[t0], %[e0], 0\n" \
+    "s_and_b32 %[t0], s88, %[t0]\n" \
+    "s_lshr_b64 s[88:89], s[88:89], %[e0]\n" \
+    "s_lshl_b32 %[t0], %[t0], %[t1]\n" /* (k' = 8: this part is 0 and so is the 5-bit shift count) */ \
+    "s_or_b32 %[start], %[start], %[t0]\n" /* raw */ \
+    "s_lshr_b32 %[t1], %[start], 1\n" /* value: even raw -> last + raw / 2, odd -> -(raw >> 1) - 1 */ \
+    "s_add_u32 %[t0], %[t1], %[a]\n" \
+    "s_not_b32 %[t1], %[t1]\n" \
+    "s_bitcmp1_b32 %[start], 0\n" \
+    "s_cselect_b32 %[t1], %[t1], %[t0]\n" \
+    "s_sub_u32 m0, m0, 1\n" /* (one scalar operand besides m0 is all v_writelane takes) */ \
+    "v_writelane_b32 %[outv], %[t1], m0\n" \
+    "s_add_u32 m0, m0, 1\n" \
+    "s_mov_b64 s[84:85], s[88:89]\n" /* commit */ \
+    "s_mov_b32 %[wi], %[lb]\n" \
+    "s_sub_u32 %[t0], %[wi], m0\n" /* + symbols left in the batch: do they fit the word window? */ \
+    "s_cmp_gt_u32 %[t0], 64\n" \
+    "s_cbranch_scc1 92f\n" /* no: hand the realign to the caller */ \
+    /* on with the next symbol (its row has been prefetched) */ \
+    "65:\n" \
+    "s_cmp_eq_u32 m0, 0\n" \
+    "s_cbranch_scc1 3f\n" \
+    "s_branch 1b\n"
+
+#define RANS_DEC_WIDE60 \
+    /* rows wider than the 64 lanes: the bucket table (cum >> shift -> first candidate, its start, its */ \
+    /* frequency) and, behind it, a probe of the next 64 row entries.  The state is untouched (identity step). */ \
+    "60:\n" \
+    "s_sub_u32 m0, m0, 1\n" \
+    "s_and_b32 %[cum], s84, 0xffff\n" \
+    "v_readlane_b32 %[lb], %[lutbase], m0\n" \
+    "s_lshr_b32 %[t0], %[cum], %[shift]\n" \
+    "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n" \
+    "v_mov_b32 v62, %[lb]\n" \
+    "ds_read_b64 v[62:63], v62\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_readfirstlane_b32 %[e0], v62\n" \
+    "v_readfirstlane_b32 %[freq], v63\n" \
+    "s_lshr_b32 %[start], %[e0], 16\n" \
+    "s_sub_u32 %[t0], %[cum], %[start]\n" \
+    "s_and_b32 %[a], %[e0], 0xffff\n" \
+    "s_mov_b32 %[e0], 1\n" /* (from here on: 1 = table symbol, 0 = escape slot) */ \
+    "s_cmp_ge_u32 %[t0], %[freq]\n" \
+    "s_cbranch_scc0 68f\n" \
+    /* second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row */ \
+    /* entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++ */ \
+    /* path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot. */ \
+    "s_cmp_eq_u32 %[freq], 0\n" /* escape marker: the bucket's first candidate is the row's */ \
+    "s_cbranch_scc1 71f\n" /* last slot, so the symbol is that slot -- no probe needed */ \
+    "v_readlane_b32 %[lb], %[rowbase], m0\n" \
+    "s_lshl1_add_u32 %[lb], %[a], %[lb]\n" \
+    "v_add_u32 v62, %[lb], %[lane2]\n" \
+    "ds_read_u16 v63, v62 offset:2\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_cmp_gt_u32 vcc, %[cum], v63\n" \
+    "s_bcnt1_i32_b64 %[t1], vcc\n" \
+    "s_cmp_eq_u32 %[t1], 64\n" \
+    "s_cbranch_scc1 8f\n" \
+    "s_cmp_eq_u32 %[t1], 0\n" \
+    "s_cbranch_scc1 71f\n" /* escape marker: symbol a is the escape slot */ \
+    "s_sub_u32 %[t0], %[t1], 1\n" \
+    "v_readlane_b32 %[lb], v63, %[t1]\n" /* cm[a + 1 + k]  = next start - 1 */ \
+    "v_readlane_b32 %[t0], v63, %[t0]\n" /* cm[a + k]      = start - 1 */ \
+    "s_cmp_eq_u32 %[lb], 0xffff\n" \
+    "s_cbranch_scc1 72f\n" /* the row's last slot: escape */ \
+    "s_add_u32 %[a], %[a], %[t1]\n" \
+    "s_sub_u32 %[freq], %[lb], %[t0]\n" \
+    "s_sub_u32 %[t0], %[cum], %[t0]\n" \
+    "s_sub_u32 %[t0], %[t0], 1\n" /* cum - start */ \
+    "s_branch 68f\n" \
+    "71:\n" \
+    "s_sub_u32 %[t0], %[cum], %[start]\n" \
+    "s_sub_u32 %[freq], 0x10000, %[start]\n" \
+    "s_mov_b32 %[e0], 0\n" \
+    "s_branch 68f\n" \
+    "72:\n" \
+    "s_add_u32 %[a], %[a], %[t1]\n" \
+    "s_sub_u32 %[freq], 0xffff, %[t0]\n" \
+    "s_sub_u32 %[t0], %[cum], %[t0]\n" \
+    "s_sub_u32 %[t0], %[t0], 1\n" \
+    "s_mov_b32 %[e0], 0\n" \
+    "68:\n" /* a, freq, cum - start: the table step, as in the loop */ \
+    "v_writelane_b32 %[outv], %[a], m0\n" \
+    "s_lshr_b64 s[86:87], s[84:85], 16\n" \
+    "s_mul_i32 %[t1], s87, %[freq]\n" \
+    "s_mul_hi_u32 s85, s86, %[freq]\n" \
+    "s_mul_i32 s84, s86, %[freq]\n" \
+    "s_add_u32 %[t1], %[t1], s85\n" \
+    "s_add_u32 s84, s84, %[t0]\n" \
+    "s_addc_u32 s85, %[t1], 0\n" \
+    "s_lshr_b64 s[86:87], s[84:85], 31\n" \
+    "s_cselect_b32 s85, s85, s84\n" \
+    "s_cselect_b32 s84, s84, %[wn]\n" \
+    "s_subb_u32 %[wi], %[wi], -1\n" \
+    "s_add_u32 m0, m0, 1\n" \
+    "s_cmp_eq_u32 %[e0], 0\n" \
+    "s_cbranch_scc1 64b\n" /* escape slot: the nibbles */ \
+    "s_branch 65b\n"
+
+// Rows of 129 ... 4032 slots in the loop for batches with several symbols on such rows (round 4).  The lanes of such a batch
+// point at the rows' COARSE first level (build_tables: slot j = the block of `stride` symbols from j * stride on), so the same 16-bit compare that resolves
+// a narrow symbol yields the block, and ONE more hop -- the 64 entries of the cdf - 1 array behind the block's first --
+// yields the symbol: k = #(entry < cum), start = k ? entry[k - 1] + 1 : the block's start (high half of the coarse slot),
+// end = entry[k] + 1 (the pad 0xFFFF behind a row makes that 65536 for the last, i.e. escape, slot).  The next symbol's first
+// level is requested right behind that hop and waited for at the next loop top; the table step and the loop edge (escape flag
+// and batch end in one s_subb) are those of the narrow body.
+#define RANS_DEC_WIDE20 \
+    "20:\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "s_andn2_b32 %[cum], 0xffff, s84\n" \
+    "v_cmp_lt_u16 vcc, %[cum], v58\n" \
+    "s_bcnt1_i32_b64 %[a], vcc\n"                /* block */ \
+    "v_readlane_b32 %[lb], %[rowbase], m0\n" \
+    "v_readlane_b32 %[t0], %[wstep], m0\n"       /* 2 * stride */ \
+    "s_mul_i32 %[e0], %[a], %[t0]\n" \
+    "s_add_u32 %[lb], %[lb], %[e0]\n" \
+    "v_add_u32 v62, %[lb], %[lane2]\n" \
+    "ds_read_u16 v63, v62 offset:2\n"            /* cdf[block * stride + 1 + lane] - 1 */ \
+    "v_readlane_b32 %[t1], v58, %[a]\n"          /* {cdf[block * stride] << 16 | ...} */ \
+    "v_readlane_b32 %[lb], %[pkn], m0\n" \
+    "v_readlane_b32 %[wn], %[wcur], %[wi]\n" \
+    "v_add_u32 v60, %[lb], %[lane4]\n" \
+    "ds_read_b32 v58, v60\n"                     /* the next symbol's first level */ \
+    "s_lshr_b32 s88, %[e0], 1\n"                 /* block * stride */ \
+    "s_lshr_b32 %[start], %[t1], 16\n" \
+    "s_and_b32 %[cum], s84, 0xffff\n" \
+    "s_lshr_b64 s[86:87], s[84:85], 16\n" \
+    "s_waitcnt lgkmcnt(1)\n" \
+    "v_cmp_gt_u32 vcc, %[cum], v63\n" \
+    "s_bcnt1_i32_b64 %[t1], vcc\n"               /* k */ \
+    "s_add_u32 %[a], s88, %[t1]\n" \
+    "v_writelane_b32 %[outv], %[a], m0\n" \
+    "v_readlane_b32 %[lb], v63, %[t1]\n"         /* cdf[a + 1] - 1 */ \
+    "s_sub_u32 %[t0], %[t1], 1\n" \
+    "v_readlane_b32 %[t0], v63, %[t0]\n"         /* cdf[a] - 1 (k >= 1; k = 0 reads lane 63 and is deselected) */ \
+    "s_add_u32 %[t0], %[t0], 1\n" \
+    "s_cmp_eq_u32 %[t1], 0\n" \
+    "s_cselect_b32 %[start], %[start], %[t0]\n" \
+    "s_sub_u32 %[e0], 0xffff, %[lb]\n"           /* 0: the row's last slot (escape) */ \
+    "s_sub_u32 %[freq], %[lb], %[start]\n" \
+    "s_add_u32 %[freq], %[freq], 1\n" \
+    "s_min_u32 %[lb], %[e0], 1\n" \
+    "s_sub_u32 %[t0], %[cum], %[start]\n" \
+    "s_mul_i32 %[t1], s87, %[freq]\n" \
+    "s_mul_hi_u32 s85, s86, %[freq]\n" \
+    "s_mul_i32 s84, s86, %[freq]\n" \
+    "s_add_u32 %[t1], %[t1], s85\n" \
+    "s_add_u32 s84, s84, %[t0]\n" \
+    "s_addc_u32 s85, %[t1], 0\n" \
+    "s_lshr_b64 s[86:87], s[84:85], 31\n" \
+    "s_cselect_b32 s85, s85, s84\n" \
+    "s_cselect_b32 s84, s84, %[wn]\n" \
+    "s_subb_u32 %[wi], %[wi], -1\n" \
+    "s_add_u32 m0, m0, 1\n" \
+    "s_subb_u32 %[lb], %[lb], 1\n" \
+    "s_cbranch_scc0 1b\n" \
+    "s_cmp_lg_u32 %[e0], 0\n" \
+    "s_cbranch_scc1 3f\n"                        /* batch done */ \
+    "s_branch 64b\n"                             /* escape slot: the nibbles */
+
+#define RANS_DEC_EXITS \
+    "3:\n" \
+    "s_mov_b32 %[more], 0\n" \
+    "s_branch 5f\n" \
+    "92:\n" \
+    "s_mov_b32 %[more], 2\n" \
+    "s_branch 5f\n" \
+    "9:\n" \
+    "s_mov_b32 %[more], 3\n" \
+    "s_branch 5f\n" \
+    "8:\n" \
+    "s_mov_b32 %[more], 1\n" \
+    "5:\n" \
+    "s_waitcnt lgkmcnt(0)\n" /* drain the row prefetch */ \
+    "s_mov_b64 %[x], s[84:85]\n" \
+    "s_add_u32 %[j], m0, 64\n" \
+    "s_mov_b32 m0, %[m0s]\n"
+
 // ---------------------------------------------------------------------------------------------
 // Decoder.  LDS holds the packed u16 CDF rows and a per-row bucket table (cum >> (16 - lut_bits) -> first candidate
 // symbol, its start and its frequency: one 8-byte read resolves a symbol unless a boundary falls inside the bucket).
@@ -877,6 +1145,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     // pk: the first 64 slots of every row as {cdf[i] << 16 | cdf[i + 1] - 1} (build_tables): the hot loop's only table
     uint32_t* pk = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(cm) +
                                                (((size_t)(t.total + 64 * t.nrows) * 2 + 15) & ~(size_t)15));  // [nrows][64]
+    uint32_t* pkc = pk + (size_t)t.nrows * 64;  // [ncoarse][64]: the coarse first level of the rows with 129 ... 4032 slots
 
     // Four streams per workgroup, one per wavefront (each on its own SIMD): the ~140 KB of tables in LDS are shared, so a
     // decode launch of 16 streams holds 4 CUs' LDS instead of 16 (a conv workgroup cannot co-reside with these tables).
@@ -892,12 +1161,19 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         const uint4* gpk = reinterpret_cast<const uint4*>(t.pk);
         uint4* lpk = reinterpret_cast<uint4*>(pk);
         for (int i = tid; i < t.nrows * 16; i += 256) lpk[i] = gpk[i];
+        const uint4* gpc = reinterpret_cast<const uint4*>(t.pkc);
+        uint4* lpc = reinterpret_cast<uint4*>(pkc);
+        for (int i = tid; i < t.ncoarse * 16; i += 256) lpc[i] = gpc[i];
         const uint2* gl = reinterpret_cast<const uint2*>(t.lut);  // bucket entries (escape candidates carry frequency 0)
         for (int i = tid; i < t.nrows * lut_n; i += 256) sl[i] = gl[i];
     }
-    for (int i = tid; i < t.nrows; i += 256)  // {row start in cm : 16 | cdf_length : 16}, {offset (signed) : 16 | unused}
+    for (int i = tid; i < t.nrows; i += 256) {  // {row start in cm : 16 | cdf_length : 16}, {offset (signed) : 16 | wstep : 8 | coarse row : 8}
+        // wstep: 0, or for a row with a coarse first level the byte step of its blocks in cm (2 * ceil(slots / 64))
+        const int cr = t.coarse[i];
+        const uint32_t wstep = cr >= 0 ? 2u * (uint32_t)((t.sizes[i] - 1 + 63) / 64) : 0u;
         rowinfo[i] = make_uint2((uint32_t)(t.row_off[i] + 64 * i) | ((uint32_t)t.sizes[i] << 16),
-                                (uint32_t)t.offsets[i] & 0xFFFFu);
+                                ((uint32_t)t.offsets[i] & 0xFFFFu) | (wstep << 16) | ((uint32_t)(cr >= 0 ? cr : 0) << 24));
+    }
     __syncthreads();
     if ((tid >> 6) >= spw || s >= nstreams) return;
     const int lane = tid & 63;
@@ -948,6 +1224,7 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
     const uint32_t dsm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dsm;
     const uint32_t cm_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)cm;
     const uint32_t pk_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)pk;
+    const uint32_t pkc_addr = pk_addr + (uint32_t)t.nrows * 256u;
     const uint32_t lane2 = (uint32_t)lane * 2u, lane4 = (uint32_t)lane * 4u;
 
     // A batch is 64 symbols, one per lane; a shorter (last) batch sits in the TOP lanes (symbol k in lane k + 64 - cnt),
@@ -970,7 +1247,15 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
         const uint32_t lutbase = dsm_addr + (uint32_t)(ti * lut_n) * 8u;  // LDS address of this lane's symbol's bucket row
         const uint2 rinfo = rowinfo[ti];  // this lane's row: {start : 16 | cdf_length : 16}, {offset : 16}
         const uint32_t rowbase = cm_addr + (rinfo.x & 0xFFFFu) * 2u;  // LDS address of the row in cm
-        const uint32_t pkrow = pk_addr + (uint32_t)ti * 256u;         // ... and of its first-level slots
+        // Rows with a coarse first level (129 ... 4032 slots): a batch with at least five symbols on such rows runs the loop
+        // that resolves them in two hops (~156 ns each instead of ~286 through the bucket table, at ~11 ns per narrow symbol of
+        // the batch for the test in front: the break-even is five); its lanes then point at the coarse slots.  Any other
+        // batch runs the plain loop, every wide row through the bucket table.
+        const uint32_t wstep = (rinfo.y >> 16) & 0xFFu;
+        uint64_t wmask = __builtin_amdgcn_ballot_w64(wstep != 0u && lane >= sh);
+        if (__builtin_popcountll(wmask) < 5) wmask = 0;
+        const bool coarse_lane = (wmask >> lane) & 1u;
+        const uint32_t pkrow = coarse_lane ? pkc_addr + (rinfo.y >> 24) * 256u : pk_addr + (uint32_t)ti * 256u;  // first-level slots
         // the same for the NEXT lane's symbol: the loop prefetches symbol m0 + 1's slots with lane select m0
         const uint32_t pkn = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)pkrow);
         uint32_t outv = 0;
@@ -1000,206 +1285,41 @@ __global__ __launch_bounds__(256) void rans_decode_kernel(const uint32_t* __rest
             uint32_t a, start, freq, cum, more;
             {
                 uint32_t lb, t0, t1, e0, m0s, wn;
+                // Two copies of the loop in one statement.  wmask == 0: the plain loop (second copy; wide rows leave it through
+                // the identity slot for the bucket-table path at 60:).  Otherwise the first copy: the same loop with one test
+                // per symbol in front (bit m0 of wmask: +2 instructions and a branch) and the two-level body at 20: for the
+                // symbols on rows with a coarse first level.
                 asm volatile(
-                    "s_mov_b64 s[84:85], %[x]\n"
-                    "s_mov_b32 %[m0s], m0\n"
-                    "s_sub_u32 m0, %[j], 64\n"                  // lane - 64 (lane selects use the low six bits)
-                    "v_readlane_b32 %[lb], %[pkrow], m0\n"
-                    "v_add_u32 v60, %[lb], %[lane4]\n"
-                    "ds_read_b32 v58, v60\n"
+                    "s_cmp_eq_u64 %[wmask], 0\n"
+                    "s_cbranch_scc1 90f\n"
+                    RANS_DEC_PROLOGUE
+                    ".p2align 6\n"
                     "1:\n"
-                    "s_waitcnt lgkmcnt(0)\n"                    // v58: this symbol's row slots (loaded one symbol ahead)
-                    "s_andn2_b32 %[cum], 0xffff, s84\n"         // cumc = 0xFFFF - cum
-                    "v_cmp_lt_u16 vcc, %[cum], v58\n"           // low halves: cumc < 0x10000 - cdf[i+1]  <=>  cdf[i+1] <= cum
-                    "s_lshr_b64 s[86:87], s[84:85], 16\n"      // x >> 16 for the update below
-                    "s_bcnt1_i32_b64 %[a], vcc\n"               // = symbol index, <= 63 (a low half of 0 never compares)
-                    "v_readlane_b32 %[t1], v58, %[a]\n"         // {0xFFFF - cdf[a] << 16 | 0x10000 - cdf[a+1]}
-                    // the row slots are dead from here on: the next symbol's row goes straight into v58 (lane 63's
-                    // successor is lane 0: a valid row, value unused), its LDS hop overlaps the state update below
-                    "v_readlane_b32 %[lb], %[pkn], m0\n"
-                    "v_readlane_b32 %[wn], %[wcur], %[wi]\n"  // next unread word (lane 64 wraps: never used then)
-                    "v_writelane_b32 %[outv], %[a], m0\n"      // (an escape's value is written over it)
-                    "v_add_u32 v60, %[lb], %[lane4]\n"
-                    "ds_read_b32 v58, v60\n"
-                    "s_lshr_b32 %[start], %[t1], 16\n"
-                    "s_and_b32 %[e0], %[t1], 0xffff\n"          // 0: not resolved here (escape slot / wide row)
-                    "s_min_u32 %[lb], %[e0], 1\n"               // ... as 0 / 1 for the loop test
-                    "s_sub_u32 %[freq], %[start], %[e0]\n"
-                    "s_add_u32 %[freq], %[freq], 1\n"
-                    "s_sub_u32 %[t0], %[start], %[cum]\n"       // cum - cdf[a]
-                    "s_mul_i32 %[t1], s87, %[freq]\n"           // x = freq * (x >> 16) + (cum - start)
-                    "s_mul_hi_u32 s85, s86, %[freq]\n"
-                    "s_mul_i32 s84, s86, %[freq]\n"
-                    "s_add_u32 %[t1], %[t1], s85\n"
-                    "s_add_u32 s84, s84, %[t0]\n"
-                    "s_addc_u32 s85, %[t1], 0\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 31\n"      // SCC = (x >= 2^31): keep; else x = x << 32 | next word
-                    "s_cselect_b32 s85, s85, s84\n"
-                    "s_cselect_b32 s84, s84, %[wn]\n"
-                    "s_subb_u32 %[wi], %[wi], -1\n"            // consumed (SCC = 0): advance
-                    "s_add_u32 m0, m0, 1\n"                    // carries out of lane 63: batch done
-                    "s_subb_u32 %[lb], %[lb], 1\n"             // borrows (0 - 1, or 1 - 1 - carry) when either holds: leave
-                    "s_cbranch_scc0 1b\n"
-                    // the loop has been left behind symbol m0 - 1: batch done, escape slot, or slot 63 of a wider row
-                    "63:\n"
-                    "s_cmp_lg_u32 %[e0], 0\n"
-                    "s_cbranch_scc1 3f\n"
-                    "s_cmp_eq_u32 %[start], 0xffff\n"
-                    "s_cbranch_scc1 60f\n"
-                    // escape (rans_interface.cpp:323-345): a = the escape slot; its table step is done.  The nibbles are
-                    // worked on a copy of the state (s[88:89], word index in lb, %[cum] = the next unread word) that is
-                    // committed at the end; a count nibble of 15 (more than 8 payload nibbles follow) or a nearly used-up
-                    // word window leaves to the C++ path with the committed state untouched.  Straight-line: every
-                    // renormalisation is a pair of selects on the SCC of the s_lshr_b64 that tests it.  The nn <= 8 payload
-                    // nibbles are taken in two steps at most, because the state can run dry only once in between: after
-                    // k = (bits(x) - 28) >> 2 nibbles it is below 2^31 and takes in a word w, and the other nn - k <= 7
-                    // nibbles are then w's low bits, which cannot bring it (>= 2^59 after the word) below 2^31 again.
-                    // Step A takes min(k, nn) nibbles and renormalises if needed, step B the rest.
-                    "64:\n"
-                    "s_cmp_gt_u32 %[wi], 56\n"
-                    "s_cbranch_scc1 9f\n"
-                    "v_readlane_b32 %[cum], %[wcur], %[wi]\n"
-                    "s_mov_b64 s[88:89], s[84:85]\n"
-                    "s_and_b32 %[e0], s88, 15\n"              // count nibble nn
-                    "s_lshr_b64 s[88:89], s[88:89], 4\n"
-                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cselect_b32 s89, s89, s88\n"
-                    "s_cselect_b32 s88, s88, %[cum]\n"
-                    "s_subb_u32 %[lb], %[wi], -1\n"
-                    "s_cmp_gt_u32 %[e0], 8\n"
-                    "s_cbranch_scc1 9f\n"                     // a longer count: C++ path
-                    "v_readlane_b32 %[cum], %[wcur], %[lb]\n"
-                    "s_flbit_i32_b64 %[t0], s[88:89]\n"       // leading zeros (<= 32)
-                    "s_sub_u32 %[t0], 36, %[t0]\n"
-                    "s_lshr_b32 %[t0], %[t0], 2\n"            // k
-                    "s_min_u32 %[t0], %[t0], %[e0]\n"         // step A: k' = min(k, nn) nibbles
-                    "s_lshl_b32 %[t1], %[t0], 2\n"
-                    "s_bfm_b64 s[86:87], %[t1], 0\n"
-                    "s_and_b32 %[start], s88, s86\n"          // raw, low part
-                    "s_lshr_b64 s[88:89], s[88:89], %[t1]\n"
-                    "s_lshr_b64 s[86:87], s[88:89], 31\n"
-                    "s_cselect_b32 s89, s89, s88\n"
-                    "s_cselect_b32 s88, s88, %[cum]\n"
-                    "s_subb_u32 %[lb], %[lb], -1\n"
-                    "s_sub_u32 %[e0], %[e0], %[t0]\n"         // step B: the other nn - k' (<= 7; 0 unless A renormalised)
-                    "s_lshl_b32 %[e0], %[e0], 2\n"
-                    "s_bfm_b32 %[t0], %[e0], 0\n"
-                    "s_and_b32 %[t0], s88, %[t0]\n"
-                    "s_lshr_b64 s[88:89], s[88:89], %[e0]\n"
-                    "s_lshl_b32 %[t0], %[t0], %[t1]\n"        // (k' = 8: this part is 0 and so is the 5-bit shift count)
-                    "s_or_b32 %[start], %[start], %[t0]\n"    // raw
-                    "s_lshr_b32 %[t1], %[start], 1\n"         // value: even raw -> last + raw / 2, odd -> -(raw >> 1) - 1
-                    "s_add_u32 %[t0], %[t1], %[a]\n"
-                    "s_not_b32 %[t1], %[t1]\n"
-                    "s_bitcmp1_b32 %[start], 0\n"
-                    "s_cselect_b32 %[t1], %[t1], %[t0]\n"
-                    "s_sub_u32 m0, m0, 1\n"                  // (one scalar operand besides m0 is all v_writelane takes)
-                    "v_writelane_b32 %[outv], %[t1], m0\n"
-                    "s_add_u32 m0, m0, 1\n"
-                    "s_mov_b64 s[84:85], s[88:89]\n"           // commit
-                    "s_mov_b32 %[wi], %[lb]\n"
-                    "s_sub_u32 %[t0], %[wi], m0\n"            // + symbols left in the batch: do they fit the word window?
-                    "s_cmp_gt_u32 %[t0], 64\n"
-                    "s_cbranch_scc1 92f\n"                    // no: hand the realign to the caller
-                    // on with the next symbol (its row has been prefetched)
-                    "65:\n"
-                    "s_cmp_eq_u32 m0, 0\n"
-                    "s_cbranch_scc1 3f\n"
-                    "s_branch 1b\n"
-                    // rows wider than the 64 lanes: the bucket table (cum >> shift -> first candidate, its start, its
-                    // frequency) and, behind it, a probe of the next 64 row entries.  The state is untouched (identity step).
-                    "60:\n"
-                    "s_sub_u32 m0, m0, 1\n"
-                    "s_and_b32 %[cum], s84, 0xffff\n"
-                    "v_readlane_b32 %[lb], %[lutbase], m0\n"
-                    "s_lshr_b32 %[t0], %[cum], %[shift]\n"
-                    "s_lshl3_add_u32 %[lb], %[t0], %[lb]\n"
-                    "v_mov_b32 v62, %[lb]\n"
-                    "ds_read_b64 v[62:63], v62\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_readfirstlane_b32 %[e0], v62\n"
-                    "v_readfirstlane_b32 %[freq], v63\n"
-                    "s_lshr_b32 %[start], %[e0], 16\n"
-                    "s_sub_u32 %[t0], %[cum], %[start]\n"
-                    "s_and_b32 %[a], %[e0], 0xffff\n"
-                    "s_mov_b32 %[e0], 1\n"                     // (from here on: 1 = table symbol, 0 = escape slot)
-                    "s_cmp_ge_u32 %[t0], %[freq]\n"
-                    "s_cbranch_scc0 68f\n"
-                    // second level: the symbol lies behind the bucket's first candidate a.  The lanes probe the 64 row
-                    // entries after a at once; k = #(entry < cum) locates it.  k = 64 (further away) is left to the C++
-                    // path below; k = 0 (escape marker) and a probe ending on the pad are the row's escape slot.
-                    "s_cmp_eq_u32 %[freq], 0\n"               // escape marker: the bucket's first candidate is the row's
-                    "s_cbranch_scc1 71f\n"                     // last slot, so the symbol is that slot -- no probe needed
-                    "v_readlane_b32 %[lb], %[rowbase], m0\n"
-                    "s_lshl1_add_u32 %[lb], %[a], %[lb]\n"
-                    "v_add_u32 v62, %[lb], %[lane2]\n"
-                    "ds_read_u16 v63, v62 offset:2\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    "v_cmp_gt_u32 vcc, %[cum], v63\n"
-                    "s_bcnt1_i32_b64 %[t1], vcc\n"
-                    "s_cmp_eq_u32 %[t1], 64\n"
-                    "s_cbranch_scc1 8f\n"
-                    "s_cmp_eq_u32 %[t1], 0\n"
-                    "s_cbranch_scc1 71f\n"                     // escape marker: symbol a is the escape slot
-                    "s_sub_u32 %[t0], %[t1], 1\n"
-                    "v_readlane_b32 %[lb], v63, %[t1]\n"      // cm[a + 1 + k]  = next start - 1
-                    "v_readlane_b32 %[t0], v63, %[t0]\n"      // cm[a + k]      = start - 1
-                    "s_cmp_eq_u32 %[lb], 0xffff\n"
-                    "s_cbranch_scc1 72f\n"                     // the row's last slot: escape
-                    "s_add_u32 %[a], %[a], %[t1]\n"
-                    "s_sub_u32 %[freq], %[lb], %[t0]\n"
-                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
-                    "s_sub_u32 %[t0], %[t0], 1\n"             // cum - start
-                    "s_branch 68f\n"
-                    "71:\n"
-                    "s_sub_u32 %[t0], %[cum], %[start]\n"
-                    "s_sub_u32 %[freq], 0x10000, %[start]\n"
-                    "s_mov_b32 %[e0], 0\n"
-                    "s_branch 68f\n"
-                    "72:\n"
-                    "s_add_u32 %[a], %[a], %[t1]\n"
-                    "s_sub_u32 %[freq], 0xffff, %[t0]\n"
-                    "s_sub_u32 %[t0], %[cum], %[t0]\n"
-                    "s_sub_u32 %[t0], %[t0], 1\n"
-                    "s_mov_b32 %[e0], 0\n"
-                    "68:\n"                                    // a, freq, cum - start: the table step, as in the loop
-                    "v_writelane_b32 %[outv], %[a], m0\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 16\n"
-                    "s_mul_i32 %[t1], s87, %[freq]\n"
-                    "s_mul_hi_u32 s85, s86, %[freq]\n"
-                    "s_mul_i32 s84, s86, %[freq]\n"
-                    "s_add_u32 %[t1], %[t1], s85\n"
-                    "s_add_u32 s84, s84, %[t0]\n"
-                    "s_addc_u32 s85, %[t1], 0\n"
-                    "s_lshr_b64 s[86:87], s[84:85], 31\n"
-                    "s_cselect_b32 s85, s85, s84\n"
-                    "s_cselect_b32 s84, s84, %[wn]\n"
-                    "s_subb_u32 %[wi], %[wi], -1\n"
-                    "s_add_u32 m0, m0, 1\n"
-                    "s_cmp_eq_u32 %[e0], 0\n"
-                    "s_cbranch_scc1 64b\n"                    // escape slot: the nibbles
-                    "s_branch 65b\n"
-                    "3:\n"
-                    "s_mov_b32 %[more], 0\n"
-                    "s_branch 5f\n"
-                    "92:\n"
-                    "s_mov_b32 %[more], 2\n"
-                    "s_branch 5f\n"
-                    "9:\n"
-                    "s_mov_b32 %[more], 3\n"
-                    "s_branch 5f\n"
-                    "8:\n"
-                    "s_mov_b32 %[more], 1\n"
-                    "5:\n"
-                    "s_waitcnt lgkmcnt(0)\n"                    // drain the row prefetch
-                    "s_mov_b64 %[x], s[84:85]\n"
-                    "s_add_u32 %[j], m0, 64\n"
-                    "s_mov_b32 m0, %[m0s]\n"
+                    "s_bitcmp1_b64 %[wmask], m0\n"
+                    "s_cbranch_scc1 20f\n"
+                    RANS_DEC_BODY
+                    RANS_DEC_DISPATCH63
+                    RANS_DEC_ESCAPE
+                    RANS_DEC_WIDE20
+                    RANS_DEC_WIDE60
+                    RANS_DEC_EXITS
+                    "s_branch 99f\n"
+                    "90:\n"
+                    RANS_DEC_PROLOGUE
+                    ".p2align 6\n"
+                    "1:\n"
+                    RANS_DEC_BODY
+                    RANS_DEC_DISPATCH63
+                    RANS_DEC_ESCAPE
+                    RANS_DEC_WIDE60
+                    RANS_DEC_EXITS
+                    "99:\n"
                     : [x] "+s"(x), [j] "+s"(j), [wi] "+s"(wi), [outv] "+v"(outv), [a] "=&s"(a), [start] "=&s"(start),
                       [freq] "=&s"(freq), [cum] "=&s"(cum), [more] "=&s"(more), [lb] "=&s"(lb), [t0] "=&s"(t0),
                       [t1] "=&s"(t1), [e0] "=&s"(e0), [m0s] "=&s"(m0s), [wn] "=&s"(wn)
                     : [shift] "s"(shift), [lutbase] "v"(lutbase), [wcur] "v"(wcur), [rowbase] "v"(rowbase),
-                      [lane2] "v"(lane2), [pkrow] "v"(pkrow), [pkn] "v"(pkn), [lane4] "v"(lane4)
+                      [lane2] "v"(lane2), [pkrow] "v"(pkrow), [pkn] "v"(pkn), [lane4] "v"(lane4), [wstep] "v"(wstep),
+                      [wmask] "s"(wmask)
                     : "s84", "s85", "s86", "s87", "s88", "s89", "v58", "v59", "v60", "v62", "v63", "vcc", "scc", "memory");
             }
             more = rfl(more);
@@ -1294,7 +1414,7 @@ size_t rans_decode_lds_bytes(const DevTables& t)
 {
     const size_t lut_n = ((size_t)1 << t.lut_bits) + 1;
     return (((size_t)t.nrows * lut_n + 1) & ~(size_t)1) * 8 + (((size_t)t.nrows + 1) & ~(size_t)1) * 8 +
-           ((((size_t)t.total + 64 * (size_t)t.nrows) * 2 + 15) & ~(size_t)15) + (size_t)t.nrows * 256;
+           ((((size_t)t.total + 64 * (size_t)t.nrows) * 2 + 15) & ~(size_t)15) + ((size_t)t.nrows + (size_t)t.ncoarse) * 256;
 }
 
 int launch_rans_decode(const uint32_t* streams, const int64_t* stream_off_words, const int64_t* stream_len_words,

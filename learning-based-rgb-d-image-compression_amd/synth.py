@@ -105,10 +105,12 @@ def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_tor
     """Full state_dict (parameters + buffers) of ELIC_united (default) or the single-modal ELIC with deterministic
     synthetic values.  `recipe`: "stress" (= stress=True, the default: ~22 bpp, wide CDF rows, 17 % escapes -- the worst
     case for the entropy coder), "trained_like" (ELIC_united only: latents mostly inside the dead zone, scales near the
-    bottom of the scale table, ~1 bpp per modality like a trained q=2_2 model -- the coder's realistic operating point) or
-    "plain" (default initialisation, everything quantises to zero)."""
+    bottom of the scale table, ~1 bpp per modality like a trained q=2_2 model -- the coder's realistic operating point),
+    "high_rate" (ELIC_united only: latents of tens to hundreds, predicted scales of 10 ... 100 -- scale-table rows of 300 ...
+    3000 entries, what a high-quality checkpoint makes the decoder search) or "plain" (default initialisation, everything
+    quantises to zero)."""
     if recipe is not None:
-        if recipe not in ("stress", "trained_like", "plain"):
+        if recipe not in ("stress", "trained_like", "high_rate", "plain"):
             raise ValueError(f"unknown recipe {recipe}")
         stress = recipe == "stress"
     if model == "STF_united":
@@ -133,6 +135,10 @@ def synthetic_state_dict(seed: int = 0, config=None, stress: bool = True, as_tor
         if model != "ELIC_united":
             raise ValueError("the trained_like recipe is defined for ELIC_united")
         _apply_trained_like(sd, cfg)
+    if recipe == "high_rate":
+        if model != "ELIC_united":
+            raise ValueError("the high_rate recipe is defined for ELIC_united")
+        _apply_high_rate(sd, cfg)
     if as_torch:
         import torch
 
@@ -173,6 +179,27 @@ def _apply_trained_like(sd, cfg):
         for i, c in enumerate(slice_ch):
             sd[f"{fam}.{i}.fusion.4.weight"] *= np.float32(2.0)
             sd[f"{fam}.{i}.fusion.4.bias"][:c] = np.float32(0.25)  # scale half
+
+
+HIGH_RATE_GAINS = (240.0, 24.0, 40.0, 12.0, 40.0)  # y, z, h_s, scale-head weight, scale-head bias
+
+
+def _apply_high_rate(sd, cfg):
+    """Wide scale-table rows: |y| of tens to hundreds and predicted scales of 10 ... 100 (sigma-index 37 ... 56 of 64, CDF rows
+    of 300 ... 3000 entries) -- the rows a high-quality checkpoint codes on, which neither other recipe reaches
+    (sigma-index <= 33).  Applied to the plain initialisation."""
+    gy, gz, gh, gw, gb = (np.float32(v) for v in HIGH_RATE_GAINS)
+    slice_ch = list(cfg["slice_ch"])
+    for mod in ("rgb", "depth"):
+        sd[f"g_a.{mod}_analysis_transform.16.weight"] *= gy
+        sd[f"h_a.{mod}_reduction.4.weight"] *= gz
+    for m in ("r", "d"):
+        sd[f"h_s.{m}_h_s3.deconv.weight"] *= gh
+    for fam in ("rgb_entropy_parameters_anchor", "depth_entropy_parameters_anchor",
+                "rgb_entropy_parameters_nonanchor", "depth_entropy_parameters_nonanchor"):
+        for i, c in enumerate(slice_ch):
+            sd[f"{fam}.{i}.fusion.4.weight"] *= gw
+            sd[f"{fam}.{i}.fusion.4.bias"][:c] = gb  # scale half
 
 
 def _apply_stress_single(sd, cfg):

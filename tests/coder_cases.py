@@ -2,11 +2,11 @@
 import numpy as np
 
 
-def lane_edge_tables(seed):
+def lane_edge_tables(seed, slots=(2, 3, 5, 17, 31, 32, 33, 62, 63, 64, 65, 66, 70)):
     """CDF rows of 2 ... 70 slots with random frequencies (many of them 1): the GPU decoder's first level holds 64 slots of a
     row in the 64 lanes, so 63 / 64 / 65 slots are its edges.  Returns (cdf [rows, stride], sizes, offsets, rng)."""
     rng = np.random.RandomState(100 + seed)
-    slots = [2, 3, 5, 17, 31, 32, 33, 62, 63, 64, 65, 66, 70]
+    slots = list(slots)
     stride = max(slots) + 1
     cdf = np.zeros((len(slots), stride), np.int32)
     for r, n in enumerate(slots):
@@ -19,10 +19,15 @@ def lane_edge_tables(seed):
     return cdf, sizes, offsets, rng
 
 
-def lane_edge_symbols(rng, n, sizes, offsets):
-    """n (index, symbol) pairs over those rows: every table slot, the first and the last one over-represented, and one in
-    ten an escape on either side of the table."""
-    idx = rng.randint(0, len(sizes), n).astype(np.int32)
+# rows around the decoder's coarse first level (129 ... 4032 slots: blocks of ceil(slots / 64) symbols), next to narrow rows and
+# to wide rows that stay with the bucket table (65 ... 128 and > 4032 slots)
+COARSE_EDGE_SLOTS = (5, 40, 64, 100, 128, 129, 130, 191, 192, 193, 1000, 4031, 4032, 4033)
+
+
+def lane_edge_symbols(rng, n, sizes, offsets, rows=None):
+    """n (index, symbol) pairs over those rows (or over `rows`, a sequence of row indices to draw from): every table slot, the
+    first and the last one over-represented, and one in ten an escape on either side of the table."""
+    idx = (rng.randint(0, len(sizes), n) if rows is None else np.asarray(rows)[rng.randint(0, len(rows), n)]).astype(np.int32)
     v = (rng.rand(n) * (sizes[idx] - 2)).astype(np.int64)      # a table slot (escape slot excluded) ...
     edge = rng.rand(n)
     v = np.where(edge < 0.15, 0, np.where(edge < 0.3, sizes[idx] - 3, v))

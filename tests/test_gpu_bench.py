@@ -44,6 +44,7 @@ def test_single_rank_line_has_the_contract_fields():
     assert lat["batch"] == 1 and lat["engine_instances"] == 1 and lat["value"] > 0.2
     assert abs(lat["value"] - 480 * 640 / ((lat["enc_ms_per_image"] + lat["dec_ms_per_image"]) * 1e-3) / 1e6) < 0.02 * lat["value"]
     assert r["latency_trained_like"]["value"] > lat["value"] * 0.8
+    assert r["latency_high_rate"]["batch"] == 1 and r["latency_high_rate"]["value"] > 0.2  # symbols on CDF rows of 300 ... 3000 entries
     assert r["vs_cpu"]["throughput"] > r["vs_cpu"]["latency_tester_semantics"] > 1.0
     assert [w["workload"] for w in r["workloads"]] == ["c3_4x480x640", "c2_8x256x256", "c5_stf_1x512x512", "c5_stf_4x512x512"]
     for w in r["workloads"][2:]:  # BASELINE config 5 rides along with its own roofline and CPU baseline

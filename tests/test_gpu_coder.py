@@ -176,6 +176,34 @@ def test_rows_around_the_lane_count(seed):
         assert np.array_equal(np.asarray(d.decode_stream(idx, cdf, sizes, offsets), np.int32), sym), n
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_rows_around_the_coarse_level(seed):
+    """Rows of 129 ... 4032 slots have a coarse first level in the decoder (blocks of ceil(slots / 64) symbols, then one
+    64-wide probe of the block); a batch of 64 symbols takes that path when at least five of its symbols sit on such rows.
+    Every slot of every row is coded -- block edges, symbol 0, the slot before the escape, escapes of both signs -- in
+    mixes from "hardly any symbol on such a row" (the bucket-table path) to "all of them", next to narrow rows, to wide
+    rows without a coarse level (65 ... 128 and 4033 slots) and around the batch length."""
+    require_gpu()
+    from rgbd_amd import ans
+
+    from coder_cases import COARSE_EDGE_SLOTS, lane_edge_symbols, lane_edge_tables
+
+    cdf, sizes, offsets, rng = lane_edge_tables(seed, COARSE_EDGE_SLOTS)
+    t, ot = ans.Tables(cdf, sizes, offsets), coder.Tables(cdf, sizes, offsets)
+    coarse = [r for r, n in enumerate(COARSE_EDGE_SLOTS) if 128 < n <= 4032]
+    other = [r for r in range(len(COARSE_EDGE_SLOTS)) if r not in coarse]
+    for n, share in ((63, 1.0), (64, 1.0), (65, 0.5), (4000, 0.03), (4000, 0.1), (4000, 0.5), (20000, 1.0)):
+        idx, sym = lane_edge_symbols(rng, n, sizes, offsets, rows=coarse)
+        idx2, sym2 = lane_edge_symbols(rng, n, sizes, offsets, rows=other)
+        pick = rng.rand(n) < share
+        idx, sym = np.where(pick, idx, idx2).astype(np.int32), np.where(pick, sym, sym2).astype(np.int32)
+        s = ans._encode(t, sym, idx)
+        assert s == coder.rans_encode(sym, idx, ot)
+        d = ans.RansDecoder()
+        d.set_stream(s)
+        assert np.array_equal(np.asarray(d.decode_stream(idx, cdf, sizes, offsets), np.int32), sym), (n, share)
+
+
 def test_both_encoder_generations_make_the_same_stream(kat, gc_tables, gpu_tables):
     """The library keeps its first encoder loop selectable (RGBD_CODER_V1, read once per process) for A/B timing.  Both
     generations -- the older one in its own process -- must produce the oracle's bytes for a stream with escapes of every

@@ -335,3 +335,33 @@ def test_full_size_self_consistency(net):
     bits = float(-torch.log2(fw["r_likelihoods"]["y"]).sum() - torch.log2(fw["r_likelihoods"]["z"]).sum())
     real = 8 * (len(out["r_strings"][0][0]) + len(out["r_strings"][1][0]))
     assert abs(bits - real) < 0.35 * real
+
+
+def test_high_rate_recipe_wide_rows_through_the_model(orc):
+    """The high_rate synthetic weights put ~98 % of the symbols on scale-table rows of 300 ... 3000 entries -- the rows the
+    decoder searches through its coarse first level.  Stream = the oracle coder's stream for the same (symbol, index)
+    pairs (rans_interface.cpp:149-206 restated), decode(encode(x)) reproduces the encoder's y_hat, batch == per image."""
+    require_gpu()
+    import rgbd_amd
+    from rgbd_amd import ELIC_united, synth
+
+    m = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    m.load_state_dict(synth.synthetic_state_dict(0, recipe="high_rate"))
+    assert m.update(force=True)
+    m = m.to("cuda")
+    r, d = synth.synthetic_batch(2, 128, 192, config_id=41)
+    rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+    one = m.compress(rgb[:1], depth[:1])
+    sizes = np.asarray(m.rgb_gaussian_conditional._cdf_length)
+    for mod, key in ((0, "r_strings"), (1, "d_strings")):
+        sym, idx = m.debug_symbols(mod)
+        assert (sizes[idx] - 1 > 128).mean() > 0.9  # the recipe does what it says
+        assert coder.rans_encode(sym, idx, orc.gc) == one[key][0][0]  # (the scale table does not depend on the weights)
+    yh = [m.debug_tensor("yhat_r").copy(), m.debug_tensor("yhat_d").copy()]
+    rec = m.decompress(one["r_strings"], one["d_strings"], one["shape"])
+    assert np.array_equal(m.debug_tensor("yhat_r"), yh[0]) and np.array_equal(m.debug_tensor("yhat_d"), yh[1])
+    m.per_image_streams = True
+    both = m.compress(rgb, depth)
+    assert both["r_strings"][0][0] == one["r_strings"][0][0] and both["d_strings"][1][0] == one["d_strings"][1][0]
+    rec2 = m.decompress(both["r_strings"], both["d_strings"], both["shape"])
+    assert torch.equal(rec2["x_hat"]["r"][:1], rec["x_hat"]["r"]) and torch.equal(rec2["x_hat"]["d"][:1], rec["x_hat"]["d"])

@@ -292,6 +292,21 @@ def test_trained_like_recipe_is_defined_and_reproducible():
         synth.synthetic_state_dict(0, recipe="nope")
 
 
+def test_high_rate_recipe_is_defined_and_reproducible():
+    """The third synthetic weight recipe (bench.py `latency_high_rate`: symbols on CDF rows of 300 ... 3000 entries)."""
+    from rgbd_amd import synth
+
+    a = synth.synthetic_state_dict(0, recipe="high_rate", as_torch=False)
+    b = synth.synthetic_state_dict(0, recipe="high_rate", as_torch=False)
+    p = synth.synthetic_state_dict(0, recipe="plain", as_torch=False)
+    k = "g_a.depth_analysis_transform.16.weight"
+    assert np.array_equal(a[k], b[k]) and np.allclose(a[k], p[k] * synth.HIGH_RATE_GAINS[0])
+    kb = "depth_entropy_parameters_nonanchor.4.fusion.4.bias"
+    assert np.allclose(a[kb][:192], synth.HIGH_RATE_GAINS[4]) and np.array_equal(a[kb][192:], p[kb][192:])
+    with pytest.raises(ValueError):
+        synth.synthetic_state_dict(0, recipe="high_rate", model="ELIC_united_R2D")
+
+
 def test_balanced_workers_fill_every_round():
     """Engine instances for a job of K batches: as few rounds as the cap allows, every round full."""
     from rgbd_amd.pool import balanced_workers
