@@ -6,6 +6,7 @@
 #   4. PMC pass for MFMA utilisation (own run, kernel trace only for the durations)  -> <tag>_mfma_by_kernel.csv
 #   5. phase table of the timed round (conv phases / coder-only / transitions)      -> <tag>_phase_table.txt
 #   6. per-layer conv profile of one instance (tools/layer_profile.py)               -> <tag>_layer_profile_c3.txt
+#   7. kernel stats of config 5 on one instance (tools/c5_profile.sh)                 -> <tag>_c5_stf_{4,1}x512x512_w1_summary.txt
 # Counter passes run the eager launch path (RGBD_NO_GRAPH=1): every dispatch is then an ordinary kernel launch.
 # Usage: bash profiles/collect.sh r04
 set -e -o pipefail
@@ -40,6 +41,8 @@ python3 profiles/pmc_traffic.py "$out/fetch_c3" "$out/write_c3" "$out/${tag}_c3"
 python3 profiles/mfma_util.py "$out/mfma" "$out/${tag}_mfma_by_kernel.csv"
 python3 profiles/phase_table.py "$out/stats" "$out/stats.log" > "$out/${tag}_phase_table.txt"
 LAYER_RAW="entropy_param|channel_context|local_context" python3 tools/layer_profile.py 4 512 640 > "$out/${tag}_layer_profile_c3.txt" 2>&1
+# 7. config 5 (STF_united) on one engine instance, B = 4 and B = 1 -> <tag>_c5_stf_*_w1_summary.txt
+bash tools/c5_profile.sh "$tag" > /dev/null 2>&1 || echo "[collect] c5 profile failed"
 # the raw traces are large: keep the summaries
 rm -rf "$out/stats" "$out/stats_w1" "$out/fetch_c3" "$out/write_c3" "$out/mfma"
 ls "$out"
