@@ -37,6 +37,7 @@ with tempfile.TemporaryDirectory() as tmp:
         r, d = synth.synthetic_pair(i, H, W_, config_id=3, smooth=True)
         Image.fromarray((r.transpose(1, 2, 0) * 255).astype(np.uint8)).save(os.path.join(root, "rgb", f"{i:04d}.png"))
         Image.fromarray((d[0] * 9000).astype(np.uint16)).save(os.path.join(root, "depth", f"{i:04d}.png"))
+    cwd0 = os.getcwd()
     os.chdir(tmp)
     for save in SAVES:
         for w, BATCH in Ws:
@@ -52,3 +53,4 @@ with tempfile.TemporaryDirectory() as tmp:
                   f"dec {meters['avg_deocde_time'].avg*1e3:7.1f} ms", flush=True)
             if w > 1 and os.environ.get("HARNESS_STAGES"):
                 print("    host seconds per stage, all workers:", t.stage_seconds, "wall", round(n * H * W_ / t.job_mpx_per_s / 1e6, 3), flush=True)
+    os.chdir(cwd0)  # (a profiler that finalises after us wants a working directory that still exists)
