@@ -526,6 +526,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
             // and the channel group only): its round trip hides behind them instead of sitting in front of the stores
             constexpr bool PRE = EU2 <= 4;
             f32x4 r1pre[PRE ? EU2 : 1];
+            // ... and so is the second layer's bias of this group (a global load that used to sit between the staging read and
+            // the add of every write-back batch): one float4 per thread when all its slots share a channel quad (256 % S42 == 0)
+            constexpr bool BPRE = PRE && 256 % S42 == 0;
+            f32x4 b2pre = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (BPRE) b2pre = *reinterpret_cast<const f32x4*>(gbias2 + g * (G2 * 16) + (tid % S42) * 4);
             if constexpr (PRE) {
 #pragma unroll
                 for (int u = 0; u < EU2; ++u) {
@@ -598,7 +603,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int tw_log2, i
 #pragma unroll
                 for (int u = 0; u < UB2; ++u) {
                     if (!ok[u]) continue;
-                    f32x4 w = v[u] + *reinterpret_cast<const f32x4*>(gbias2 + cbs[u]);
+                    f32x4 w;
+                    if constexpr (BPRE) w = v[u] + b2pre;
+                    else w = v[u] + *reinterpret_cast<const f32x4*>(gbias2 + cbs[u]);
                     if (a.res1) w += r1[u];
                     if (a.act == ACT_RELU) {
 #pragma unroll

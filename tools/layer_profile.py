@@ -19,6 +19,10 @@ net = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
 net.load_state_dict(sd)
 net.update(force=True)
 net = net.to("cuda")
+if os.environ.get("LAYER_FORCE_FUSE"):  # rgbd_debug_force_fuse mode for the whole run (A/B of the fused-tail kernels)
+    from rgbd_amd._lib import lib
+
+    lib().rgbd_debug_force_fuse(int(os.environ["LAYER_FORCE_FUSE"]))
 net.per_image_streams = True
 r, d = synth.synthetic_batch(B, H, W, config_id=2)
 rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
