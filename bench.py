@@ -275,7 +275,10 @@ def main():
         spec.loader.exec_module(sched)
         args.workers = sched.balanced_workers(args.steps)
     if not _USER_QUEUES:
-        os.environ["GPU_MAX_HW_QUEUES"] = str(max(24, args.workers + 8))
+        # hardware queues of this process (fixed when HIP starts).  ELIC_united with 20 instances: 64 queues run the driver's
+        # command at 55.5-55.6 ms/step three times out of three, 28 at 55.4-57.1 (round 4 sweep of 16 ... 64: streams that share
+        # a queue serialise); STF_united with 16 instances wants few (24: 13.1 vs 10.3 Mpx/s with more, round 4)
+        os.environ["GPU_MAX_HW_QUEUES"] = str(64 if WORKLOADS[args.workload][4] == "ELIC_united" else max(24, args.workers + 8))
 
     import torch
 
