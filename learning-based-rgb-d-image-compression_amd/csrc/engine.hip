@@ -144,10 +144,15 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
     // table: it resolves them in one hop.
     std::vector<int32_t> coarse(nrows, -1);
     std::vector<uint32_t> pkc;
+    // (the decoder's tables without any coarse row, as rans_decode_lds_bytes counts them: a table set that fits the LDS
+    // without coarse rows must keep fitting -- rows that would not fit stay with the bucket table)
+    const size_t lds_base = (((size_t)nrows * LN + 1) & ~(size_t)1) * 8 + (((size_t)nrows + 1) & ~(size_t)1) * 8 +
+                            ((((size_t)total + 64 * (size_t)nrows) * 2 + 15) & ~(size_t)15) + (size_t)nrows * 256;
+    const size_t lds_room = lds_base < 157 * 1024 ? (157 * 1024 - lds_base) / 256 : 0;
     for (int r = 0; r < nrows; ++r) {
         const int32_t* row = cdf + (size_t)r * stride;
         const int n = sizes[r] - 1;
-        if (n <= 128 || n > 4032 || pkc.size() / 64 >= 255) continue;
+        if (n <= 128 || n > 4032 || pkc.size() / 64 >= 255 || pkc.size() / 64 >= lds_room) continue;
         coarse[r] = (int32_t)(pkc.size() / 64);
         pkc.resize(pkc.size() + 64, 0u);
         const int st = (n + 63) / 64;
