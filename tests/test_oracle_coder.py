@@ -138,3 +138,26 @@ def test_lane_edge_tables_against_reference_cpp(seed):
         d_ref.set_stream(want)
         assert d_ref.decode_stream(idx.tolist(), cdf_l, sz_l, off_l) == sym.tolist()
         assert coder.rans_decode(want, idx, ot).tolist() == sym.tolist()
+
+
+def test_coarse_edge_tables_against_reference_cpp():
+    """The table family of tests/test_gpu_coder.py::test_rows_around_the_coarse_level (rows of 128 ... 4033 slots next to narrow
+    ones, every slot, escapes on both sides) through the reference's own C++ coder: the oracle is pinned on exactly the inputs
+    the GPU decoder's coarse first level is tested with."""
+    from coder_cases import COARSE_EDGE_SLOTS, lane_edge_symbols, lane_edge_tables
+
+    ref = coder.load_reference_coder()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref needs /root/reference)")
+    cdf, sizes, offsets, rng = lane_edge_tables(0, COARSE_EDGE_SLOTS)
+    ot = coder.Tables(cdf, sizes, offsets)
+    cdf_l, sz_l, off_l = cdf.tolist(), sizes.tolist(), offsets.tolist()
+    coarse = [r for r, n in enumerate(COARSE_EDGE_SLOTS) if 128 < n <= 4032]
+    for n, rows in ((65, None), (3000, coarse), (3000, None)):
+        idx, sym = lane_edge_symbols(rng, n, sizes, offsets, rows=rows)
+        want = ref["ans"].RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf_l, sz_l, off_l)
+        assert coder.rans_encode(sym, idx, ot) == want
+        d_ref = ref["ans"].RansDecoder()
+        d_ref.set_stream(want)
+        assert d_ref.decode_stream(idx.tolist(), cdf_l, sz_l, off_l) == sym.tolist()
+        assert coder.rans_decode(want, idx, ot).tolist() == sym.tolist()
