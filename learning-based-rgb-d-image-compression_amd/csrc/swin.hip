@@ -40,13 +40,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnSet s0, LnSet s1, size
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         const float mean = sum / (float)C;
-        float sq = 0.f;
+        // the lane's sum of squared deviations: d0^2 fused onto the rounded d1^2, then the other terms in order.  (That is how
+        // the compiler contracted `sq += d * d` over the unrolled loop in rounds 1-3 -- `0 + d0 * d0 + d1 * d1` has two legal
+        // contractions -- and every STF_united stream since was coded with it; written out so that it cannot change again.
+        // Round 4 first spelled the other one, fma(d1, d1, d0 * d0): a last-bit change of the variance that moved the
+        // stf_c5 golden's stream lengths by 16 and 12 bytes and was found when its floors were re-recorded.)
+        float dv[24];
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
             const int c = lane + 64 * k;
-            const float d = c < C ? v[k] - mean : 0.f;
-            sq = __fmaf_rn(d, d, sq);
+            dv[k] = c < C ? v[k] - mean : 0.f;
         }
+        float sq = __fmaf_rn(dv[0], dv[0], __fmul_rn(dv[1], dv[1]));
+#pragma unroll
+        for (int k = 2; k < 24; ++k) sq = __fmaf_rn(dv[k], dv[k], sq);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
         const float rstd = 1.0f / sqrtf(sq / (float)C + 1e-5f);
@@ -95,14 +102,20 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(LnSet s0, LnSet s1, siz
 #pragma unroll
             for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], o);
         const float mean = ((s[0] + s[2]) + (s[1] + s[3])) / fc;
-        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        float q[4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int j = 0; j < 4; ++j) {  // the same leaf as above: d0^2 fused onto the rounded d1^2 (0 for a single pass), then in order
+            const float d0 = 4 * sub < C ? v[0][j] - mean : 0.f;
+            const float d1 = (R > 1 && 64 + 4 * sub < C) ? v[R > 1 ? 1 : 0][j] - mean : 0.f;
+            q[j] = __fmaf_rn(d0, d0, __fmul_rn(d1, d1));
+        }
+#pragma unroll
+        for (int r = 2; r < R; ++r) {
             const int c = 64 * r + 4 * sub;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float d = c < C ? v[r][j] - mean : 0.f;
-                q[j] = __fmaf_rn(d, d, q[j]);  // (explicit: left to the compiler, a lone product fuses with the tree's first add)
+                q[j] = __fmaf_rn(d, d, q[j]);
             }
         }
 #pragma unroll

@@ -230,6 +230,8 @@ def main():
         united_case("e_480x640_tl", 1, 480, 640, 3, recipe="trained_like")
     if on("f_480x640_stress"):
         united_case("f_480x640_stress", 1, 480, 640, 3)
+    if on("i_128x192_hr"):
+        united_case("i_128x192_hr", 1, 128, 192, 41, recipe="high_rate")
 
 
 if __name__ == "__main__":

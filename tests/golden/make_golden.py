@@ -7,7 +7,8 @@ Outputs (data only -- inputs are regenerated from rgbd_amd.synth, never stored):
     tests/golden/coder_kat.npz      pure-coder known answers from the reference's C++ (KAT tiny / B2 / tables)
     tests/golden/model_*.npz        ELIC_united streams, latents and reconstructions from the reference's
                                     compress()/decompress() on synthetic weights + inputs (model_e_480x640_tl: the bench's
-                                    image shape with the trained_like weights, `--only-e`)
+                                    image shape with the trained_like weights, `--only-e`; model_i_128x192_hr: the high_rate
+                                    weights, `--only-hr`)
     tests/golden/bicee_*.npz        Bi-CEE stage alone (BASELINE config 4): compress_united / decompress_united outputs
     tests/golden/elic_*.npz         single-modal ELIC (BASELINE config 1): streams, latents, reconstruction
     tests/golden/stf_*.npz          STF_united (Swin transforms; BASELINE config 5 at reduced size)
@@ -295,6 +296,12 @@ def main():
         return
     if "--only-r2d" in sys.argv:  # refresh one fixture without touching the others
         r2d_case(model_config, synth, "128x192", 1, 128, 192, 4)
+        return
+    if "--only-hr" in sys.argv:  # the high_rate weights (98 % of the symbols on CDF rows of 300 ... 3000 entries): wide rows end to end
+        net = ELIC(config=model_config(), channel=4).eval()
+        net.load_state_dict(synth.synthetic_state_dict(0, recipe="high_rate"))
+        assert net.update(force=True)
+        model_case(net, synth, "i_128x192_hr", 1, 128, 192, 41, False)
         return
     if "--only-e" in sys.argv:  # the bench's image shape (480x640 -> 512x640) with the trained-like weights (~3.6 bpp)
         net = ELIC(config=model_config(), channel=4).eval()

@@ -205,6 +205,8 @@ def main():
         united_case(ELIC, model_config, synth, "g_256x256_s1", 1, 256, 256, 2, seed=1, new=True)
     if on("h_256x256_s2"):
         united_case(ELIC, model_config, synth, "h_256x256_s2", 1, 256, 256, 2, seed=2, new=True)
+    if on("i_128x192_hr"):  # the high_rate weights (wide CDF rows); golden from make_golden.py --only-hr
+        united_case(ELIC, model_config, synth, "i_128x192_hr", 1, 128, 192, 41, recipe="high_rate")
     if on("bicee_c4_b2_8x12"):
         bicee_case(ELIC, model_config, synth, "c4_b2_8x12", 2, 8, 12, 5)
     if on("elic_c1_256x256"):

@@ -269,6 +269,15 @@ def test_elic_united_trained_like_vs_reference_golden(net_tl, gc):
     _vs_golden(net_tl, gc, "e_480x640_tl")
 
 
+def test_elic_united_high_rate_vs_reference_golden(gc):
+    """The high_rate synthetic weights (98 % of the symbols on scale-table rows of 300 ... 3000 entries: the rows the decoder
+    searches through its coarse first level) against the reference's run of the same case (make_golden.py --only-hr)."""
+    from rgbd_amd import synth
+
+    require_gpu()
+    _vs_golden(_model("ELIC_united", synth.synthetic_state_dict(0, recipe="high_rate")), gc, "i_128x192_hr")
+
+
 @pytest.mark.parametrize("name", ["a_128x192", "b_100x150", "c_b2_128x128", "d_256x256", "f_480x640_stress"])
 def test_elic_united_vs_reference_golden(net, gc, name):
     """f_480x640_stress: the bench's own operating point (c3's image shape with the stress recipe the bench runs)."""
