@@ -275,10 +275,12 @@ def main():
         spec.loader.exec_module(sched)
         args.workers = sched.balanced_workers(args.steps)
     if not _USER_QUEUES:
-        # hardware queues of this process (fixed when HIP starts).  ELIC_united with 20 instances: 64 queues run the driver's
-        # command at 55.5-55.6 ms/step three times out of three, 28 at 55.4-57.1 (round 4 sweep of 16 ... 64: streams that share
-        # a queue serialise); STF_united with 16 instances wants few (24: 13.1 vs 10.3 Mpx/s with more, round 4)
-        os.environ["GPU_MAX_HW_QUEUES"] = str(64 if WORKLOADS[args.workload][4] == "ELIC_united" else max(24, args.workers + 8))
+        # hardware queues of this process (fixed when HIP starts).  ELIC_united with 20 instances, round-4 sweep of the driver's
+        # command: 16 / 24 / 28 / 32 / 40 / 48 / 64 queues -> 58.8 / 56.9 / 56.3 / 56.0 / 55.9 / 56.4 / 55.6 ms per step (streams
+        # that share a queue serialise).  40, not 64: with 64 a torch kernel launch of the pipelined harness failed ("CUDA
+        # driver error: 1"; 48 and 40 are clean there) -- no need to sit next to that limit for 0.5 %.  STF_united with 16
+        # instances wants few (24: 30.0-30.6 vs 28.3-30.4 Mpx/s with 64)
+        os.environ["GPU_MAX_HW_QUEUES"] = str(40 if WORKLOADS[args.workload][4] == "ELIC_united" else max(24, args.workers + 8))
 
     import torch
 
