@@ -3411,6 +3411,7 @@ int rgbd_abi_version(void) { return RGBD_AMD_ABI_VERSION; }
 // hipFree -- with a pool's other threads launching in that window it produced exactly such mixed waits, and the suite hung.)
 int rgbd_set_blocking_sync(int32_t on)
 {
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // a device-wide wait: not while a stream of this process captures
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto));
     return RGBD_OK;
