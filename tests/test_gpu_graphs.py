@@ -293,6 +293,43 @@ def test_caller_side_stream_next_to_pool_then_destroy_and_close(synth_sd):
     torch.cuda.synchronize()
 
 
+def test_garbage_engine_is_gone_before_the_wait_policy_switches(synth_sd):
+    """Round 4's sighting of the `hipFree never returns` wait: an engine that had done its work under the SPINNING
+    policy sat in a reference cycle, and the cyclic collector destroyed it while a CodecPool -- which had just switched the
+    device to blocking sync -- was uploading its first instance.  The policy switch now collects garbage first and drains the
+    device: here the garbage engine must be gone (its destroy has run) by the time the pool's constructor returns, and
+    everything keeps working afterwards.  Run once under the per-test timeout; do not loop it."""
+    import gc
+    import weakref
+
+    import rgbd_amd
+    from rgbd_amd._lib import lib
+
+    require_gpu()
+    assert lib().rgbd_get_blocking_sync() == 0
+    r, d = _pair(1, 128, 192, 84)
+    lone = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    lone.load_state_dict(synth_sd)
+    lone.update(force=True)
+    lone = lone.to("cuda")
+    for _ in range(3):                   # eager, capture, replay under the spinning policy
+        want = lone.compress(r, d)
+    holder = {"net": lone}
+    holder["self"] = holder              # a cycle: only the cyclic collector can free it
+    alive = weakref.ref(lone)
+    del lone, holder
+    assert alive() is not None           # (still garbage-in-waiting)
+    pool = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=2, device="cuda", per_image_streams=False)
+    assert alive() is None               # destroyed before the switch, under the policy it ran with
+    assert lib().rgbd_get_blocking_sync() == 1
+    outs, xr, xd = pool.roundtrip(torch.cat([r, r]), torch.cat([d, d]))
+    assert all(o["shape"] == want["shape"] for o in outs)
+    pool.close()
+    gc.collect()
+    assert lib().rgbd_get_blocking_sync() == 0
+    torch.cuda.synchronize()
+
+
 def test_eval_forward_is_captured_and_replayed(net):
     """ELIC_united.forward() goes through the same prologue / captured body / epilogue split as compress(): eager, captured
     and replayed calls on a side stream return the same tensors, and new pixels in the same shape come out of the replay."""
