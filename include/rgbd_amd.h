@@ -77,6 +77,17 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
                      const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
                      int32_t act, const float* residual_dev, float* y_dev, void* stream);
 
+/* The same operator in the arithmetic of the CPU kernels the reference's conv2d / conv_transpose2d calls end in (torch CPU ->
+ * oneDNN 3.7.1 jit:avx512_core / jit_1x1:avx512_core, third-party to the reference): per output element a fresh
+ * fp32 fma chain per block of input channels (tap-major inside a block, channels ascending), the block sums added in order.
+ * blocks: channels per block (nblocks entries; NULL = one block per 16 channels, the multi-tap kernels' structure).
+ * bias_mode: 0 = sum, then + bias; 1 = S_0 + bias, then the other block sums; 2 = the first chain starts from the bias.
+ * flags bit 0: sigmoid (act 3) as torch's vectorised CPU kernel computes it; bit 1: run the blocks as split-K ranges. */
+int rgbd_conv2d_ref_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
+                         const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
+                         int32_t act, const float* residual_dev, float* y_dev, void* stream, const int32_t* blocks,
+                         int32_t nblocks, int32_t bias_mode, int32_t flags);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * The codec.  Replaces models/elic_united.py: ELIC_united.__init__ :14-86, load_state_dict :588-620,
  * update :580-586, compress :403-427 (+ compress_united :350-401, compress_one_slice :265-348),

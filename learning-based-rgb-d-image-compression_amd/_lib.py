@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librgbd_amd.so")
 _SO = os.environ.get("RGBD_AMD_LIB", _SO)  # A/B builds: point at another librgbd_amd.so
-_SRCS = ["conv_mfma.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "engine.hip"]
+_SRCS = ["conv_mfma.hip", "conv_mfma_blk.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "engine.hip"]
 _LIB = None
 
 ERRORS = {-22: "invalid argument", -12: "out of memory", -5: "HIP runtime error", -28: "buffer too small",
@@ -32,8 +32,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     csrc = os.path.join(_HERE, "csrc")
     objdir = os.path.join(csrc, "build")
-    hdrs = [os.path.join(csrc, "common.h"), os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
-    extra = {"conv_mfma.hip": [os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h")]}
+    hdrs = [os.path.join(csrc, "common.h"), os.path.join(csrc, "exact_math.h"),
+            os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
+    body = os.path.join(csrc, "conv_mfma_body.h")
+    extra = {"conv_mfma.hip": [body, os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h")],
+             "conv_mfma_blk.hip": [body]}
     hdrs.append(os.path.join(csrc, "splitk_table.h"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(objdir, exist_ok=True)
@@ -43,7 +46,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         deps = [src] + hdrs + extra.get(name, [])
         if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
-            jobs.append([hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-c", src, "-o", obj])
+            # (conv_mfma_blk.hip: MFMA results in VGPRs -- its kernels read them with vector instructions in the main loop)
+            flags = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if name == "conv_mfma_blk.hip" else []
+            jobs.append([hipcc, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17"] + flags + ["-c", src, "-o", obj])
     if not jobs and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(o) for o in objs):
         return _SO
     if verbose:
@@ -82,6 +87,8 @@ def lib():
         "rgbd_rans_decoder_destroy": (None, [c_vp]),
         "rgbd_conv2d_nchw": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32, c_i32,
                                             c_i32, c_i32, c_vp, c_vp, c_vp]),
+        "rgbd_conv2d_ref_nchw": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32, c_i32,
+                                                c_i32, c_i32, c_vp, c_vp, c_vp, i32p, c_i32, c_i32, c_i32]),
         "rgbd_pointwise_nchw": (ctypes.c_int, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_vp, c_vp]),
         "rgbd_elic_create": (ctypes.c_int, [c_i32, c_i32, i32p, c_i32, ctypes.POINTER(c_vp)]),
         "rgbd_elic_destroy": (None, [c_vp]),
@@ -142,7 +149,7 @@ def lib():
 
 EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
            "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
-           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
+           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_conv2d_ref_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats", "rgbd_layernorm", "rgbd_debug_force_layernorm_form",

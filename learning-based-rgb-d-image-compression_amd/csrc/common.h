@@ -30,6 +30,13 @@ struct Act {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Physical position of logical channel c inside its group of 16 (engines with rgbd_elic::chperm; a 4x4 transpose, its own
+// inverse).  The MFMA kernels reduce a 16-channel chunk k-step by k-step, lane group by lane group: physical channels
+// e, 4+e, 8+e, 12+e for e = 0..3.  With logical channel 4e + q stored at physical 4q + e that order IS channel 0, 1, ... 15 --
+// the order the reference's CPU kernels accumulate in -- without touching a kernel: weights are packed with
+// both channel axes permuted, and only code that tells channels apart (bias / gate vectors, quantisers, NCHW conversion) maps.
+__host__ __device__ static inline int rgbd_cperm(int c, int on = 1) { return on ? ((c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3)) : c; }
+
 // ---- convolution launcher (conv_mfma.hip) -----------------------------------------------------
 struct TapTable {
     int8_t dy[4][25];
@@ -109,6 +116,14 @@ struct ConvArgs {
     int groups;   // 0 / 1: one operand set; 2: workgroups [tiles*N, 2*tiles*N) of the work list run the same layer on g1
     ConvPtrs g1;
     TapTable taps;
+    // ---- reference arithmetic: the accumulation structure of the CPU kernels the reference runs on ----------
+    int blocked;         // 1: blocked accumulation (conv_mfma_blk.hip): a fresh fma chain per block, block sums added in order
+    int bias_mode;       // where the bias enters: 0 the epilogue (sum, then + bias), 1 the running total starts from it
+                         // (total = S_0 + bias: oneDNN's direct kernels), 2 the first chain starts from it (its 1x1 kernels)
+    int tail_bias_init;  // fused trailing / leading 1x1 layers (w2, w3): their chains start from the bias (as bias_mode 2)
+    int exact_math;      // epilogue sigmoid as the reference's vectorised CPU kernel computes it (Sleef expf_u10 + IEEE divide)
+    uint32_t blk_end[8];      // blocked: bit c set = a block ends with 16-channel chunk c (the last chunk's bit is always set)
+    uint16_t split_c16[18];   // splitk > 1 with explicit ranges: split s reduces chunks [split_c16[s], split_c16[s + 1]); all 0 = even ranges
 };
 
 // split factor of a layer: a function of the layer and of the per-image output grid only -- never of the batch size -- so
@@ -159,9 +174,9 @@ int conv_log_enable(int on);            // shape log for tools/tune_tiles.py
 long conv_log_read(char* buf, long cap);  // CSV text; returns the size needed
 
 // ---- pointwise kernels (pointwise.hip) --------------------------------------------------------
-int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s);
+int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s, int perm = 0);
 int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int cs, float* dst, int clamp01,
-                              hipStream_t s);
+                              hipStream_t s, int perm = 0);
 // x1 / y1 (both or neither): a second tensor pair of the same shape handled by the same launch (the other modality's ESA branch)
 int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s,
                       const float* x1 = nullptr, float* y1 = nullptr);

@@ -221,7 +221,9 @@ struct PackedConv {
     bool subpix = false;  // pack_subpix(): [16 = phase * 4 + cout][9 taps][cin_pad] of a k = 5, stride-2 transposed conv
 };
 
-int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedConv* pc, DevGen* gen = nullptr)
+// perm_in / perm_out: store the input / output channels at their permuted positions (rgbd_cperm)
+int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedConv* pc, DevGen* gen = nullptr, int perm_in = 0,
+              int perm_out = 0)
 {
     if (w.shape.size() != 4 || w.shape[2] != w.shape[3]) return RGBD_EINVAL;
     const int k = (int)w.shape[2];
@@ -239,12 +241,12 @@ int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedC
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < k * k; ++t) {
                 const size_t src = transposed ? (((size_t)ci * cout + co) * k * k + t) : (((size_t)co * cin + ci) * k * k + t);
-                h[((size_t)co * k * k + t) * pc->cin_pad + ci] = w.v[src];
+                h[((size_t)rgbd_cperm(co, perm_out) * k * k + t) * pc->cin_pad + rgbd_cperm(ci, perm_in)] = w.v[src];
             }
     std::vector<float> hb(pc->cout_pad, 0.f);
     if (b) {
         if ((int)b->v.size() != cout) return RGBD_EINVAL;
-        memcpy(hb.data(), b->v.data(), sizeof(float) * cout);
+        for (int co = 0; co < cout; ++co) hb[rgbd_cperm(co, perm_out)] = b->v[co];
     }
     HIP_TRY(hipMalloc((void**)&pc->w, n * sizeof(float)));
     if (gen) gen->p.push_back(pc->w);  // registered at once: a later failure leaves nothing behind
@@ -3610,9 +3612,58 @@ void rgbd_rans_decoder_destroy(rgbd_rans_decoder* d)
     delete d;
 }
 
+// blocked accumulation for a layer of cin_pad channels: block boundaries (in channels, multiples of 16) -> ConvArgs::blk_end
+static int set_blocks(ConvArgs* a, const int32_t* blocks, int nblocks)
+{
+    memset(a->blk_end, 0, sizeof(a->blk_end));
+    const int n16 = a->cin_pad / 16;
+    if (n16 > 256) return RGBD_EINVAL;
+    if (!blocks || nblocks <= 0) {  // every 16-channel chunk is a block (the multi-tap kernels of the reference's CPU library)
+        for (int c = 0; c < n16; ++c) a->blk_end[c >> 5] |= 1u << (c & 31);
+    } else {
+        int pos = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            if (blocks[b] <= 0 || (blocks[b] % 16 && b + 1 < nblocks)) return RGBD_EINVAL;
+            pos += blocks[b];
+            const int c = (pos + 15) / 16 - 1;
+            if (c >= n16) return RGBD_EINVAL;
+            a->blk_end[c >> 5] |= 1u << (c & 31);
+        }
+        if ((pos + 15) / 16 != n16) return RGBD_EINVAL;
+    }
+    a->blocked = 1;
+    return RGBD_OK;
+}
+
+static int conv2d_nchw_impl(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
+                            const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
+                            int32_t act, const float* residual_dev, float* y_dev, void* stream, int refmode,
+                            const int32_t* blocks, int32_t nblocks, int32_t bias_mode, int32_t flags);
+
 int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
                      const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
                      int32_t act, const float* residual_dev, float* y_dev, void* stream)
+{
+    return conv2d_nchw_impl(x_dev, n, cin, h, w, weight, bias, cout, k, stride, pad, transposed, act, residual_dev, y_dev, stream,
+                            0, nullptr, 0, 0, 0);
+}
+
+// The same layer in the reference's CPU arithmetic: channels stored permuted (rgbd_cperm), accumulation in
+// blocks (`blocks`: channels per block, nullptr = one block per 16 channels), bias_mode as ConvArgs::bias_mode.
+// flags bit 0: sigmoid as the reference's vector kernel computes it; bit 1: reduce the blocks as split-K ranges (1x1 layers)
+int rgbd_conv2d_ref_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
+                         const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
+                         int32_t act, const float* residual_dev, float* y_dev, void* stream, const int32_t* blocks,
+                         int32_t nblocks, int32_t bias_mode, int32_t flags)
+{
+    return conv2d_nchw_impl(x_dev, n, cin, h, w, weight, bias, cout, k, stride, pad, transposed, act, residual_dev, y_dev, stream,
+                            1, blocks, nblocks, bias_mode, flags);
+}
+
+static int conv2d_nchw_impl(const float* x_dev, int32_t n, int32_t cin, int32_t h, int32_t w, const float* weight,
+                            const float* bias, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t transposed,
+                            int32_t act, const float* residual_dev, float* y_dev, void* stream, int refmode,
+                            const int32_t* blocks, int32_t nblocks, int32_t bias_mode, int32_t flags)
 {
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (!x_dev || !weight || !y_dev || n <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k > 5 || stride < 1 || stride > 2)
@@ -3626,8 +3677,10 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
         hb.v.assign(bias, bias + cout);
     }
     PackedConv pc;
-    const bool subpix = transposed && g_subpix == 2 && cout <= 4 && k == 5 && stride == 2 && pad == 2 && !residual_dev;
-    int rc = subpix ? pack_subpix(hw, bias ? &hb : nullptr, &pc, nullptr) : pack_conv(hw, bias ? &hb : nullptr, transposed != 0, &pc);
+    const bool subpix = !refmode && transposed && g_subpix == 2 && cout <= 4 && k == 5 && stride == 2 && pad == 2 && !residual_dev;
+    const int perm = refmode ? 1 : 0;
+    int rc = subpix ? pack_subpix(hw, bias ? &hb : nullptr, &pc, nullptr)
+                    : pack_conv(hw, bias ? &hb : nullptr, transposed != 0, &pc, nullptr, perm, perm);
     if (rc) return rc;
     int OH, OW;
     if (!transposed) {
@@ -3641,10 +3694,10 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
     const size_t xb = (size_t)n * h * w * pc.cin_pad * sizeof(float), yb = (size_t)n * OH * OW * pc.cout_pad * sizeof(float);
     HIP_TRY(hipMalloc((void**)&xin, xb));
     HIP_TRY(hipMalloc((void**)&yout, yb));
-    rc = launch_nchw_to_nhwc16(x_dev, n, cin, h, w, xin, pc.cin_pad, s);
+    rc = launch_nchw_to_nhwc16(x_dev, n, cin, h, w, xin, pc.cin_pad, s, perm);
     if (!rc && residual_dev) {
         HIP_TRY(hipMalloc((void**)&res, yb));
-        rc = launch_nchw_to_nhwc16(residual_dev, n, cout, OH, OW, res, pc.cout_pad, s);
+        rc = launch_nchw_to_nhwc16(residual_dev, n, cout, OH, OW, res, pc.cout_pad, s, perm);
     }
     if (!rc) {
         ConvArgs a{};
@@ -3676,20 +3729,38 @@ int rgbd_conv2d_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, int3
             a.r1cs = pc.cout_pad;
         }
         float* part = nullptr;
-        a.splitk = g_force_splitk > 0 ? std::min(g_force_splitk, pc.cin_pad / 16) : 1;
+        a.splitk = (g_force_splitk > 0 && !refmode) ? std::min(g_force_splitk, pc.cin_pad / 16) : 1;
+        if (refmode) {
+            a.bias_mode = bias_mode;
+            a.exact_math = flags & 1;
+            if ((flags & 2) && blocks && nblocks > 1 && nblocks <= 16) {  // the blocks as split-K ranges of the single-chain kernel
+                a.splitk = nblocks;
+                int pos = 0;
+                for (int b = 0; b < nblocks; ++b) {
+                    a.split_c16[b] = (uint16_t)(pos / 16);
+                    pos += blocks[b];
+                }
+                a.split_c16[nblocks] = (uint16_t)((pos + 15) / 16);
+                if (bias_mode == 1) rc = RGBD_EINVAL;
+            } else if (blocks && nblocks == 1) {
+                if (bias_mode == 1) bias_mode = a.bias_mode = 0, rc = RGBD_OK;  // (one block: S_0 + bias is the epilogue's add)
+            } else {
+                rc = set_blocks(&a, blocks, nblocks);
+            }
+        }
         if (a.splitk > 1) {
             HIP_TRY(hipMalloc((void**)&part, (size_t)a.splitk * yb));
             a.partial = part;
         }
         a.ckbd = g_force_ckbd;
         if (a.ckbd) HIP_TRY(hipMemsetAsync(yout, 0, yb, s));  // the half that is not computed reads as zero
-        rc = launch_conv(a, s);
+        if (!rc) rc = launch_conv(a, s);
         if (part) {
             (void)hipStreamSynchronize(s);
             (void)hipFree(part);
         }
     }
-    if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, cout, OH, OW, pc.cout_pad, y_dev, 0, s);
+    if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, cout, OH, OW, pc.cout_pad, y_dev, 0, s, perm);
     hipError_t e = hipStreamSynchronize(s);
     if (!rc && e != hipSuccess) rc = RGBD_EHIP;
     (void)hipFree(xin);

@@ -17,7 +17,7 @@ static inline unsigned grid_for(size_t work, int block = 256, unsigned cap = 256
 
 // ---------------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc16_kernel(const float* __restrict__ src, int N, int C, int H, int W, float* __restrict__ dst,
-                                      int cs)
+                                      int cs, int perm)
 {
     const size_t npix = (size_t)N * H * W;
     const int c4n = cs / 4;
@@ -29,23 +29,23 @@ __global__ void nchw_to_nhwc16_kernel(const float* __restrict__ src, int N, int 
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = c4 * 4 + e;
+            const int c = rgbd_cperm(c4 * 4 + e, perm);  // the logical channel stored at this physical position
             v[e] = c < C ? src[(n * C + c) * (size_t)H * W + hw] : 0.f;
         }
         *reinterpret_cast<f32x4*>(dst + pix * cs + c4 * 4) = v;
     }
 }
 
-int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s)
+int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s, int perm)
 {
     const size_t work = (size_t)N * H * W * (cs / 4);
-    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, N, C, H, W, dst, cs);
+    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, N, C, H, W, dst, cs, perm);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int N, int C, int H, int W, int cs,
-                                    float* __restrict__ dst, int clamp01)
+                                    float* __restrict__ dst, int clamp01, int perm)
 {
     const size_t total = (size_t)N * C * H * W;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -53,17 +53,17 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int N, int C,
         const size_t nc = i / ((size_t)H * W);
         const int c = (int)(nc % C);
         const size_t n = nc / C;
-        float v = src[(n * H * W + hw) * cs + c];
+        float v = src[(n * H * W + hw) * cs + rgbd_cperm(c, perm)];
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
         dst[i] = v;
     }
 }
 
 int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int cs, float* dst, int clamp01,
-                              hipStream_t s)
+                              hipStream_t s, int perm)
 {
     const size_t work = (size_t)N * C * H * W;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, N, C, H, W, cs, dst, clamp01);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, N, C, H, W, cs, dst, clamp01, perm);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
