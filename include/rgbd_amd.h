@@ -95,6 +95,17 @@ int rgbd_conv2d_ref_nchw(const float* x_dev, int32_t n, int32_t cin, int32_t h, 
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct rgbd_elic rgbd_elic;
 
+/* Reference arithmetic.  An engine created for ELIC_united / ELIC / ELIC_united_R2D computes every float that
+ * feeds a coding decision in the accumulation order of the CPU kernels the reference runs on (torch CPU 2.10 -> oneDNN 3.7.1 /
+ * MKL / Sleef; third-party to the reference).  Where that order depends on the layer shape -- the reduce blocks of oneDNN's 1x1
+ * convolution kernel (kind 0) -- it is data measured on the reference machine and handed over here, per
+ * (cin, cout, input h, w, batch of the reference call): blocks[0..nblocks) = channels per block.  Shapes without an entry
+ * run as a single block.  rgbd_elic_get_refnum: 1 when the engine uses this arithmetic (STF_united: 0). */
+int rgbd_elic_set_ref_blocks(rgbd_elic* m, int32_t kind, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t batch,
+                             const int32_t* blocks, int32_t nblocks);
+int rgbd_elic_get_refnum(const rgbd_elic* m);
+int rgbd_elic_ref_table_misses(const rgbd_elic* m);
+
 /* A second instance that borrows `src`'s packed device weights and tables (own workspace, own stream): several
  * instances on one GPU then cost one weight copy.  `src` must outlive the clone. */
 int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out);

@@ -180,20 +180,36 @@ int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int 
 // x1 / y1 (both or neither): a second tensor pair of the same shape handled by the same launch (the other modality's ESA branch)
 int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int OH, int OW, hipStream_t s,
                       const float* x1 = nullptr, float* y1 = nullptr);
+// ref_channels > 0: the reference's CPU arithmetic (see bilinear_kernel) for a tensor of that many channels, stored permuted
 int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s, const float* x1 = nullptr,
-                    float* y1 = nullptr);
+                    float* y1 = nullptr, int ref_channels = 0);
 int launch_channel_mean(const float* x, int N, int HW, int cs, int C, float* mean, hipStream_t s);
 int launch_channel_mean_strided(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s);
 int launch_channel_scale_to_strided(const float* x, int N, int HW, int xcs, int C, const float* scale, int sstride, int mode,
                                     float* y, int ycs, hipStream_t s);
 // w1t is fc.2.weight transposed to [hidden][C]; hid is a [N][hidden] scratch buffer
 // mstride: distance between the images' mean vectors (0 = C: packed)
+// perm: the mean / scale vectors are indexed by channel POSITION (rgbd_cperm), the FC weights by channel
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
-                 float* scale, hipStream_t s, int mstride = 0);
+                 float* scale, hipStream_t s, int mstride = 0, int perm = 0);
 // mode 0: y = x*s ; mode 1: y = x + x*s   (s per (n, c))
 int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const float* scale, int mode, float* y, int ycs,
                             hipStream_t s);
 int launch_copy_channels(const float* src, int scs, float* dst, int dcs, int npix, int C, hipStream_t s);
+// small-tensor convolution in the reference's im2col + sgemm arithmetic (pointwise.hip: small_conv_ref_kernel)
+struct SmallConvArgs {
+    const float* x;
+    const float* w;     // the MFMA kernels' packed weights [cout_pad][ntaps][cin_pad], read in place
+    const float* bias;
+    const float* res1;  // added before the activation (optional)
+    const float* mul;   // multiplied after the activation (optional)
+    const float* res2;  // added last (optional)
+    float* y;
+    float* y2;          // optional second destination
+    int N, H, W, xcs, C, cin_pad, O, OH, OW, ycs, r1cs, mcs, r2cs, y2cs, K, stride, pad, act, nb;
+    int kb[17];         // K-block boundaries in k = c * K * K + ky * K + kx
+};
+int launch_small_conv_ref(const SmallConvArgs& a, hipStream_t s);
 int launch_fill_zero(float* p, size_t n, hipStream_t s);
 // packed input of the first analysis conv: y[n][oy][ox][KP], see im2col5s2_kernel
 int launch_im2col5s2(const float* x, int N, int H, int W, int cs, int C, float* y, int OH, int OW, int KP, hipStream_t s);
@@ -239,6 +255,7 @@ struct PartGeom {
     int C;  // channels of this slice
     int anchor;  // 1 = anchor positions
     int per_image;  // 1: one stream per image; 0: one stream for the batch (reference B>1 format)
+    int perm;       // 1: the tensors store channels at their permuted positions (rgbd_cperm); symbols stay in logical order
 };
 
 int launch_ckbd_encode_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs,
@@ -250,12 +267,13 @@ int launch_ckbd_decode_part(const float* params, int pcs, float* yhat, int yhcs,
                             const int64_t* stream_base, int64_t part_off_per_image, hipStream_t s);
 int launch_ckbd_estimate_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs, float* lik,
                               int lcs, PartGeom g, hipStream_t s);
+// perm: z / zhat / lik store their channels permuted (rgbd_cperm); medians, prm and the symbol order are logical
 int launch_eb_forward(const float* z, int zcs, int B, int h, int w, int C, const float* med, const float* prm, float* zhat,
-                      float* lik, hipStream_t s);
+                      float* lik, hipStream_t s, int perm = 0);
 int launch_z_quant(const float* z, int zcs, int B, int h, int w, int C, const float* medians, int32_t* sym,
-                   int32_t* idx, hipStream_t s);
+                   int32_t* idx, hipStream_t s, int perm = 0);
 int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float* medians, float* zhat, int zcs,
-                     hipStream_t s);
+                     hipStream_t s, int perm = 0);
 
 // One wave per stream.  counts[s] symbols starting at sym_base[s]; writes words backwards into
 // out + s*cap_words; out_words[s] receives the number of 32-bit words produced (stream = last out_words words).

@@ -3,6 +3,7 @@
 // Mirrors the call structure of the reference's models/elic_united.py:350-578 but keeps every tensor, symbol,
 // index and bitstream resident in HBM; the only device->host traffic is the finished streams.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -263,7 +264,7 @@ int pack_conv(const HostTensor& w, const HostTensor* b, bool transposed, PackedC
 // element ky = ry + 2 - 2 dy, kx = rx + 2 - 2 dx when that is inside the kernel, else a zero weight; the taps run dy, dx =
 // 1, 0, -1, which keeps every phase's real taps in the order make_taps() gives them -- with fma(0, x, acc) == acc the
 // value of every output is the same chain as in the per-phase form (tests/test_gpu_conv.py::test_subpixel_deconv).
-int pack_subpix(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen* gen)
+int pack_subpix(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen* gen, int perm_in = 0)
 {
     if (w.shape.size() != 4 || w.shape[2] != 5 || w.shape[3] != 5 || w.shape[1] > 4) return RGBD_EINVAL;
     const int cin = (int)w.shape[0], cout = (int)w.shape[1];
@@ -285,7 +286,7 @@ int pack_subpix(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen
                     const int ky = ry + 2 - 2 * dy, kx = rx + 2 - 2 * dx;
                     if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
                     for (int ci = 0; ci < cin; ++ci)
-                        h[((size_t)row * 9 + u) * pc->cin_pad + ci] = w.v[(((size_t)ci * cout + co) * 5 + ky) * 5 + kx];
+                        h[((size_t)row * 9 + u) * pc->cin_pad + rgbd_cperm(ci, perm_in)] = w.v[(((size_t)ci * cout + co) * 5 + ky) * 5 + kx];
                 }
             }
     HIP_TRY(hipMalloc((void**)&pc->w, h.size() * sizeof(float)));
@@ -299,7 +300,7 @@ int pack_subpix(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen
 
 // Conv2d(cin <= 3 -> cout, k 5, stride 2, pad 2) as a 1x1 layer over the packed input of launch_im2col5s2: weight of
 // term n = tap * cin + c at packed index (n / 16) * 16 + (n % 4) * 4 + (n % 16) / 4
-int pack_kpack(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen* gen)
+int pack_kpack(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen* gen, int perm_out = 0)
 {
     if (w.shape.size() != 4 || w.shape[2] != 5 || w.shape[3] != 5 || w.shape[1] > 3) return RGBD_EINVAL;
     const int cout = (int)w.shape[0], cin = (int)w.shape[1], nterm = 25 * cin;
@@ -312,7 +313,7 @@ int pack_kpack(const HostTensor& w, const HostTensor* b, PackedConv* pc, DevGen*
             const int t = n / cin, c = n % cin, r = n % 16;
             w1.v[(size_t)co * KP + (n / 16) * 16 + (r % 4) * 4 + r / 4] = w.v[((size_t)co * cin + c) * 25 + t];
         }
-    const int rc = pack_conv(w1, b, false, pc, gen);
+    const int rc = pack_conv(w1, b, false, pc, gen, 0, perm_out);
     pc->cin = nterm;  // FLOP accounting: the real reduction length
     return rc;
 }
@@ -566,6 +567,35 @@ struct rgbd_elic {
     float* dbg_s = nullptr;
 
     bool is_clone = false;  // created by rgbd_elic_clone_shared: shares the parent's buffer generations (DevGen)
+
+    // ---- reference arithmetic ----------------------------------------------------------------------
+    // refnum: every float operation that feeds a coding decision is performed in the order and with the roundings of the CPU
+    // kernels the reference runs on (torch CPU: oneDNN convolutions, Sleef sigmoid, ...): blocked accumulation in the
+    // convolutions (conv_mfma_blk.hip), channels stored permuted inside their groups of 16 (rgbd_cperm) so that the MFMA
+    // k order is ascending channels.  STF_united keeps the k-ordered single-chain arithmetic of rounds 1-4 (its channel
+    // slices are not 16-aligned).  ref_blocks: the reduce blocks of the reference's 1x1 kernels per layer shape, measured on
+    // the reference machine (tools/refarith/discover.py -> refarith_tables.json -> rgbd_elic_set_ref_blocks).
+    bool refnum = getenv("RGBD_LEGACY_NUMERICS") == nullptr;
+    int ref_batch = 1;  // the batch size of the reference call this call stands for (per-image streams: 1)
+    struct RefTables {
+        // kind 0 (1x1 reduce blocks): {0, cin, cout, h, w, batch} -> channels per block
+        // kind 1 (small-tensor path, im2col + sgemm): {1, cin, cout, h, w, k * 100 + stride * 10 + pad} -> K-block lengths
+        std::map<std::array<int, 6>, std::vector<int>> blocks;
+        int misses = 0;
+    };
+    std::shared_ptr<RefTables> ref_tab = std::make_shared<RefTables>();
+    int perm() const { return refnum ? 1 : 0; }
+    const std::vector<int>* ref_blocks(int kind, int cin, int cout, int h, int w, int last = -1) const
+    {
+        auto it = ref_tab->blocks.find({kind, cin, cout, h, w, last < 0 ? ref_batch : last});
+        if (it == ref_tab->blocks.end()) {
+            ++ref_tab->misses;
+            static const bool warn = getenv("RGBD_REFARITH_DEBUG") != nullptr;
+            if (warn) fprintf(stderr, "[rgbd_amd] no reference block table for kind %d cin %d cout %d %dx%d batch %d\n", kind, cin, cout, h, w, ref_batch);
+            return nullptr;
+        }
+        return &it->second;
+    }
 
     // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
     bool profile = false;
@@ -1030,6 +1060,7 @@ struct rgbd_elic {
             else if (splittable && g_force_splitk >= 0)
                 if (const int t = conv_splitk_table(a.cin_pad, a.cout_pad, mt, (long)OH * OW, a.nphase)) a.splitk = t;
         }
+        if (refnum) plan_refnum(cp, name, pc, pc2, pc3, sp != nullptr, x, stride, OH, OW);
         // split-K partial planes; a GELU layer (STF_united's MLP) also goes through the reducer, with a single plane
         cp.partial_bytes = (a.splitk > 1 || a.act == ACT_GELU) ? (size_t)a.splitk * x.n * OH * OW * pc->cout_pad * sizeof(float) : 0;
         cp.flops = 2.0 * (double)x.n * OH * OW * (double)pc->cout * pc->cin * k * k /
@@ -1039,6 +1070,72 @@ struct rgbd_elic {
         cp.fused = pc2 != nullptr;
         cp.ok = !dry();
         return cp;
+    }
+
+    // The accumulation structure of the reference's CPU kernel for this layer (oracle/cpu_arith.c is the C
+    // restatement the GPU results are compared with, bit for bit):
+    //   conv, k > 1 (oneDNN jit:avx512_core)      a block per 16 input channels; (S_0 + bias) + S_1 + ...
+    //   conv, 1x1   (oneDNN jit_1x1:avx512_core)  the layer shape's reduce blocks (ref_blocks); the first chain starts at the bias
+    //   conv_transpose2d, stride 1                a block per 16 input channels; bias last
+    // Layers with no decision behind them that have a faster special form keep it (the image-producing sub-pixel layer);
+    // stride-2 transposed convs: see deconv_s2_ref().
+    void plan_refnum(ConvPlan& cp, const std::string& name, const PackedConv* pc, const PackedConv* pc2, const PackedConv* pc3,
+                     bool subpix, const Act& x, int stride, int OH, int OW)
+    {
+        ConvArgs& a = cp.a;
+        a.exact_math = 1;
+        const bool kpacked = name.size() > 6 && name.compare(name.size() - 6, 6, ".kpack") == 0;
+        if (subpix || kpacked || (pc->transposed && stride != 1)) return;  // (single chain, bias in the epilogue)
+        if (pc2) a.tail_bias_init = 1;  // the fused 1x1 tails: one reduce block (fusable_ref() has checked), chains start at the bias
+        (void)pc3;
+        if (pc->k == 1 && !pc->transposed) {
+            a.bias_mode = 2;
+            const std::vector<int>* bl = ref_blocks(0, pc->cin, pc->cout, x.h, x.w);
+            if (!bl || bl->size() <= 1) {
+                a.splitk = 1;  // one block: the single-chain kernel with the bias in front
+                return;
+            }
+            const int nb = (int)bl->size();
+            // small grids: the blocks as split-K ranges (the ordered reducer adds the block sums); large maps: in the kernel
+            const bool split = (long)OH * OW <= 2048 && nb <= 16 && !pc2;
+            if (split) {
+                a.splitk = nb;
+                int pos = 0;
+                for (int b = 0; b < nb; ++b) {
+                    a.split_c16[b] = (uint16_t)(pos / 16);
+                    pos += (*bl)[b];
+                }
+                a.split_c16[nb] = (uint16_t)((pos + 15) / 16);
+            } else {
+                a.splitk = 1;
+                if (set_blocks_of(&a, bl->data(), nb)) fail(RGBD_EINVAL);
+            }
+            return;
+        }
+        a.splitk = 1;
+        a.bias_mode = pc->transposed ? 0 : 1;
+        if (set_blocks_of(&a, nullptr, 0)) fail(RGBD_EINVAL);
+    }
+    static int set_blocks_of(ConvArgs* a, const int* blocks, int nblocks)
+    {
+        memset(a->blk_end, 0, sizeof(a->blk_end));
+        const int n16 = a->cin_pad / 16;
+        if (n16 > 256) return RGBD_EINVAL;
+        if (!blocks || nblocks <= 0) {
+            for (int c = 0; c < n16; ++c) a->blk_end[c >> 5] |= 1u << (c & 31);
+        } else {
+            int pos = 0;
+            for (int b = 0; b < nblocks; ++b) {
+                if (blocks[b] <= 0 || (blocks[b] % 16 && b + 1 < nblocks)) return RGBD_EINVAL;
+                pos += blocks[b];
+                const int c = (pos + 15) / 16 - 1;
+                if (c >= n16) return RGBD_EINVAL;
+                a->blk_end[c >> 5] |= 1u << (c & 31);
+            }
+            if ((pos + 15) / 16 != n16) return RGBD_EINVAL;
+        }
+        a->blocked = 1;
+        return RGBD_OK;
     }
 
     // can the two plans share a launch?  Same layer shape, strides and epilogue, operand by operand
@@ -1054,7 +1151,9 @@ struct rgbd_elic {
                a.mcs == b.mcs && !a.res2 == !b.res2 && a.r2cs == b.r2cs && a.splitk == b.splitk && a.loaded == b.loaded &&
                a.ckbd == b.ckbd && !a.y2 == !b.y2 && a.y2cs == b.y2cs && a.subpix == b.subpix && !a.w2 == !b.w2 &&
                a.cout2_pad == b.cout2_pad && a.act_mid == b.act_mid && !a.w3 == !b.w3 && a.y3cs == b.y3cs &&
-               a.cout3_pad == b.cout3_pad && memcmp(&a.taps, &b.taps, sizeof(TapTable)) == 0;
+               a.cout3_pad == b.cout3_pad && memcmp(&a.taps, &b.taps, sizeof(TapTable)) == 0 && a.blocked == b.blocked &&
+               a.bias_mode == b.bias_mode && a.tail_bias_init == b.tail_bias_init && a.exact_math == b.exact_math &&
+               memcmp(a.blk_end, b.blk_end, sizeof(a.blk_end)) == 0 && memcmp(a.split_c16, b.split_c16, sizeof(a.split_c16)) == 0;
     }
 
     // launch one plan, or two plans as one grouped launch (q != nullptr: the caller has checked pairable())
@@ -1142,11 +1241,78 @@ struct rgbd_elic {
         return true;
     }
 
+    // The reference's small-tensor route (torch ConvParams::use_mkldnn is false: batch 1, kernel <= 3, <= 20480 input
+    // elements -> im2col + MKL sgemm): its own accumulation order, k = c -> ky -> kx in K blocks.
+    bool small_tensor_layer(const std::string& name, const Act& x) const  // (x: any tensor on the layer's input grid)
+    {
+        if (!refnum || ref_batch != 1) return false;
+        auto it = convs.find(name + ".weight");
+        if (it == convs.end()) return false;
+        const PackedConv& pc = it->second;
+        return !pc.transposed && !pc.subpix && pc.k <= 3 && (long)pc.cin * x.h * x.w <= 20480;
+    }
+    Act conv_small(const std::string& name, const Act& x, int stride, int pad, const Epi& ep, const Act* dst)
+    {
+        const PackedConv* pc = conv_of(name + ".weight");
+        if (!pc) return Act();
+        const int k = pc->k, OH = (x.h + 2 * pad - k) / stride + 1, OW = (x.w + 2 * pad - k) / stride + 1;
+        Act y = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
+        if (dry() || rc) return y;
+        if (ep.ckbd || y.h != OH || y.w != OW || y.c != pc->cout) {
+            fail(RGBD_EINVAL);
+            return y;
+        }
+        SmallConvArgs a{};
+        a.x = x.p;
+        a.w = pc->w;
+        a.bias = pc->bias;
+        a.y = y.p;
+        a.N = x.n;
+        a.H = x.h;
+        a.W = x.w;
+        a.xcs = x.cs;
+        a.C = pc->cin;
+        a.cin_pad = pc->cin_pad;
+        a.O = pc->cout;
+        a.OH = OH;
+        a.OW = OW;
+        a.ycs = y.cs;
+        a.K = k;
+        a.stride = stride;
+        a.pad = pad;
+        a.act = ep.act;
+        if (ep.res1) a.res1 = ep.res1->p, a.r1cs = ep.res1->cs;
+        if (ep.mul) a.mul = ep.mul->p, a.mcs = ep.mul->cs;
+        if (ep.res2) a.res2 = ep.res2->p, a.r2cs = ep.res2->cs;
+        if (ep.dup) a.y2 = ep.dup->p, a.y2cs = ep.dup->cs;
+        const int Kt = pc->cin * k * k;
+        const std::vector<int>* bl = ref_blocks(1, pc->cin, pc->cout, x.h, x.w, k * 100 + stride * 10 + pad);
+        a.nb = 1;
+        a.kb[0] = 0;
+        a.kb[1] = Kt;
+        if (bl && bl->size() <= 16) {
+            int pos = 0;
+            a.nb = (int)bl->size();
+            for (int b = 0; b < a.nb; ++b) {
+                pos += (*bl)[b];
+                a.kb[b + 1] = pos;
+            }
+            if (pos != Kt) {
+                fail(RGBD_EINVAL);
+                return y;
+            }
+        }
+        const int r = launch_small_conv_ref(a, s);
+        if (r) fail(r);
+        return y;
+    }
+
     Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
              const std::string* fuse1x1 = nullptr, const std::string* lead1x1 = nullptr, const Act* lead_dst = nullptr)
     {
         Act out;
         if (!fuse1x1 && conv_kpacked(name, x, stride, pad, ep, dst, &out)) return out;
+        if (!fuse1x1 && small_tensor_layer(name, x)) return conv_small(name, x, stride, pad, ep, dst);
         ConvPlan cp = conv_plan(name, x, stride, pad, ep, dst, fuse1x1, lead1x1, lead_dst);
         conv_issue(cp);
         return cp.y;
@@ -1203,6 +1369,10 @@ struct rgbd_elic {
                 return;
             }
         }
+        if (!fuse1x1 && small_tensor_layer(n[0], x[0]) && small_tensor_layer(n[1], x[1])) {
+            for (int m = 0; m < 2; ++m) out[m] = conv_small(n[m], x[m], stride, pad, ep[m], dst ? dst[m] : nullptr);
+            return;
+        }
         ConvPlan p[2];
         for (int m = 0; m < 2; ++m)
             p[m] = conv_plan(n[m], x[m], stride, pad, ep[m], dst ? dst[m] : nullptr, fuse1x1 ? fuse1x1[m] : nullptr,
@@ -1250,17 +1420,27 @@ struct rgbd_elic {
         if (a == convs.end() || b == convs.end()) return false;
         const PackedConv &p3 = a->second, &p1 = b->second;
         if (p3.transposed || p1.transposed || p1.k != 1 || p3.k != 3 || p1.cin_pad != p3.cout_pad || p1.cout % 16) return false;
+        if (refnum) {  // the fused tail runs its 1x1 as one chain: only when the reference's kernel has one reduce block there
+            if (small_tensor_layer(mid, x) || small_tensor_layer(last, x)) return false;
+            const std::vector<int>* bl = ref_blocks(0, p1.cin, p1.cout, x.h, x.w);
+            if (bl && bl->size() > 1) return false;
+        }
         return conv_fused_plan(p3.cout_pad, p1.cout_pad, p3.k * p3.k, x.n * groups, x.h, x.w, tile_mode) > 0;
     }
 
     // ... and can the leading 1x1 + ReLU of the block after it ride along?  (its input is this block's output)
-    bool lead_fusable(const std::string& last, const std::string& lead)
+    bool lead_fusable(const std::string& last, const std::string& lead, const Act& x)
     {
         static const bool off = getenv("RGBD_NO_FUSE_LEAD") != nullptr;
         if (off || g_fuse_lead_off || lead.empty()) return false;
         auto b = convs.find(last + ".weight"), c = convs.find(lead + ".weight");
         if (b == convs.end() || c == convs.end()) return false;
         const PackedConv &p1 = b->second, &p0 = c->second;
+        if (refnum) {  // (as in fusable(): the leading 1x1 rides along only as a single reduce block)
+            if (small_tensor_layer(lead, x)) return false;
+            const std::vector<int>* bl = ref_blocks(0, p0.cin, p0.cout, x.h, x.w);
+            if (bl && bl->size() > 1) return false;
+        }
         return !p0.transposed && p0.k == 1 && p0.cin_pad == p1.cout_pad && p0.cout_pad == p1.cin_pad && p0.cout % 16 == 0 &&
                p1.cout_pad % 32 == 0;
     }
@@ -1287,7 +1467,7 @@ struct rgbd_elic {
         Act out = dst ? *dst : alloc(x.n, x.h, x.w, last->cout);
         const std::string last_name = p + ".branch.4";
         const bool fuse = fusable(p + ".branch.2", last_name, x);
-        const bool lead = fuse && lead_fusable(last_name, next_lead);
+        const bool lead = fuse && lead_fusable(last_name, next_lead, x);
         Act lead_out;
         if (lead) lead_out = alloc(x.n, x.h, x.w, convs.find(next_lead + ".weight")->second.cout);  // outlives this block
         const size_t mark = arena.top;
@@ -1317,7 +1497,7 @@ struct rgbd_elic {
         Act out = alloc(x.n, x.h, x.w, x.c);
         const std::string last_name = p + ".conv.4";
         const bool fuse = fusable(p + ".conv.2", last_name, x);
-        const bool lead = fuse && lead_fusable(last_name, next_lead);
+        const bool lead = fuse && lead_fusable(last_name, next_lead, x);
         Act lead_out;
         if (lead) lead_out = alloc(x.n, x.h, x.w, convs.find(next_lead + ".weight")->second.cout);
         const size_t mark = arena.top;
@@ -1403,7 +1583,7 @@ struct rgbd_elic {
             // when pairable() fails), each of them is re-planned at N -- so fusing has to be possible at both sizes
             fuse = fuse && fusable(mid[m], last_name[m], x[m], G) && fusable(mid[m], last_name[m], x[m], 1);
         }
-        for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m]);
+        for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m], x[m]);
         Act lead_out[2];
         if (lead)
             for (int m = 0; m < 2; ++m)
@@ -1458,7 +1638,7 @@ struct rgbd_elic {
             lead0[m] = p[m] + ".conv.0";
             fuse = fuse && fusable(mid[m], last_name[m], x[m], G) && fusable(mid[m], last_name[m], x[m], 1);  // (see bottleneck2)
         }
-        for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m]);
+        for (int m = 0; m < 2; ++m) lead = lead && fuse && lead_fusable(last_name[m], next_lead[m], x[m]);
         Act lead_out[2];
         if (lead)
             for (int m = 0; m < 2; ++m)
@@ -1565,10 +1745,11 @@ struct rgbd_elic {
         for (int m = 0; m < 2; ++m) up[m] = alloc(x[m].n, x[m].h, x[m].w, c3b[m].c);
         if (!dry() && !rc) {
             const bool same2 = same && x[0].h == x[1].h && x[0].w == x[1].w && c3b[0].cs == c3b[1].cs && up[0].cs == up[1].cs;
+            const int rc0 = refnum ? c3b[0].c : 0, rc1 = refnum ? c3b[1].c : 0;
             int r = launch_bilinear(c3b[0].p, c3b[0].n, c3b[0].h, c3b[0].w, c3b[0].cs, up[0].p, x[0].h, x[0].w, s,
-                                    same2 ? c3b[1].p : nullptr, same2 ? up[1].p : nullptr);
+                                    same2 ? c3b[1].p : nullptr, same2 ? up[1].p : nullptr, rc0);
             if (!r && !same2)
-                r = launch_bilinear(c3b[1].p, c3b[1].n, c3b[1].h, c3b[1].w, c3b[1].cs, up[1].p, x[1].h, x[1].w, s);
+                r = launch_bilinear(c3b[1].p, c3b[1].n, c3b[1].h, c3b[1].w, c3b[1].cs, up[1].p, x[1].h, x[1].w, s, nullptr, nullptr, rc1);
             if (r) fail(r);
         }
         Epi addup[2];
@@ -1611,7 +1792,7 @@ struct rgbd_elic {
         c3 = conv(p + ".conv3_", c3, 1, 1);
         Act up = alloc(x.n, x.h, x.w, c3.c);
         if (!dry() && !rc) {
-            const int r = launch_bilinear(c3.p, c3.n, c3.h, c3.w, c3.cs, up.p, x.h, x.w, s);
+            const int r = launch_bilinear(c3.p, c3.n, c3.h, c3.w, c3.cs, up.p, x.h, x.w, s, nullptr, nullptr, refnum ? c3.c : 0);
             if (r) fail(r);
         }
         Epi addup;
@@ -1673,7 +1854,7 @@ struct rgbd_elic {
         const int HW = x.h * x.w;
         int r = means ? RGBD_OK : launch_channel_mean(x.p, x.n, HW, x.cs, x.c, mean, s);
         const float* mu = means ? means : mean;
-        if (!r) r = launch_se_fc(mu, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0);
+        if (!r) r = launch_se_fc(mu, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0, perm());
         if (!r) r = launch_channel_scale_to(x.p, x.n, HW, x.cs, x.c, sc, mode, y.p, y.cs, s);
         if (r) fail(r);
     }
@@ -1695,7 +1876,7 @@ struct rgbd_elic {
         const int HW = own.h * own.w;
         int r = launch_channel_mean_strided(own.p, own.n, HW, own.cs, own.c, mean, C, s);
         if (!r) r = launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
-        if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s);
+        if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s, 0, perm());
         if (!r) r = launch_channel_scale_to_strided(own.p, own.n, HW, own.cs, own.c, sc, C, 0, f.p, f.cs, s);
         if (!r) r = launch_channel_scale_to_strided(other.p, other.n, HW, other.cs, other.c, sc + own.c, C, 0, f.p + own.c, f.cs, s);
         if (r) fail(r);
@@ -1968,6 +2149,7 @@ struct rgbd_elic {
         g.C = yhat_slice.c;
         g.anchor = anchor;
         g.per_image = cd.per_image;
+        g.perm = perm();
         const int64_t mod_off = (int64_t)mod * g.B * cd.per_image_total;
         int32_t* sym = cd.sym + mod_off;
         int32_t* idx = cd.idx + mod_off;
@@ -2561,6 +2743,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
     const int64_t T = (int64_t)Ctot * h * w;  // y symbols per image per modality
     const int64_t Tz = (int64_t)N * zh * zw;
     const int ny = per_image ? B : 1;
+    ref_batch = per_image ? 1 : B;  // per-image streams stand for the reference called image by image
     named.clear();
     pre_leads.clear();
     arena.reset();
@@ -2614,10 +2797,10 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
         hyp_r = alloc(B, h, w, 2 * M);
         hyp_d = alloc(B, h, w, 2 * M);
         if (!dry()) {
-            int r = launch_nchw_to_nhwc16(lat->y[0], B, M, h, w, y_r.p, y_r.cs, s);
-            if (!r) r = launch_nchw_to_nhwc16(lat->y[1], B, M, h, w, y_d.p, y_d.cs, s);
-            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[0], B, 2 * M, h, w, hyp_r.p, hyp_r.cs, s);
-            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s);
+            int r = launch_nchw_to_nhwc16(lat->y[0], B, M, h, w, y_r.p, y_r.cs, s, perm());
+            if (!r) r = launch_nchw_to_nhwc16(lat->y[1], B, M, h, w, y_d.p, y_d.cs, s, perm());
+            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[0], B, 2 * M, h, w, hyp_r.p, hyp_r.cs, s, perm());
+            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s, perm());
             if (r) return r;
         }
     } else {
@@ -2667,11 +2850,11 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
                     if (!md) break;
                     int32_t* zs = zsym + (size_t)m * B * Tz;
                     int32_t* zi = zidx + (size_t)m * B * Tz;
-                    int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s);
+                    int r = launch_z_quant(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, zs, zi, s, perm());
                     if (!r)
                         r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
                                                zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
-                    if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+                    if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s, perm());
                     if (r) fail(r);
                 }
             }
@@ -2756,6 +2939,7 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
                            float* ly_r, float* ly_d, float* lz_r, float* lz_d)
 {
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    ref_batch = B;  // forward() is one reference call on the whole batch
     named.clear();
     pre_leads.clear();
     arena.reset();
@@ -2798,7 +2982,7 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
                 float* md = dense_of(std::string(mods[m]) + "_entropy_bottleneck.medians");
                 float* prm = dense_of(std::string(mods[m]) + "_entropy_bottleneck.cumulative");
                 if (!md || !prm) break;
-                const int r = launch_eb_forward(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, prm, zo[m]->p, zl[m]->p, s);
+                const int r = launch_eb_forward(zz[m]->p, zz[m]->cs, B, zh, zw, N, md, prm, zo[m]->p, zl[m]->p, s, perm());
                 if (r) fail(r);
             }
         }
@@ -2847,10 +3031,10 @@ int rgbd_elic::run_forward(const float* rgb_dev, const float* depth_dev, int B, 
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xr.p, B, 3, H, W, xr.cs, xr_dev, 0, s);
     if (!r) r = launch_nhwc_to_nchw_clamp(xd.p, B, 1, H, W, xd.cs, xd_dev, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(lik_r.p, B, M, h, w, lik_r.cs, ly_r, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(lik_d.p, B, M, h, w, lik_d.cs, ly_d, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(zl_r.p, B, N, zh, zw, zl_r.cs, lz_r, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(zl_d.p, B, N, zh, zw, zl_d.cs, lz_d, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(lik_r.p, B, M, h, w, lik_r.cs, ly_r, 0, s, perm());
+    if (!r) r = launch_nhwc_to_nchw_clamp(lik_d.p, B, M, h, w, lik_d.cs, ly_d, 0, s, perm());
+    if (!r) r = launch_nhwc_to_nchw_clamp(zl_r.p, B, N, zh, zw, zl_r.cs, lz_r, 0, s, perm());
+    if (!r) r = launch_nhwc_to_nchw_clamp(zl_d.p, B, N, zh, zw, zl_d.cs, lz_d, 0, s, perm());
     if (!r) r = wait_stream();
     return r;
 }
@@ -2868,6 +3052,7 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
     const int zh = lat ? 1 : h / 4, zw = lat ? 1 : w / 4, H = h * 16, W = w * 16;
     const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
     const int per_image = (n_y == B && !(B == 1)) ? 1 : (n_y == 1 ? (B == 1 ? 1 : 0) : -1);
+    ref_batch = per_image == 0 ? B : 1;
     if (per_image < 0) return RGBD_EINVAL;
     named.clear();
     pre_leads.clear();
@@ -2954,8 +3139,8 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
         hyp_r = alloc(B, h, w, 2 * M);
         hyp_d = alloc(B, h, w, 2 * M);
         if (!dry()) {
-            int r = launch_nchw_to_nhwc16(lat->hyp[0], B, 2 * M, h, w, hyp_r.p, hyp_r.cs, s);
-            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s);
+            int r = launch_nchw_to_nhwc16(lat->hyp[0], B, 2 * M, h, w, hyp_r.p, hyp_r.cs, s, perm());
+            if (!r) r = launch_nchw_to_nhwc16(lat->hyp[1], B, 2 * M, h, w, hyp_d.p, hyp_d.cs, s, perm());
             if (r) return r;
         }
     }
@@ -2976,12 +3161,12 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
                     int32_t* zi_ = zidx + (size_t)m * B * Tz;
                     // indexes = channel id in (c, row, col) order: the quantiser's index writer on a zeroed tensor
                     int r = launch_fill_zero(zo[m]->p, zo[m]->elems(), s);
-                    if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s);
+                    if (!r) r = launch_z_quant(zo[m]->p, zo[m]->cs, B, zh, zw, N, md, zs_, zi_, s, perm());
                     if (!r)
                         r = launch_rans_decode(words, d_zoff + (size_t)m * ns_z, d_zlen + (size_t)m * ns_z, ns_z,
                                                state + (size_t)4 * ns_y + (size_t)m * ns_z * 2, 1, zi_, zs_, d_zbase, 0, Tz,
                                                tables[2 + m].d, s);
-                    if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s);
+                    if (!r) r = launch_z_dequant(zs_, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s, perm());
                     if (r) fail(r);
                 }
             }
@@ -3040,8 +3225,8 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
 
     // ==== epilogue (never captured): results into the caller's NCHW tensors ==========================================
     if (lat) {
-        int r = launch_nhwc_to_nchw_clamp(out0.p, B, M, h, w, out0.cs, lat->yhat[0], 0, s);
-        if (!r) r = launch_nhwc_to_nchw_clamp(out1.p, B, M, h, w, out1.cs, lat->yhat[1], 0, s);
+        int r = launch_nhwc_to_nchw_clamp(out0.p, B, M, h, w, out0.cs, lat->yhat[0], 0, s, perm());
+        if (!r) r = launch_nhwc_to_nchw_clamp(out1.p, B, M, h, w, out1.cs, lat->yhat[1], 0, s, perm());
         return r;
     }
     int r = launch_nhwc_to_nchw_clamp(out0.p, B, 3, H, W, out0.cs, xr_dev, 1, s);
@@ -3054,6 +3239,7 @@ int rgbd_elic::run_decompress_impl(const uint8_t* const* ys[2], const int64_t* y
 int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat_dev, float* ly, float* lz)
 {
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
+    ref_batch = B;
     named.clear();
     pre_leads.clear();
     arena.reset();
@@ -3080,7 +3266,7 @@ int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat
             float* md = dense_of("entropy_bottleneck.medians");
             float* prm = dense_of("entropy_bottleneck.cumulative");
             if (md && prm) {
-                const int r = launch_eb_forward(z.p, z.cs, B, zh, zw, N, md, prm, zhat.p, zlik.p, s);
+                const int r = launch_eb_forward(z.p, z.cs, B, zh, zw, N, md, prm, zhat.p, zlik.p, s, perm());
                 if (r) fail(r);
             }
         }
@@ -3114,8 +3300,8 @@ int rgbd_elic::run_forward1(const float* x_dev, int B, int H, int W, float* xhat
     }
     if (dry()) return RGBD_OK;
     int r = launch_nhwc_to_nchw_clamp(xh.p, B, in_ch, H, W, xh.cs, xhat_dev, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(lik.p, B, M, h, w, lik.cs, ly, 0, s);
-    if (!r) r = launch_nhwc_to_nchw_clamp(zlik.p, B, N, zh, zw, zlik.cs, lz, 0, s);
+    if (!r) r = launch_nhwc_to_nchw_clamp(lik.p, B, M, h, w, lik.cs, ly, 0, s, perm());
+    if (!r) r = launch_nhwc_to_nchw_clamp(zlik.p, B, N, zh, zw, zlik.cs, lz, 0, s, perm());
     if (!r) r = wait_stream();
     return r;
 }
@@ -3126,6 +3312,7 @@ int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_im
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64;
     const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
     const int ny = per_image ? B : 1;
+    ref_batch = per_image ? 1 : B;
     named.clear();
     pre_leads.clear();
     arena.reset();
@@ -3187,11 +3374,11 @@ int rgbd_elic::run_compress1(const float* x_dev, int B, int H, int W, int per_im
         Act zhat = alloc(B, zh, zw, N);
         float* md = dense_of("entropy_bottleneck.medians");
         if (!dry() && !rc && md) {
-            int r = launch_z_quant(z.p, z.cs, B, zh, zw, N, md, zsym, zidx, s);
+            int r = launch_z_quant(z.p, z.cs, B, zh, zw, N, md, zsym, zidx, s, perm());
             if (!r)
                 r = launch_rans_encode(zsym, zidx, meta64 + B, meta64 + 2 * B, B, B, tables[2].d, tables[2].d, zwords, zcap,
                                        meta64 + 3 * B, err, s);
-            if (!r) r = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
+            if (!r) r = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s, perm());
             if (r) fail(r);
         }
         named["zhat"] = zhat;
@@ -3253,6 +3440,7 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
     const int h = zh * 4, w = zw * 4, H = zh * 64, W = zw * 64;
     const int64_t T = (int64_t)M * h * w, Tz = (int64_t)N * zh * zw;
     const int per_image = (n_y == B) ? 1 : 0;
+    ref_batch = per_image ? 1 : B;
     named.clear();
     pre_leads.clear();
     arena.reset();
@@ -3321,11 +3509,11 @@ int rgbd_elic::run_decompress1(const uint8_t* const* ys, const int64_t* ylen, in
         float* md = dense_of("entropy_bottleneck.medians");
         if (!dry() && md) {
             int q = launch_fill_zero(zhat.p, zhat.elems(), s);
-            if (!q) q = launch_z_quant(zhat.p, zhat.cs, B, zh, zw, N, md, zsym, zidx, s);  // indexes = channel id
+            if (!q) q = launch_z_quant(zhat.p, zhat.cs, B, zh, zw, N, md, zsym, zidx, s, perm());  // indexes = channel id
             if (!q)
                 q = launch_rans_decode(words, meta64 + o_zoff, meta64 + o_zoff + B, B, state + (size_t)2 * n_y, 1, zidx, zsym,
                                        meta64 + o_zbase, 0, Tz, tables[2].d, s);
-            if (!q) q = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s);
+            if (!q) q = launch_z_dequant(zsym, B, zh, zw, N, md, zhat.p, zhat.cs, s, perm());
             if (q) fail(q);
         }
         named["zhat"] = zhat;
@@ -4061,6 +4249,7 @@ int rgbd_elic_create_stf(int32_t N, int32_t M, const int32_t* slice_ch, int32_t 
     const int r = rgbd_elic_create(N, M, slice_ch, n_slices, out);
     if (r) return r;
     (*out)->variant = 2;
+    (*out)->refnum = false;  // (Swin transforms: channel slices that are not 16-aligned; the single-chain arithmetic of rounds 1-4)
     return RGBD_OK;
 }
 
@@ -4128,6 +4317,8 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
     m->slice_ch = src->slice_ch;
     m->variant = src->variant;
     m->in_ch = src->in_ch;
+    m->refnum = src->refnum;
+    m->ref_tab = src->ref_tab;
     m->convs = src->convs;    // device pointers are shared, read-only; the generations below keep them alive
     m->dense = src->dense;
     m->gen_w = src->gen_w;
@@ -4224,6 +4415,25 @@ static bool ends_with(const std::string& s, const char* suf)
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+int rgbd_elic_set_ref_blocks(rgbd_elic* m, int32_t kind, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t batch,
+                             const int32_t* blocks, int32_t nblocks)
+{
+    if (!m || !blocks || nblocks <= 0 || nblocks > 64 || kind < 0 || kind > 3) return RGBD_EINVAL;
+    int sum = 0;
+    for (int i = 0; i < nblocks; ++i) {
+        if (blocks[i] <= 0) return RGBD_EINVAL;
+        sum += blocks[i];
+    }
+    if (kind == 0 && sum != cin) return RGBD_EINVAL;
+    if (kind == 1 && nblocks > 16) return RGBD_EINVAL;
+    m->ref_tab->blocks[{kind, cin, cout, h, w, batch}] = std::vector<int>(blocks, blocks + nblocks);
+    m->graphs_invalidate();
+    return RGBD_OK;
+}
+
+int rgbd_elic_get_refnum(const rgbd_elic* m) { return m ? (m->refnum ? 1 : 0) : RGBD_EINVAL; }
+int rgbd_elic_ref_table_misses(const rgbd_elic* m) { return m ? m->ref_tab->misses : RGBD_EINVAL; }
+
 int rgbd_elic_finalize(rgbd_elic* m)
 {
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
@@ -4259,18 +4469,25 @@ int rgbd_elic_finalize(rgbd_elic* m)
             const std::string bname = name.substr(0, name.size() - 6) + "bias";
             auto bit = m->raw.find(bname);
             PackedConv pc;
-            const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc, gen.get());
+            // refnum: activations store their channels permuted (rgbd_cperm) -- except the network's input (read channel by
+            // channel by the K-packing gather) and its output images (<= 4 channels, converted straight to NCHW)
+            const int pm = m->perm();
+            const int k0 = (int)t.shape[2];
+            const int cin0 = transposed ? (int)t.shape[0] : (int)t.shape[1], cout0 = transposed ? (int)t.shape[1] : (int)t.shape[0];
+            const bool image_in = !transposed && cin0 <= 3 && k0 == 5, image_out = transposed && cout0 <= 4 && k0 == 5;
+            const int r = pack_conv(t, bit == m->raw.end() ? nullptr : &bit->second, transposed, &pc, gen.get(), image_in ? 0 : pm,
+                                    image_out ? 0 : pm);
             if (r) return r;
             convs[name] = pc;
             if (!transposed && pc.cin <= 3 && pc.k == 5) {  // the image-consuming layer: also as a 1x1 over a K-packed input
                 PackedConv pk;
-                const int r4 = pack_kpack(t, bit == m->raw.end() ? nullptr : &bit->second, &pk, gen.get());
+                const int r4 = pack_kpack(t, bit == m->raw.end() ? nullptr : &bit->second, &pk, gen.get(), pm);
                 if (r4) return r4;
                 convs[name.substr(0, name.size() - 6) + "kpack.weight"] = pk;
             }
             if (transposed && pc.cout <= 4 && pc.k == 5) {  // the image-producing layer: also in its sub-pixel form
                 PackedConv ps;
-                const int r3 = pack_subpix(t, bit == m->raw.end() ? nullptr : &bit->second, &ps, gen.get());
+                const int r3 = pack_subpix(t, bit == m->raw.end() ? nullptr : &bit->second, &ps, gen.get(), pm);
                 if (r3) return r3;
                 convs[name.substr(0, name.size() - 6) + "subpix.weight"] = ps;
             }
@@ -4526,7 +4743,9 @@ int rgbd_elic_debug_tensor(rgbd_elic* m, const char* name, float* data, int64_t 
     if (cap_floats < need) return RGBD_ENOSPC;
     float* tmp = nullptr;
     HIP_TRY(hipMalloc((void**)&tmp, (size_t)need * sizeof(float)));
-    int r = launch_nhwc_to_nchw_clamp(a.p, a.n, a.c, a.h, a.w, a.cs, tmp, 0, m->s);
+    // (x_hat tensors come out of the image-producing layers in channel order; everything else is stored permuted)
+    const int pm = (m->perm() && a.c > 4) ? 1 : 0;
+    int r = launch_nhwc_to_nchw_clamp(a.p, a.n, a.c, a.h, a.w, a.cs, tmp, 0, m->s, pm);
     if (!r && hipStreamSynchronize(m->s) != hipSuccess) r = RGBD_EHIP;  // (the stream may be non-blocking: hipMemcpy would not wait for it)
     if (!r && hipMemcpy(data, tmp, (size_t)need * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) r = RGBD_EHIP;
     (void)hipFree(tmp);

@@ -68,11 +68,12 @@ __global__ void ckbd_part_kernel(const float* __restrict__ y, int ycs, const flo
         const int b = (int)(t / g.h);
         const int col = ckbd_col(row, k, g.anchor);
         const size_t pix = ((size_t)b * g.h + row) * g.w + col;
-        const float scale = params[pix * pcs + c];
-        const float mean = params[pix * pcs + g.C + c];
+        const int pc = rgbd_cperm(c, g.perm);  // where channel c sits in the tensors (g.C is a multiple of 16 when perm)
+        const float scale = params[pix * pcs + pc];
+        const float mean = params[pix * pcs + g.C + pc];
         const int64_t pos = sym_pos(g, stream_base, part_off, b, c, row, k);
         if (MODE == 0) {
-            const float xm = y[pix * ycs + c] - mean;
+            const float xm = y[pix * ycs + pc] - mean;
             const float r = rintf(xm);  // round half to even, like torch.round
             const int s = (int)r;
             if (dbg_x) {  // parity bookkeeping (rgbd_elic_set_debug_floats): the rounded value and the indexed scale
@@ -81,16 +82,16 @@ __global__ void ckbd_part_kernel(const float* __restrict__ y, int ycs, const flo
             }
             sym[pos] = s;
             idx[pos] = scale_to_index(tbl, scale);
-            yhat[pix * yhcs + c] = (float)s + mean;
+            yhat[pix * yhcs + pc] = (float)s + mean;
         } else if (MODE == 1) {
             idx[pos] = scale_to_index(tbl, scale);
         } else {
-            yhat[pix * yhcs + c] = (float)sym[pos] + mean;
+            yhat[pix * yhcs + pc] = (float)sym[pos] + mean;
         }
         if (MODE != 1 && g.anchor) {
             // the anchor pass defines the whole slice: off-parity positions start at zero (ckbd.py:66-72)
             const size_t opix = ((size_t)b * g.h + row) * g.w + (col ^ 1);
-            yhat[opix * yhcs + c] = 0.f;
+            yhat[opix * yhcs + pc] = 0.f;
         }
     }
 }
@@ -151,18 +152,19 @@ __global__ void ckbd_estimate_kernel(const float* __restrict__ y, int ycs, const
         const int b = (int)(t / g.h);
         const int col = ckbd_col(row, k, g.anchor);
         const size_t pix = ((size_t)b * g.h + row) * g.w + col;
-        const float scale = fmaxf(params[pix * pcs + c], 0.11f);  // LowerBound(0.11)
-        const float mean = params[pix * pcs + g.C + c];
-        const float out = __fadd_rn(rintf(y[pix * ycs + c] - mean), mean);  // quantize(..., "dequantize", means)
-        yhat[pix * yhcs + c] = out;
+        const int pc = rgbd_cperm(c, g.perm);
+        const float scale = fmaxf(params[pix * pcs + pc], 0.11f);  // LowerBound(0.11)
+        const float mean = params[pix * pcs + g.C + pc];
+        const float out = __fadd_rn(rintf(y[pix * ycs + pc] - mean), mean);  // quantize(..., "dequantize", means)
+        yhat[pix * yhcs + pc] = out;
         const float v = fabsf(__fsub_rn(out, mean));
         const float cst = -0.70710678118654752440f;  // -(2 ** -0.5)
         const float upper = 0.5f * erfcf(cst * ((0.5f - v) / scale));
         const float lower = 0.5f * erfcf(cst * ((-0.5f - v) / scale));
-        lik[pix * lcs + c] = fmaxf(upper - lower, 1e-9f);
+        lik[pix * lcs + pc] = fmaxf(upper - lower, 1e-9f);
         if (g.anchor) {
             const size_t opix = ((size_t)b * g.h + row) * g.w + (col ^ 1);
-            yhat[opix * yhcs + c] = 0.f;
+            yhat[opix * yhcs + pc] = 0.f;
         }
     }
 }
@@ -211,34 +213,35 @@ __device__ __forceinline__ float eb_logits(const float* __restrict__ p, float x)
 
 __global__ void eb_forward_kernel(const float* __restrict__ z, int zcs, int B, int h, int w, int C,
                                   const float* __restrict__ med, const float* __restrict__ prm, float* __restrict__ zhat,
-                                  float* __restrict__ lik)
+                                  float* __restrict__ lik, int perm)
 {
     const size_t total = (size_t)B * h * w * zcs;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % zcs);
+        const int pc = (int)(i % zcs);           // position in the tensor
+        const int c = rgbd_cperm(pc, perm);      // the channel stored there (the permutation is its own inverse)
         const size_t pix = i / zcs;
         if (c >= C) {
-            zhat[pix * zcs + c] = 0.f;
-            lik[pix * zcs + c] = 0.f;
+            zhat[pix * zcs + pc] = 0.f;
+            lik[pix * zcs + pc] = 0.f;
             continue;
         }
-        const float out = __fadd_rn(rintf(z[pix * zcs + c] - med[c]), med[c]);
-        zhat[pix * zcs + c] = out;
+        const float out = __fadd_rn(rintf(z[pix * zcs + pc] - med[c]), med[c]);
+        zhat[pix * zcs + pc] = out;
         const float lo = eb_logits(prm + (size_t)c * 58, out - 0.5f);
         const float up = eb_logits(prm + (size_t)c * 58, out + 0.5f);
         const float sm = lo + up;
         const float sg = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
         const float a = 1.0f / (1.0f + expf(-(sg * up))), b = 1.0f / (1.0f + expf(-(sg * lo)));
-        lik[pix * zcs + c] = fmaxf(fabsf(a - b), 1e-9f);
+        lik[pix * zcs + pc] = fmaxf(fabsf(a - b), 1e-9f);
     }
 }
 
 int launch_eb_forward(const float* z, int zcs, int B, int h, int w, int C, const float* med, const float* prm, float* zhat,
-                      float* lik, hipStream_t s)
+                      float* lik, hipStream_t s, int perm)
 {
     const size_t work = (size_t)B * h * w * zcs;
     hipLaunchKernelGGL(eb_forward_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, z, zcs, B, h, w, C, med, prm,
-                       zhat, lik);
+                       zhat, lik, perm);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
@@ -246,7 +249,7 @@ int launch_eb_forward(const float* z, int zcs, int B, int h, int w, int C, const
 // ---------------------------------------------------------------------------------------------
 // z path: sym = round(z - median_c), index = c, per-image streams in (c, row, col) order
 __global__ void z_quant_kernel(const float* __restrict__ z, int zcs, int B, int h, int w, int C,
-                               const float* __restrict__ med, int32_t* __restrict__ sym, int32_t* __restrict__ idx)
+                               const float* __restrict__ med, int32_t* __restrict__ sym, int32_t* __restrict__ idx, int perm)
 {
     const size_t total = (size_t)B * h * w * C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -255,42 +258,43 @@ __global__ void z_quant_kernel(const float* __restrict__ z, int zcs, int B, int 
         const size_t hw = pix % ((size_t)h * w);
         const size_t b = pix / ((size_t)h * w);
         const size_t pos = (b * C + c) * (size_t)h * w + hw;
-        sym[pos] = (int)rintf(z[pix * zcs + c] - med[c]);
+        sym[pos] = (int)rintf(z[pix * zcs + rgbd_cperm(c, perm)] - med[c]);
         idx[pos] = c;
     }
 }
 
 int launch_z_quant(const float* z, int zcs, int B, int h, int w, int C, const float* medians, int32_t* sym, int32_t* idx,
-                   hipStream_t s)
+                   hipStream_t s, int perm)
 {
     const size_t work = (size_t)B * h * w * C;
     hipLaunchKernelGGL(z_quant_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, z, zcs, B, h, w, C, medians,
-                       sym, idx);
+                       sym, idx, perm);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
 
 __global__ void z_dequant_kernel(const int32_t* __restrict__ sym, int B, int h, int w, int C,
-                                 const float* __restrict__ med, float* __restrict__ zhat, int zcs)
+                                 const float* __restrict__ med, float* __restrict__ zhat, int zcs, int perm)
 {
     const size_t total = (size_t)B * h * w * zcs;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % zcs);
+        const int pc = (int)(i % zcs);
+        const int c = rgbd_cperm(pc, perm);  // the channel stored at position pc
         const size_t pix = i / zcs;
         const size_t hw = pix % ((size_t)h * w);
         const size_t b = pix / ((size_t)h * w);
         float v = 0.f;
         if (c < C) v = (float)sym[(b * C + c) * (size_t)h * w + hw] + med[c];
-        zhat[pix * zcs + c] = v;
+        zhat[pix * zcs + pc] = v;
     }
 }
 
 int launch_z_dequant(const int32_t* sym, int B, int h, int w, int C, const float* medians, float* zhat, int zcs,
-                     hipStream_t s)
+                     hipStream_t s, int perm)
 {
     const size_t work = (size_t)B * h * w * zcs;
     hipLaunchKernelGGL(z_dequant_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, sym, B, h, w, C, medians,
-                       zhat, zcs);
+                       zhat, zcs, perm);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }

@@ -4,6 +4,7 @@
 // All tensors are NHWC with channel stride cs (multiple of 4 floats): every access is a 16-byte vector per lane and
 // consecutive lanes walk consecutive channels, so each wave instruction touches contiguous 1 KiB runs.
 #include "common.h"
+#include "exact_math.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -109,8 +110,15 @@ int launch_maxpool7s3(const float* x, int N, int H, int W, int cs, float* y, int
 
 // F.interpolate(mode="bilinear", align_corners=False) to (H, W) (attention.py:91):
 // src = max(0, scale*(dst+0.5)-0.5), i0 = floor(src), i1 = min(i0+1, in-1), l1 = src - i0, l0 = 1 - l1
+// ref != 0: the arithmetic of torch's CPU kernels (UpSampleKernel.cpp, third-party to the reference; restated from black-box
+// probes, oracle/cpu_arith.c orc_bilinear): the source index is ONE fused multiply-add, and the four taps are combined
+//   * output H + W > 128 (the generic separable kernel): t_k = fma(v_k0, lx0, v_k1 * lx1);  out = fma(t_0, ly0, t_1 * ly1)
+//   * output H + W <= 128 (the channels-last vector kernel): w_ij = ly_i * lx_j, and
+//       channels below C - C % 16 (its vector body):  fma(w00, v00, fma(w01, v01, fma(w11, v11, w10 * v10)))
+//       the C % 16 tail channels (its scalar loop):    fma(w11, v11, fma(w10, v10, fma(w00, v00, w01 * v01)))
+// ref: 1 + C (the tensor's channel count; channels are stored permuted, rgbd_cperm)
 __global__ void bilinear_kernel(const float* __restrict__ x0, int N, int h, int w, int cs, float* __restrict__ y0, int H,
-                                int W, float sy, float sx, const float* __restrict__ x1, float* __restrict__ y1)
+                                int W, float sy, float sx, const float* __restrict__ x1, float* __restrict__ y1, int ref)
 {
     const float* __restrict__ x = blockIdx.y ? x1 : x0;  // (pair of tensors, see maxpool7s3_kernel)
     float* __restrict__ y = blockIdx.y ? y1 : y0;
@@ -123,8 +131,8 @@ __global__ void bilinear_kernel(const float* __restrict__ x0, int N, int h, int 
         t /= W;
         const int oy = (int)(t % H);
         const size_t n = t / H;
-        float fy = __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
-        float fx = __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
+        float fy = ref ? __fmaf_rn(sy, (float)oy + 0.5f, -0.5f) : __fsub_rn(__fmul_rn(sy, (float)oy + 0.5f), 0.5f);
+        float fx = ref ? __fmaf_rn(sx, (float)ox + 0.5f, -0.5f) : __fsub_rn(__fmul_rn(sx, (float)ox + 0.5f), 0.5f);
         fy = fy < 0.f ? 0.f : fy;
         fx = fx < 0.f ? 0.f : fx;
         const int y0 = (int)fy, x0 = (int)fx;
@@ -139,20 +147,35 @@ __global__ void bilinear_kernel(const float* __restrict__ x0, int N, int h, int 
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float top = __fadd_rn(__fmul_rn(lx0, v00[e]), __fmul_rn(lx1, v01[e]));
-            const float bot = __fadd_rn(__fmul_rn(lx0, v10[e]), __fmul_rn(lx1, v11[e]));
-            o[e] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+            if (!ref) {
+                const float top = __fadd_rn(__fmul_rn(lx0, v00[e]), __fmul_rn(lx1, v01[e]));
+                const float bot = __fadd_rn(__fmul_rn(lx0, v10[e]), __fmul_rn(lx1, v11[e]));
+                o[e] = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+            } else if (H + W > 128) {
+                const float top = __fmaf_rn(v00[e], lx0, __fmul_rn(v01[e], lx1));
+                const float bot = __fmaf_rn(v10[e], lx0, __fmul_rn(v11[e], lx1));
+                o[e] = __fmaf_rn(top, ly0, __fmul_rn(bot, ly1));
+            } else {
+                const float w00 = __fmul_rn(ly0, lx0), w01 = __fmul_rn(ly0, lx1), w10 = __fmul_rn(ly1, lx0), w11 = __fmul_rn(ly1, lx1);
+                const int C = ref - 1, lc = rgbd_cperm(c4 * 4 + e);  // the channel stored at this position
+                if (lc < C - C % 16)
+                    o[e] = __fmaf_rn(w00, v00[e], __fmaf_rn(w01, v01[e], __fmaf_rn(w11, v11[e], __fmul_rn(w10, v10[e]))));
+                else
+                    o[e] = __fmaf_rn(w11, v11[e], __fmaf_rn(w10, v10[e], __fmaf_rn(w00, v00[e], __fmul_rn(w01, v01[e]))));
+            }
         }
         *reinterpret_cast<f32x4*>(y + ((n * H + oy) * (size_t)W + ox) * cs + c4 * 4) = o;
     }
 }
 
-int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s, const float* x1, float* y1)
+int launch_bilinear(const float* x, int N, int h, int w, int cs, float* y, int H, int W, hipStream_t s, const float* x1, float* y1,
+                    int ref_channels)
 {
     if (!x1 != !y1) return RGBD_EINVAL;
     const size_t work = (size_t)N * H * W * (cs / 4);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(work), x1 ? 2 : 1), dim3(256), 0, s, x, N, h, w, cs, y, H, W, sy, sx, x1, y1);
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(work), x1 ? 2 : 1), dim3(256), 0, s, x, N, h, w, cs, y, H, W, sy, sx, x1, y1,
+                       ref_channels > 0 ? 1 + ref_channels : 0);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
@@ -209,13 +232,13 @@ int launch_channel_mean_strided(const float* x, int N, int HW, int cs, int C, fl
 // so both passes read weights with consecutive lanes on consecutive addresses.
 // pass 1: one wavefront per (hidden unit, image); lanes stride the dot product, fixed shuffle-tree reduction.
 __global__ __launch_bounds__(64) void se_hidden_kernel(const float* __restrict__ mean, int C, int hidden,
-                                                       const float* __restrict__ w0, float* __restrict__ hid, int mstride)
+                                                       const float* __restrict__ w0, float* __restrict__ hid, int mstride, int perm)
 {
     const int j = blockIdx.x;
     const size_t n = blockIdx.y;
     const int lane = threadIdx.x;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], mean[n * mstride + c], s);
+    for (int c = lane; c < C; c += 64) s = fmaf(w0[(size_t)j * C + c], mean[n * mstride + rgbd_cperm(c, perm)], s);
 #pragma unroll
     for (int off = 32; off; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) hid[n * hidden + j] = fmaxf(s, 0.f);
@@ -223,17 +246,18 @@ __global__ __launch_bounds__(64) void se_hidden_kernel(const float* __restrict__
 
 // pass 2: one thread per (image, channel), sequential over the hidden units.
 __global__ void se_gate_kernel(const float* __restrict__ hid, int C, int hidden, const float* __restrict__ w1t,
-                               float* __restrict__ scale)
+                               float* __restrict__ scale, int perm)
 {
     extern __shared__ float hsh[];
     const size_t n = blockIdx.y;
     for (int j = threadIdx.x; j < hidden; j += blockDim.x) hsh[j] = hid[n * hidden + j];
     __syncthreads();
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int pc = blockIdx.x * blockDim.x + threadIdx.x;  // position in the gate vector (= in the gated tensor)
+    if (pc >= C) return;
+    const int c = rgbd_cperm(pc, perm);                     // the channel stored there
     float s = 0.f;
     for (int j = 0; j < hidden; ++j) s = fmaf(w1t[(size_t)j * C + c], hsh[j], s);
-    scale[n * C + c] = 1.0f / (1.0f + expf(-s));
+    scale[n * C + pc] = perm ? rgbd_sigmoid_ref(s) : 1.0f / (1.0f + expf(-s));
 }
 
 // (Single-launch variants were built and measured twice.  Round 2: every workgroup recomputing the hidden layer into LDS, then
@@ -244,11 +268,11 @@ __global__ void se_gate_kernel(const float* __restrict__ hid, int C, int hidden,
 // same box.  Each SE stage reduces over a different axis (pixels, channels, hidden units, then back out); fusing
 // neighbours trades a ~4 us launch for recomputation that costs more.  The launches below stay.)
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
-                 float* scale, hipStream_t s, int mstride)
+                 float* scale, hipStream_t s, int mstride, int perm)
 {
-    hipLaunchKernelGGL(se_hidden_kernel, dim3(hidden, N), dim3(64), 0, s, mean, C, hidden, w0, hid, mstride > 0 ? mstride : C);
+    hipLaunchKernelGGL(se_hidden_kernel, dim3(hidden, N), dim3(64), 0, s, mean, C, hidden, w0, hid, mstride > 0 ? mstride : C, perm);
     hipLaunchKernelGGL(se_gate_kernel, dim3((C + 255) / 256, N), dim3(256), (size_t)hidden * sizeof(float), s, hid, C,
-                       hidden, w1t, scale);
+                       hidden, w1t, scale, perm);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
@@ -362,6 +386,59 @@ int launch_fill_zero(float* p, size_t n, hipStream_t s)
 {
     if (!n) return RGBD_OK;
     hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, p, n);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-tensor convolution in the arithmetic of the reference's CPU path for such tensors (torch's im2col + MKL sgemm route:
+// batch 1, kernel <= 3, at most 20480 input elements; DESIGN.md 4a, oracle/cpu_arith.c orc_conv_im2col_kblocks): per output
+// ONE thread walks k = c * KH * KW + ky * KW + kx in ascending order, a fresh fma chain per K block (kb[0..nb]: boundaries
+// in k), out = (S_0 + bias) + S_1 + ...  The layers that take this path are tiny (the ESA pooled branch, latent-grid layers of
+// small images): a few MFLOP each, so a plain vector-ALU kernel reading the MFMA kernels' packed weights in place.
+// x / y: NHWC, channels permuted (rgbd_cperm); w: packed [cout_pad][ntaps][cin_pad] (both channel axes permuted).
+__global__ void small_conv_ref_kernel(SmallConvArgs a)
+{
+    const size_t total = (size_t)a.N * a.OH * a.OW * a.O;
+    const int taps = a.K * a.K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % a.O);
+        size_t t = i / a.O;
+        const int ox = (int)(t % a.OW);
+        t /= a.OW;
+        const int oy = (int)(t % a.OH);
+        const size_t n = t / a.OH;
+        const int po = rgbd_cperm(o);
+        const float* wrow = a.w + (size_t)po * taps * a.cin_pad;
+        float tot = 0.f;
+        for (int b = 0; b < a.nb; ++b) {
+            float s = 0.f;
+            for (int k = a.kb[b]; k < a.kb[b + 1]; ++k) {
+                const int c = k / taps, tp = k - c * taps, ky = tp / a.K, kx = tp - ky * a.K;
+                const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;  // (a zero of the im2col matrix: fma(0, w, s) == s)
+                const int pc = rgbd_cperm(c);
+                s = __fmaf_rn(a.x[((n * a.H + iy) * a.W + ix) * (size_t)a.xcs + pc], wrow[(size_t)tp * a.cin_pad + pc], s);
+            }
+            tot = b == 0 ? __fadd_rn(s, a.bias[po]) : __fadd_rn(tot, s);
+        }
+        const size_t opix = (n * a.OH + oy) * a.OW + ox;
+        if (a.res1) tot = __fadd_rn(tot, a.res1[opix * a.r1cs + po]);
+        if (a.act == ACT_RELU) tot = fmaxf(tot, 0.f);
+        else if (a.act == ACT_LEAKY) tot = tot > 0.f ? tot : __fmul_rn(tot, 0.01f);
+        else if (a.act == ACT_SIGMOID) tot = rgbd_sigmoid_ref(tot);
+        if (a.mul) tot = __fmul_rn(tot, a.mul[opix * a.mcs + po]);
+        if (a.res2) tot = __fadd_rn(tot, a.res2[opix * a.r2cs + po]);
+        a.y[opix * a.ycs + po] = tot;
+        if (a.y2) a.y2[opix * a.y2cs + po] = tot;
+    }
+}
+
+int launch_small_conv_ref(const SmallConvArgs& a, hipStream_t s)
+{
+    if (a.nb < 1 || a.nb > 16 || a.K < 1 || a.K > 3) return RGBD_EINVAL;
+    const size_t work = (size_t)a.N * a.OH * a.OW * a.O;
+    hipLaunchKernelGGL(small_conv_ref_kernel, dim3(grid_for(work)), dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }

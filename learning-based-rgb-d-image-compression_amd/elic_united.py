@@ -206,6 +206,9 @@ class ELIC_united:
         st = self._table_slots()[0][1].scale_table.float().contiguous().numpy()
         check(L.rgbd_elic_set_scale_table(self._h, st.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(st.shape[0])),
               "set_scale_table")
+        from . import refarith
+
+        refarith.push(L, self._h, check)  # the reference's accumulation blocks per layer shape
         check(L.rgbd_elic_finalize(self._h), "finalize")
         self._dirty = False
         self._gen += 1
