@@ -192,6 +192,11 @@ int launch_channel_scale_to_strided(const float* x, int N, int HW, int xcs, int 
 // perm: the mean / scale vectors are indexed by channel POSITION (rgbd_cperm), the FC weights by channel
 int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, const float* w1t, float* hid,
                  float* scale, hipStream_t s, int mstride = 0, int perm = 0);
+// the same block in the reference's CPU arithmetic (pointwise.hip: channel_mean_ref_kernel, se_linear_ref_kernel).  w1 is
+// fc.2.weight as stored ([C][hidden]); cls0 / cls1: per-row dot-product class of the two layers (device, nullptr = all main)
+int launch_channel_mean_ref(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s);
+int launch_se_fc_ref(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, const int* cls0,
+                     const int* cls1, float* hid, float* scale, hipStream_t s, int mstride = 0);
 // mode 0: y = x*s ; mode 1: y = x + x*s   (s per (n, c))
 int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const float* scale, int mode, float* y, int ycs,
                             hipStream_t s);
@@ -210,6 +215,13 @@ struct SmallConvArgs {
     int kb[17];         // K-block boundaries in k = c * K * K + ky * K + kx
 };
 int launch_small_conv_ref(const SmallConvArgs& a, hipStream_t s);
+// stride-2 transposed conv in the reference's arithmetic: the (tap, channel)-ordered GEMM of one (phase, column class)
+int launch_gather_taps(const float* x, int B, int h, int w, int cs, int j0, int jw, int ntap, const int* dy, const int* dx,
+                       float* col, hipStream_t s);
+int launch_gather_wslabs(const float* wp, int cout_pad, int ntaps_total, int cin_pad, int ntap, const int* slab, float* wout,
+                         hipStream_t s);
+int launch_scatter_phase(const float* src, int B, int h, int jw, int scs, int j0, int py, int px, float* dst, int OW, int dcs,
+                         int C, hipStream_t s);
 int launch_fill_zero(float* p, size_t n, hipStream_t s);
 // packed input of the first analysis conv: y[n][oy][ox][KP], see im2col5s2_kernel
 int launch_im2col5s2(const float* x, int N, int H, int W, int cs, int C, float* y, int OH, int OW, int KP, hipStream_t s);

@@ -903,6 +903,12 @@ struct rgbd_elic {
         }
         return &it->second;
     }
+    // per-row dot-product classes of an SE_Block Linear layer (reference arithmetic; nullptr = every row "main")
+    const int* cls_of(const std::string& wname)
+    {
+        auto it = dense.find(wname + ".rowclass");
+        return (it == dense.end() || ref_batch != 1) ? nullptr : reinterpret_cast<const int*>(it->second);
+    }
     float* dense_of(const std::string& name)
     {
         auto it = dense.find(name);
@@ -1852,9 +1858,13 @@ struct rgbd_elic {
         float* hid = (float*)arena.take((size_t)x.n * (x.c / 16 + 1) * sizeof(float));
         if (dry() || rc || !w0 || !w1) return;
         const int HW = x.h * x.w;
-        int r = means ? RGBD_OK : launch_channel_mean(x.p, x.n, HW, x.cs, x.c, mean, s);
+        int r = means ? RGBD_OK : (refnum ? launch_channel_mean_ref(x.p, x.n, HW, x.cs, x.c, mean, x.c, s)
+                                          : launch_channel_mean(x.p, x.n, HW, x.cs, x.c, mean, s));
         const float* mu = means ? means : mean;
-        if (!r) r = launch_se_fc(mu, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0, perm());
+        if (!r && refnum)
+            r = launch_se_fc_ref(mu, x.n, x.c, x.c / 16, w0, w1, cls_of(p + ".fc.0.weight"), cls_of(p + ".fc.2.weight"), hid, sc, s,
+                                 means ? mstride : 0);
+        else if (!r) r = launch_se_fc(mu, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0, perm());
         if (!r) r = launch_channel_scale_to(x.p, x.n, HW, x.cs, x.c, sc, mode, y.p, y.cs, s);
         if (r) fail(r);
     }
@@ -1874,9 +1884,14 @@ struct rgbd_elic {
         }
         if (dry() || rc || !w0 || !w1) return;
         const int HW = own.h * own.w;
-        int r = launch_channel_mean_strided(own.p, own.n, HW, own.cs, own.c, mean, C, s);
-        if (!r) r = launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
-        if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s, 0, perm());
+        int r = refnum ? launch_channel_mean_ref(own.p, own.n, HW, own.cs, own.c, mean, C, s)
+                       : launch_channel_mean_strided(own.p, own.n, HW, own.cs, own.c, mean, C, s);
+        if (!r)
+            r = refnum ? launch_channel_mean_ref(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s)
+                       : launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
+        if (!r && refnum)
+            r = launch_se_fc_ref(mean, own.n, C, C / 16, w0, w1, cls_of(p + ".fc.0.weight"), cls_of(p + ".fc.2.weight"), hid, sc, s);
+        else if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s, 0, perm());
         if (!r) r = launch_channel_scale_to_strided(own.p, own.n, HW, own.cs, own.c, sc, C, 0, f.p, f.cs, s);
         if (!r) r = launch_channel_scale_to_strided(other.p, other.n, HW, other.cs, other.c, sc + own.c, C, 0, f.p + own.c, f.cs, s);
         if (r) fail(r);
@@ -2017,6 +2032,118 @@ struct rgbd_elic {
         *out[1] = t2[1];
     }
 
+    // conv_transpose2d(k 5, stride 2, pad 2, output_padding 1) + activation in the reference's CPU arithmetic (oneDNN's
+    // brg_deconv: DESIGN.md 4a; oracle/cpu_arith.c orc_deconv_s2): the taps of an output pixel are accumulated tap by tap over
+    // all input channels, in chains whose membership depends on the layer shape and on the pixel's column block -- a measured
+    // recipe per (phase, column), refarith_tables.json kind 3.  Per phase and column class (columns with the same recipe) this
+    // is ONE GEMM whose K axis is (tap, channel): gathered input rows x gathered weight slabs, the chains as split-K ranges
+    // whose sums the ordered reducer adds (+ bias, activation), rows scattered to the phase's output positions.
+    // false = no recipe for this shape (the caller runs the sub-pixel-phase kernel).
+    bool deconv_s2_ref(const std::string& name, const Act& x, int act, Act* out)
+    {
+        if (!refnum) return false;
+        const PackedConv* pc = conv_of(name + ".weight");
+        if (!pc || !pc->transposed || pc->k != 5 || pc->subpix || x.cs != pc->cin_pad) return false;
+        const std::vector<int>* rec = ref_blocks(3, pc->cin, pc->cout, x.h, x.w);
+        if (!rec) return false;
+        const int h = x.h, w = x.w, B = x.n;
+        *out = alloc(B, 2 * h, 2 * w, pc->cout);
+        // parse: 4 * w descriptors {n, n x (ky, kx, fresh)}
+        std::vector<const int*> desc(4 * (size_t)w, nullptr);
+        {
+            size_t pos = 0;
+            for (size_t i = 0; i < desc.size(); ++i) {
+                if (pos >= rec->size()) {
+                    fail(RGBD_EINVAL);
+                    return true;
+                }
+                desc[i] = rec->data() + pos;
+                pos += 1 + 3 * (size_t)(*rec)[pos];
+            }
+            if (pos != rec->size()) {
+                fail(RGBD_EINVAL);
+                return true;
+            }
+        }
+        auto same = [](const int* a, const int* b) { return a[0] == b[0] && memcmp(a, b, sizeof(int) * (1 + 3 * (size_t)a[0])) == 0; };
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph >> 1, px = ph & 1;
+            for (int j0 = 0; j0 < w;) {
+                const int* d = desc[(size_t)ph * w + j0];
+                int j1 = j0 + 1;
+                while (j1 < w && same(d, desc[(size_t)ph * w + j1])) ++j1;
+                const int jw = j1 - j0, nt = d[0];
+                if (nt < 1 || nt > 16) {
+                    fail(RGBD_EINVAL);
+                    return true;
+                }
+                int dy[16], dx[16], slab[16], nch = 0;
+                uint16_t bnd[18] = {0};
+                for (int t = 0; t < nt; ++t) {
+                    const int ky = d[1 + 3 * t], kx = d[2 + 3 * t], fresh = d[3 + 3 * t];
+                    dy[t] = (py + 2 - ky) / 2;  // input row of output row 2 ty + py under tap ky: ty + (py + pad - ky) / 2
+                    dx[t] = (px + 2 - kx) / 2;
+                    slab[t] = ky * 5 + kx;
+                    if (fresh || t == 0) bnd[nch++] = (uint16_t)(t * (pc->cin_pad / 16));
+                }
+                bnd[nch] = (uint16_t)(nt * (pc->cin_pad / 16));
+                if (nch > 16) {
+                    fail(RGBD_EINVAL);
+                    return true;
+                }
+                const size_t mark = arena.top;
+                const size_t npx = (size_t)B * h * jw;
+                const int Kp = nt * pc->cin_pad;
+                float* col = (float*)arena.take(npx * Kp * sizeof(float));
+                float* wsel = (float*)arena.take((size_t)pc->cout_pad * Kp * sizeof(float));
+                float* tmp = (float*)arena.take(npx * pc->cout_pad * sizeof(float));
+                float* part = nch > 1 ? (float*)arena.take((size_t)nch * npx * pc->cout_pad * sizeof(float)) : nullptr;
+                if (!dry() && !rc) {
+                    int r = launch_gather_taps(x.p, B, h, w, x.cs, j0, jw, nt, dy, dx, col, s);
+                    if (!r) r = launch_gather_wslabs(pc->w, pc->cout_pad, 25, pc->cin_pad, nt, slab, wsel, s);
+                    if (!r) {
+                        ConvArgs a{};
+                        a.x = col;
+                        a.N = 1;
+                        a.H = B * h;
+                        a.W = jw;
+                        a.xcs = Kp;
+                        a.cin_pad = Kp;
+                        a.w = wsel;
+                        a.ntaps_total = 1;
+                        a.bias = pc->bias;
+                        a.y = tmp;
+                        a.OH = B * h;
+                        a.OW = jw;
+                        a.ycs = pc->cout_pad;
+                        a.cout_pad = pc->cout_pad;
+                        a.cout_store = pc->cout_pad;
+                        a.GH = B * h;
+                        a.GW = jw;
+                        a.IS = a.OS = 1;
+                        a.nphase = 1;
+                        a.taps.n[0] = 1;
+                        a.span_y = a.span_x = 1;
+                        a.act = act;
+                        a.loaded = tile_mode;
+                        a.exact_math = 1;
+                        a.splitk = nch;
+                        if (nch > 1) {
+                            a.partial = part;
+                            for (int c = 0; c <= nch; ++c) a.split_c16[c] = bnd[c];
+                        }
+                        r = launch_conv(a, s);
+                    }
+                    if (!r) r = launch_scatter_phase(tmp, B, h, jw, pc->cout_pad, j0, py, px, out->p, 2 * w, out->cs, pc->cout_pad, s);
+                    if (r) fail(r);
+                }
+                arena.top = mark;
+                j0 = j1;
+            }
+        }
+        return true;
+    }
+
     // synthesis.py:345-362.  cat(own, other) -> SE -> deconv without materialising the unscaled concatenation: the channel
     // means of the two inputs land side by side (what the mean of the concatenation would be, channel by channel), the
     // gate is computed from them, and each input is scaled straight into its half of the deconv's input buffer
@@ -2026,6 +2153,8 @@ struct rgbd_elic {
         se_cat_to(p + ".se", own, other, f);
         Epi e;
         e.act = last ? ACT_NONE : ACT_LEAKY;
+        Act o;
+        if (!last && deconv_s2_ref(p + ".deconv", f, ACT_LEAKY, &o)) return o;
         return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
     }
 
@@ -2041,6 +2170,13 @@ struct rgbd_elic {
         Epi e[2];
         e[0].act = e[1].act = last ? ACT_NONE : ACT_LEAKY;
         const std::string n[2] = {p[0] + ".deconv", p[1] + ".deconv"};
+        const PackedConv* pc0 = conv_of(n[0] + ".weight");
+        if (!last && refnum && pc0 && ref_blocks(3, pc0->cin, pc0->cout, f[0].h, f[0].w)) {
+            bool ok = true;
+            for (int m = 0; m < 2; ++m) ok = deconv_s2_ref(n[m], f[m], ACT_LEAKY, &out[m]) && ok;
+            if (!ok) fail(RGBD_ESTATE);
+            return;
+        }
         conv2(n, f, last ? 1 : 2, last ? 1 : 2, e, nullptr, out);
     }
 
@@ -2199,7 +2335,8 @@ struct rgbd_elic {
         float* hm = (float*)arena.take((size_t)B * HC2 * sizeof(float));
         auto means_of = [&](const Act& t, float* dstm, int stride) {
             if (dry() || rc || !mean_cache) return;
-            const int r = launch_channel_mean_strided(t.p, t.n, t.h * t.w, t.cs, t.c, dstm, stride, s);
+            const int r = refnum ? launch_channel_mean_ref(t.p, t.n, t.h * t.w, t.cs, t.c, dstm, stride, s)
+                                 : launch_channel_mean_strided(t.p, t.n, t.h * t.w, t.cs, t.c, dstm, stride, s);
             if (r) fail(r);
         };
         means_of(hyp_r, hm, HC2);
@@ -2525,6 +2662,8 @@ struct rgbd_elic {
         se_scale_to(p + ".se", x, 0, f);
         Epi e;
         e.act = last ? ACT_NONE : ACT_LEAKY;
+        Act o;
+        if (!last && deconv_s2_ref(p + ".deconv", f, ACT_LEAKY, &o)) return o;
         return conv(p + ".deconv", f, last ? 1 : 2, last ? 1 : 2, e);
     }
     // synthesis.py:336-343
@@ -4418,14 +4557,15 @@ static bool ends_with(const std::string& s, const char* suf)
 int rgbd_elic_set_ref_blocks(rgbd_elic* m, int32_t kind, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t batch,
                              const int32_t* blocks, int32_t nblocks)
 {
-    if (!m || !blocks || nblocks <= 0 || nblocks > 64 || kind < 0 || kind > 3) return RGBD_EINVAL;
+    if (!m || !blocks || nblocks <= 0 || nblocks > (kind >= 2 ? 65536 : 64) || kind < 0 || kind > 3) return RGBD_EINVAL;
     int sum = 0;
     for (int i = 0; i < nblocks; ++i) {
-        if (blocks[i] <= 0) return RGBD_EINVAL;
+        if (kind == 3 ? blocks[i] < 0 : (kind == 2 ? (blocks[i] < 0 || blocks[i] > 2) : blocks[i] <= 0)) return RGBD_EINVAL;
         sum += blocks[i];
     }
     if (kind == 0 && sum != cin) return RGBD_EINVAL;
     if (kind == 1 && nblocks > 16) return RGBD_EINVAL;
+    if (kind == 2 && nblocks != cout) return RGBD_EINVAL;  // (one class per output row)
     m->ref_tab->blocks[{kind, cin, cout, h, w, batch}] = std::vector<int>(blocks, blocks + nblocks);
     m->graphs_invalidate();
     return RGBD_OK;
@@ -4494,7 +4634,17 @@ int rgbd_elic_finalize(rgbd_elic* m)
         } else if (ends_with(name, ".weight") && t.shape.size() == 2) {
             // SE_Block linears; fc.2 ([C][hidden]) is kept transposed so the gate kernel reads it coalesced
             std::vector<float> hv = t.v;
-            if (ends_with(name, ".fc.2.weight")) {
+            if (m->refnum && (ends_with(name, ".fc.0.weight") || ends_with(name, ".fc.2.weight"))) {
+                // the reference's Linear on one vector: per-row accumulation class, measured per layer shape
+                const int J = (int)t.shape[0], K = (int)t.shape[1];
+                auto ct = m->ref_tab->blocks.find({2, K, J, 0, 0, 1});
+                if (ct != m->ref_tab->blocks.end() && (int)ct->second.size() == J) {
+                    float* dcls = nullptr;
+                    if (const int r = dev_copy(reinterpret_cast<const float*>(ct->second.data()), (size_t)J, &dcls)) return r;
+                    dense[name + ".rowclass"] = dcls;
+                }
+            }
+            if (ends_with(name, ".fc.2.weight") && !m->refnum) {
                 const size_t C = (size_t)t.shape[0], Hd = (size_t)t.shape[1];
                 for (size_t c = 0; c < C; ++c)
                     for (size_t j = 0; j < Hd; ++j) hv[j * C + c] = t.v[c * Hd + j];

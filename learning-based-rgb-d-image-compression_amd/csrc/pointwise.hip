@@ -442,3 +442,255 @@ int launch_small_conv_ref(const SmallConvArgs& a, hipStream_t s)
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// SE_Block in the reference's CPU arithmetic (oracle/cpu_arith.c orc_mean_row / orc_dot_main / orc_dot_rem).
+//
+// (1) Global average pool = ATen's cascade sum over the H*W values of a channel, 8-lane vectors in 4 interleaved accumulator
+// sets: value p of the channel belongs to vector v = p / 8, lane l = p % 8, accumulator k = v % 4 (for the first
+// 4 * (nvec / 4) vectors; the other vectors go to accumulator 0 afterwards); every 16 steps an accumulator is folded into a
+// second-level one; then accumulators 1..3 are added to 0, the n % 8 tail values are summed, the 8 lanes added one by one,
+// and the sum is divided by n.  One thread per (channel, accumulator, lane): 32 threads per channel, 8 channels per
+// workgroup (consecutive threads = consecutive channels of one pixel: 32-byte pieces of the NHWC rows).
+__global__ __launch_bounds__(256) void channel_mean_ref_kernel(const float* __restrict__ x, int HW, int cs, int C,
+                                                               float* __restrict__ mean, int mstride)
+{
+    __shared__ float part[32][8];
+    const int cl = threadIdx.x & 7, kl = threadIdx.x >> 3;  // channel inside the block; k * 8 + l
+    const int k = kl >> 3, l = kl & 7;
+    const int pc = blockIdx.x * 8 + cl;                      // channel POSITION (the mean vector is indexed by position, too)
+    const size_t n = blockIdx.y;
+    const bool live = pc < C;
+    const float* b = x + n * (size_t)HW * cs + (live ? pc : 0);
+    const int V = HW < 8 ? 1 : 8;
+    const int nvec = HW / V, size_ilp = nvec / 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // the cascade's four levels (16 steps each)
+    if (l < V) {
+        int i = 0;
+        for (; i + 16 <= size_ilp;) {
+            for (int j = 0; j < 16; ++j, ++i) a0 = __fadd_rn(a0, b[(size_t)((i * 4 + k) * V + l) * cs]);
+            a1 = __fadd_rn(a1, a0);
+            a0 = 0.f;
+            if ((i & 0xF0) == 0) {
+                a2 = __fadd_rn(a2, a1);
+                a1 = 0.f;
+                if ((i & 0xF00) == 0) {
+                    a3 = __fadd_rn(a3, a2);
+                    a2 = 0.f;
+                }
+            }
+        }
+        for (; i < size_ilp; ++i) a0 = __fadd_rn(a0, b[(size_t)((i * 4 + k) * V + l) * cs]);
+        a0 = __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);  // acc[0] += acc[1], acc[2], acc[3]
+        if (k == 0)
+            for (int v = size_ilp * 4; v < nvec; ++v) a0 = __fadd_rn(a0, b[(size_t)(v * V + l) * cs]);
+    }
+    part[kl][cl] = a0;
+    __syncthreads();
+    if (kl < 8) {  // lane l of the channel: accumulators 1..3 onto 0
+        float p = part[l][cl];
+        p = __fadd_rn(p, part[8 + l][cl]);
+        p = __fadd_rn(p, part[16 + l][cl]);
+        p = __fadd_rn(p, part[24 + l][cl]);
+        part[l][cl] = p;
+    }
+    __syncthreads();
+    if (kl == 0 && live) {
+        float fin = 0.f;
+        for (int p = nvec * V; p < HW; ++p) fin = __fadd_rn(fin, b[(size_t)p * cs]);
+        for (int q = 0; q < V; ++q) fin = __fadd_rn(fin, part[q][cl]);
+        mean[n * mstride + pc] = __fdiv_rn(fin, (float)HW);
+    }
+}
+
+int launch_channel_mean_ref(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s)
+{
+    hipLaunchKernelGGL(channel_mean_ref_kernel, dim3((C + 7) / 8, N), dim3(256), 0, s, x, HW, cs, C, mean, mstride);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// (2) The two bias-free Linear layers on ONE vector (nn.Linear with batch 1 -> MKL sgemm with n = 1): every output row is a dot
+// product in one of three orders (row_class: 0 main, 1 / 2 remainder rows with one / two accumulators; measured per layer
+// shape, refarith_tables.json).  One wavefront per output row; lanes 0..31 are the lanes of the 16-lane accumulators.
+//   x: input vector; xperm: its entries sit at channel POSITIONS (the mean vector)    act: 1 ReLU, 3 sigmoid
+//   yperm: output row j is stored at position rgbd_cperm(j) (the gate vector)
+__device__ __forceinline__ float hred16(float v, int lane)
+{
+    // lanes l + 8, l + 4, l + 2, l + 1 (the order of the CPU's horizontal add); only lane 0's result is used
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) v = __fadd_rn(v, __shfl_down(v, s, 64));
+    (void)lane;
+    return v;
+}
+
+__global__ __launch_bounds__(64) void se_linear_ref_kernel(const float* __restrict__ w, const float* __restrict__ x, int K, int J,
+                                                           int xstride, int xperm, const int* __restrict__ row_class, int act,
+                                                           float* __restrict__ y, int ystride, int yperm)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const size_t n = blockIdx.y;
+    const float* wr = w + (size_t)j * K;
+    const float* xv = x + n * xstride;
+    auto X = [&](int k) { return xv[rgbd_cperm(k, xperm)]; };
+    const int cls = row_class ? row_class[j] : 0;
+    float out;
+    if (cls == 0) {
+        const int nb = (K - 1) / 16, nt = (K - 1) % 16;
+        float acc = 0.f;
+        if (lane == 0) acc = __fmul_rn(wr[0], X(0));
+        if (lane < 16)
+            for (int v = 0; v < nb; ++v) {
+                const int k = 1 + v * 16 + lane;
+                acc = __fmaf_rn(wr[k], X(k), acc);
+            }
+        float S = hred16(lane < 16 ? acc : 0.f, lane);
+        S = __shfl(S, 0, 64);
+        if (nt) {
+            float t = 0.f;
+            if (lane < nt) {
+                const int k = 1 + nb * 16 + lane;
+                t = lane == 0 ? __fmaf_rn(wr[k], X(k), S) : __fmul_rn(wr[k], X(k));
+            }
+            S = hred16(lane < 16 ? t : 0.f, lane);
+        }
+        out = S;
+    } else {
+        const int U = cls, step = U * 16, n2 = (K - 1) / step;
+        float acc = 0.f;
+        if (lane < step)
+            for (int q = 0; q < n2; ++q) {
+                const int k = 1 + step * q + lane;
+                acc = __fmaf_rn(wr[k], X(k), acc);
+            }
+        if (U == 2) acc = __fadd_rn(acc, __shfl_down(acc, 16, 64));  // A + B, lane by lane
+        int pos = 1 + step * n2, rem = K - pos;
+        while (rem >= 16) {
+            if (lane < 16) acc = __fmaf_rn(wr[pos + lane], X(pos + lane), acc);
+            pos += 16;
+            rem -= 16;
+        }
+        if (lane < rem) acc = __fmaf_rn(wr[pos + lane], X(pos + lane), acc);
+        const float S = hred16(lane < 16 ? acc : 0.f, lane);
+        out = __fadd_rn(S, __fmul_rn(wr[0], X(0)));
+    }
+    if (lane == 0) {
+        if (act == ACT_RELU) out = fmaxf(out, 0.f);
+        else if (act == ACT_SIGMOID) out = rgbd_sigmoid_ref(out);
+        y[n * ystride + rgbd_cperm(j, yperm)] = out;
+    }
+}
+
+int launch_se_fc_ref(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, const int* cls0,
+                     const int* cls1, float* hid, float* scale, hipStream_t s, int mstride)
+{
+    // fc.0: [hidden][C] on the means (by position) -> ReLU -> hid[n][hidden];  fc.2: [C][hidden] (NOT transposed) -> sigmoid
+    hipLaunchKernelGGL(se_linear_ref_kernel, dim3(hidden, N), dim3(64), 0, s, w0, mean, C, hidden, mstride > 0 ? mstride : C, 1,
+                       cls0, ACT_RELU, hid, hidden, 0);
+    hipLaunchKernelGGL(se_linear_ref_kernel, dim3(C, N), dim3(64), 0, s, w1, hid, hidden, C, hidden, 0, cls1, ACT_SIGMOID, scale,
+                       C, 1);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stride-2 transposed convolution in the reference's CPU arithmetic (oneDNN brg_deconv; DESIGN.md 4a, oracle/cpu_arith.c
+// orc_deconv_s2): per output phase and column class the taps are accumulated tap by tap (all input channels of a tap, then the
+// next tap) in chains -- the reduction order of a GEMM whose K axis is (tap, channel).  The engine builds that GEMM per
+// (phase, class): this kernel gathers its A matrix, col[pixel][t * cs + c] = x[n][ty + dy_t][j0 + tx + dx_t][c] (zero outside
+// the image), the next one its B matrix from the MFMA kernels' packed weights, and the third scatters the result rows to the
+// phase's positions of the output.
+struct TapList {
+    int n;
+    int8_t dy[16], dx[16];
+    uint8_t slab[16];
+};
+
+__global__ void gather_taps_kernel(const float* __restrict__ x, int B, int h, int w, int cs, int j0, int jw, TapList tl,
+                                   float* __restrict__ col)
+{
+    const int c4n = cs / 4;
+    const size_t total = (size_t)B * h * jw * tl.n * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int t = (int)(r % tl.n);
+        r /= tl.n;
+        const int tx = (int)(r % jw);
+        r /= jw;
+        const int ty = (int)(r % h);
+        const size_t n = r / h;
+        const int iy = ty + tl.dy[t], ix = j0 + tx + tl.dx[t];
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w) v = *reinterpret_cast<const f32x4*>(x + ((n * h + iy) * (size_t)w + ix) * cs + c4 * 4);
+        *reinterpret_cast<f32x4*>(col + (((n * h + ty) * (size_t)jw + tx) * tl.n + t) * cs + c4 * 4) = v;
+    }
+}
+
+__global__ void gather_wslabs_kernel(const float* __restrict__ wp, int cout_pad, int ntaps_total, int cin_pad, TapList tl,
+                                     float* __restrict__ wout)
+{
+    const int c4n = cin_pad / 4;
+    const size_t total = (size_t)cout_pad * tl.n * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int t = (int)(r % tl.n);
+        const size_t co = r / tl.n;
+        *reinterpret_cast<f32x4*>(wout + (co * tl.n + t) * cin_pad + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(wp + (co * ntaps_total + tl.slab[t]) * cin_pad + c4 * 4);
+    }
+}
+
+// dst[n][2 ty + py][2 (j0 + tx) + px][:] = src[(n h + ty) jw + tx][:]
+__global__ void scatter_phase_kernel(const float* __restrict__ src, int B, int h, int jw, int scs, int j0, int py, int px,
+                                     float* __restrict__ dst, int OW, int dcs, int c4n)
+{
+    const size_t total = (size_t)B * h * jw * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int tx = (int)(r % jw);
+        r /= jw;
+        const int ty = (int)(r % h);
+        const size_t n = r / h;
+        *reinterpret_cast<f32x4*>(dst + ((n * 2 * h + 2 * ty + py) * (size_t)OW + 2 * (j0 + tx) + px) * dcs + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(src + ((n * h + ty) * (size_t)jw + tx) * scs + c4 * 4);
+    }
+}
+
+int launch_gather_taps(const float* x, int B, int h, int w, int cs, int j0, int jw, int ntap, const int* dy, const int* dx,
+                       float* col, hipStream_t s)
+{
+    if (ntap < 1 || ntap > 16 || cs % 4) return RGBD_EINVAL;
+    TapList tl{};
+    tl.n = ntap;
+    for (int t = 0; t < ntap; ++t) tl.dy[t] = (int8_t)dy[t], tl.dx[t] = (int8_t)dx[t];
+    const size_t work = (size_t)B * h * jw * ntap * (cs / 4);
+    hipLaunchKernelGGL(gather_taps_kernel, dim3(grid_for(work)), dim3(256), 0, s, x, B, h, w, cs, j0, jw, tl, col);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+int launch_gather_wslabs(const float* wp, int cout_pad, int ntaps_total, int cin_pad, int ntap, const int* slab, float* wout,
+                         hipStream_t s)
+{
+    if (ntap < 1 || ntap > 16 || cin_pad % 4) return RGBD_EINVAL;
+    TapList tl{};
+    tl.n = ntap;
+    for (int t = 0; t < ntap; ++t) tl.slab[t] = (uint8_t)slab[t];
+    const size_t work = (size_t)cout_pad * ntap * (cin_pad / 4);
+    hipLaunchKernelGGL(gather_wslabs_kernel, dim3(grid_for(work)), dim3(256), 0, s, wp, cout_pad, ntaps_total, cin_pad, tl, wout);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}
+
+int launch_scatter_phase(const float* src, int B, int h, int jw, int scs, int j0, int py, int px, float* dst, int OW, int dcs,
+                         int C, hipStream_t s)
+{
+    if (C % 4 || scs % 4 || dcs % 4) return RGBD_EINVAL;
+    const size_t work = (size_t)B * h * jw * (C / 4);
+    hipLaunchKernelGGL(scatter_phase_kernel, dim3(grid_for(work)), dim3(256), 0, s, src, B, h, jw, scs, j0, py, px, dst, OW, dcs, C / 4);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}

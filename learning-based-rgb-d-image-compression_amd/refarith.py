@@ -33,4 +33,17 @@ def push(L, handle, check):
         arr = (ctypes.c_int32 * len(blocks))(*blocks)
         check(L.rgbd_elic_set_ref_blocks(handle, 1, cin, cout, h, w, k * 100 + stride * 10 + pad, arr, len(blocks)), "set_ref_blocks")
         n += 1
+    # kind 2: SE_Block Linear layers on one vector: dot-product class per output row, run-length encoded
+    for K, J, rle in tables().get("linear", []):
+        cls = []
+        for c, cnt in zip(rle[0::2], rle[1::2]):
+            cls += [c] * cnt
+        arr = (ctypes.c_int32 * len(cls))(*cls)
+        check(L.rgbd_elic_set_ref_blocks(handle, 2, K, J, 0, 0, 1, arr, len(cls)), "set_ref_blocks")
+        n += 1
+    # kind 3: stride-2 transposed convs of the hyper-synthesis: tap chains per (phase, column), flattened
+    for cin, cout, k, h, w, b, flat in tables().get("deconv_s2", []):
+        arr = (ctypes.c_int32 * len(flat))(*flat)
+        check(L.rgbd_elic_set_ref_blocks(handle, 3, cin, cout, h, w, b, arr, len(flat)), "set_ref_blocks")
+        n += 1
     return n

@@ -201,3 +201,213 @@ void orc_sigmoid(const float* x, float* y, int64_t n)
 {
     for (int64_t i = 0; i < n; i++) y[i] = 1.0f / (1.0f + orc_expf_u10(0.0f - x[i]));
 }
+
+/* ---- torch's CPU bilinear upsampling (UpSampleKernel.cpp), align_corners = False -------------------------------------------
+ * x [C][h][w] -> y [C][H][W].  The source index is one fused multiply-add; the taps are combined in one of two ways:
+ *   H + W > 128  (generic separable kernel):      t_k = fma(v_k0, lx0, v_k1 * lx1);  out = fma(t_0, ly0, t_1 * ly1)
+ *   H + W <= 128 (channels-last vector kernel):   w_ij = ly_i * lx_j;
+ *        channels < C - C % 16:  fma(w00, v00, fma(w01, v01, fma(w11, v11, w10 * v10)))
+ *        the C % 16 tail:        fma(w11, v11, fma(w10, v10, fma(w00, v00, w01 * v01)))                                  */
+void orc_bilinear(const float* x, int C, int h, int w, float* y, int H, int W)
+{
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (int c = 0; c < C; c++)
+        for (int oy = 0; oy < H; oy++)
+            for (int ox = 0; ox < W; ox++) {
+                float fy = fmaf(sy, (float)oy + 0.5f, -0.5f), fx = fmaf(sx, (float)ox + 0.5f, -0.5f);
+                if (fy < 0) fy = 0;
+                if (fx < 0) fx = 0;
+                int y0 = (int)fy, x0 = (int)fx;
+                if (y0 > h - 1) y0 = h - 1;
+                if (x0 > w - 1) x0 = w - 1;
+                const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+                float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+                if (ly1 > 1) ly1 = 1;
+                if (lx1 > 1) lx1 = 1;
+                if (ly1 < 0) ly1 = 0;
+                if (lx1 < 0) lx1 = 0;
+                const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                const float* b = x + (size_t)c * h * w;
+                const float v00 = b[y0 * w + x0], v01 = b[y0 * w + x1], v10 = b[y1 * w + x0], v11 = b[y1 * w + x1];
+                float o;
+                if (H + W > 128) {
+                    const float t0 = fmaf(v00, lx0, v01 * lx1), t1 = fmaf(v10, lx0, v11 * lx1);
+                    o = fmaf(t0, ly0, t1 * ly1);
+                } else {
+                    const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+                    if (c < C - C % 16) o = fmaf(w00, v00, fmaf(w01, v01, fmaf(w11, v11, w10 * v10)));
+                    else o = fmaf(w11, v11, fmaf(w10, v10, fmaf(w00, v00, w01 * v01)));
+                }
+                y[((size_t)c * H + oy) * W + ox] = o;
+            }
+}
+
+/* ---- mean over a contiguous row: ATen's cascade sum (SumKernel.cpp: vectorized_inner_sum / row_sum / multi_row_sum), 8-lane
+ * vectors (4 interleaved accumulator vectors, cascade levels of 16 steps), rows shorter than 8 in its scalar form; then / n  */
+static int orc_ceil_log2(long x)
+{
+    if (x <= 2) return 1;
+    int r = 0;
+    long v = x - 1;
+    while (v > 0) {
+        v >>= 1;
+        r++;
+    }
+    return r;
+}
+float orc_mean_row(const float* x, int n)
+{
+    const int V = n < 8 ? 1 : 8;
+    const int vec_size = n / V, size_ilp = vec_size / 4;
+    float part[4][8];
+    memset(part, 0, sizeof(part));
+    {
+        int lp = orc_ceil_log2(size_ilp) / 4;
+        if (lp < 4) lp = 4;
+        const int step = 1 << lp;
+        const long mask = step - 1;
+        float acc[4][4][8];
+        memset(acc, 0, sizeof(acc));
+        int i = 0;
+        for (; i + step <= size_ilp;) {
+            for (int j = 0; j < step; j++, i++)
+                for (int k = 0; k < 4; k++)
+                    for (int l = 0; l < V; l++) acc[0][k][l] += x[((long)i * 4 + k) * V + l];
+            for (int j = 1; j < 4; j++) {
+                for (int k = 0; k < 4; k++)
+                    for (int l = 0; l < V; l++) {
+                        acc[j][k][l] += acc[j - 1][k][l];
+                        acc[j - 1][k][l] = 0;
+                    }
+                if ((i & (mask << (j * lp))) != 0) break;
+            }
+        }
+        for (; i < size_ilp; i++)
+            for (int k = 0; k < 4; k++)
+                for (int l = 0; l < V; l++) acc[0][k][l] += x[((long)i * 4 + k) * V + l];
+        for (int j = 1; j < 4; j++)
+            for (int k = 0; k < 4; k++)
+                for (int l = 0; l < V; l++) acc[0][k][l] += acc[j][k][l];
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < V; l++) part[k][l] = acc[0][k][l];
+    }
+    for (int v = size_ilp * 4; v < vec_size; v++)
+        for (int l = 0; l < V; l++) part[0][l] += x[(long)v * V + l];
+    for (int k = 1; k < 4; k++)
+        for (int l = 0; l < V; l++) part[0][l] += part[k][l];
+    float fin = 0.f;
+    for (int k = vec_size * V; k < n; k++) fin += x[k];
+    for (int l = 0; l < V; l++) fin += part[0][l];
+    return fin / (float)n;
+}
+void orc_mean_rows(const float* x, int rows, int n, float* y)
+{
+    for (int r = 0; r < rows; r++) y[r] = orc_mean_row(x + (size_t)r * n, n);
+}
+
+/* ---- y = W x for ONE input vector (nn.Linear with batch 1 -> MKL sgemm with n = 1): each output row is a dot product in one
+ * of three orders, depending on where the row falls in MKL's row partition (class per row: measured, refarith_tables.json):
+ *   0 "main":  lane l of ONE 16-lane accumulator takes elements 1 + 16 v + l; element 0 starts lane 0's chain; lanes reduced
+ *              l + 8, l + 4, l + 2, l + 1; then the (K - 1) % 16 tail elements as a second vector whose lane 0 continues from
+ *              the body's sum, reduced the same way
+ *   2 "rem2":  two accumulators (elements 1 + 32 j + l and 17 + 32 j + l), added lane-wise, leftover vectors / tail fma'd in,
+ *              lanes reduced, element 0's product added last
+ *   1 "rem1":  the same with one accumulator                                                                                */
+static float orc_hred16(float* a)
+{
+    for (int s = 8; s >= 1; s /= 2)
+        for (int l = 0; l < s; l++) a[l] = a[l] + a[l + s];
+    return a[0];
+}
+float orc_dot_main(const float* w, const float* x, int K)
+{
+    float acc[16];
+    memset(acc, 0, sizeof(acc));
+    acc[0] = w[0] * x[0];
+    const int nb = (K - 1) / 16, nt = (K - 1) % 16;
+    for (int v = 0; v < nb; v++)
+        for (int l = 0; l < 16; l++) {
+            const int k = 1 + v * 16 + l;
+            acc[l] = fmaf(w[k], x[k], acc[l]);
+        }
+    float S = orc_hred16(acc);
+    if (nt) {
+        float t[16];
+        memset(t, 0, sizeof(t));
+        for (int l = 0; l < nt; l++) {
+            const int k = 1 + nb * 16 + l;
+            t[l] = l == 0 ? fmaf(w[k], x[k], S) : w[k] * x[k];
+        }
+        S = orc_hred16(t);
+    }
+    return S;
+}
+float orc_dot_rem(const float* w, const float* x, int K, int U)
+{
+    float A[2][16];
+    memset(A, 0, sizeof(A));
+    const int step = U * 16, n2 = (K - 1) / step;
+    for (int j = 0; j < n2; j++)
+        for (int u = 0; u < U; u++)
+            for (int l = 0; l < 16; l++) {
+                const int k = 1 + step * j + u * 16 + l;
+                A[u][l] = fmaf(w[k], x[k], A[u][l]);
+            }
+    int pos = 1 + step * n2, rem = K - pos;
+    float acc[16];
+    for (int l = 0; l < 16; l++) acc[l] = U == 2 ? A[0][l] + A[1][l] : A[0][l];
+    while (rem >= 16) {
+        for (int l = 0; l < 16; l++) acc[l] = fmaf(w[pos + l], x[pos + l], acc[l]);
+        pos += 16;
+        rem -= 16;
+    }
+    for (int l = 0; l < rem; l++) acc[l] = fmaf(w[pos + l], x[pos + l], acc[l]);
+    const float S = orc_hred16(acc);
+    return S + w[0] * x[0];
+}
+void orc_linear_b1(const float* W, const float* x, int J, int K, const int* row_class, float* y)
+{
+    for (int j = 0; j < J; j++) {
+        const int c = row_class ? row_class[j] : 0;
+        y[j] = c == 0 ? orc_dot_main(W + (size_t)j * K, x, K) : orc_dot_rem(W + (size_t)j * K, x, K, c);
+    }
+}
+
+/* ---- conv_transpose2d, stride 2, kernel k, padding k/2, output_padding 1 (oneDNN brg_deconv + brgconv_strided) ----------------
+ * w [C][O][k][k].  Output pixel (oy, ox) of phase (py, px) = (oy & 1, ox & 1) gathers the taps with (oy + pad - ky) even and
+ * (ox + pad - kx) even.  The taps are accumulated in CHAINS: inside a chain every tap continues the fma chain of the previous
+ * one, channels ascending inside a tap; a new chain starts from 0; the chain sums are added in order; the bias comes last.
+ * Which taps share a chain depends on the layer shape and on the column block of the output pixel (measured: a "recipe" per
+ * (py, px, j = ox / 2)): desc[desc_off[(py * 2 + px) * Win + j]] = n, then n x {ky, kx, fresh}.  Taps outside the image add
+ * nothing (exact zeros). */
+void orc_deconv_s2(const float* x, int N, int C, int H, int W, const float* w, int O, int k, const float* b, const int* desc_off,
+                   const int* desc, float* y)
+{
+    const int pad = k / 2, OH = 2 * H, OW = 2 * W;
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int n = 0; n < N; n++)
+        for (int o = 0; o < O; o++)
+            for (int oy = 0; oy < OH; oy++)
+                for (int ox = 0; ox < OW; ox++) {
+                    const int* d = desc + desc_off[((oy & 1) * 2 + (ox & 1)) * W + ox / 2];
+                    const int nt = d[0];
+                    float tot = 0.f, s = 0.f;
+                    int have = 0;
+                    for (int t = 0; t < nt; t++) {
+                        const int ky = d[1 + 3 * t], kx = d[2 + 3 * t], fresh = d[3 + 3 * t];
+                        if (fresh && t > 0) {
+                            tot = have ? tot + s : s;
+                            have = 1;
+                            s = 0.f;
+                        }
+                        const int ty = oy + pad - ky, tx = ox + pad - kx;
+                        if (ty < 0 || tx < 0 || (ty & 1) || (tx & 1)) continue;
+                        const int iy = ty / 2, ix = tx / 2;
+                        if (iy >= H || ix >= W) continue;
+                        for (int c = 0; c < C; c++)
+                            s = fmaf(x[(((size_t)n * C + c) * H + iy) * W + ix], w[(((size_t)c * O + o) * k + ky) * k + kx], s);
+                    }
+                    tot = have ? tot + s : s;
+                    y[(((size_t)n * O + o) * OH + oy) * OW + ox] = b ? tot + b[o] : tot;
+                }
+}

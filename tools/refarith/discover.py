@@ -84,6 +84,172 @@ def probe_im2col_kblocks(cin, cout, k, h, w, pad, stride=1):
     return [bounds[i + 1] - bounds[i] for i in range(len(bounds) - 1)]
 
 
+def classify_linear_rows(K, J, samples=6):
+    """nn.Linear(K -> J, bias=False) applied to ONE vector: per output row, which of the dot-product orders of
+    oracle/cpu_arith.c (0 main, 1 / 2 remainder rows with one / two accumulators) reproduces torch on random data"""
+    import ctypes
+    from oracle import cpu_arith as ca
+
+    L = ca.lib()
+    L.orc_dot_main.restype = ctypes.c_float
+    L.orc_dot_rem.restype = ctypes.c_float
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    g = torch.Generator().manual_seed(K * 7919 + J)
+    W = (torch.randn(J, K, generator=g) / K ** 0.5).contiguous()
+    xs = [torch.randn(1, K, generator=g) for _ in range(samples)]
+    refs = [F.linear(x, W)[0].numpy() for x in xs]
+    Wn = W.numpy()
+    out = []
+    for j in range(J):
+        fit = None
+        for cls in (0, 2, 1):
+            ok = True
+            for x, r in zip(xs, refs):
+                xn = x[0].numpy()
+                v = L.orc_dot_main(P(Wn[j]), P(xn), K) if cls == 0 else L.orc_dot_rem(P(Wn[j]), P(xn), K, cls)
+                if np.float32(v) != r[j]:
+                    ok = False
+                    break
+            if ok:
+                fit = cls
+                break
+        if fit is None:
+            raise RuntimeError(f"Linear {K}->{J}: row {j} fits none of the known accumulation orders")
+        out.append(fit)
+    return out
+
+
+def _dc_ranks_at(cin, cout, k, h, w, oy, ox, b=1):
+    """stride-2 transposed conv: for every tap that reaches output pixel (oy, ox), its position from the END of its fma chain
+    (in units of taps = cin terms)"""
+    pad = k // 2
+    taps = [(ky, kx) for ky in range(k) for kx in range(k) if (oy + pad - ky) % 2 == 0 and (ox + pad - kx) % 2 == 0
+            and 0 <= (oy + pad - ky) // 2 < h and 0 <= (ox + pad - kx) // 2 < w]
+    nv = len(taps) * cin
+    res = {}
+    for g0 in range(0, len(taps), cout):
+        grp = taps[g0:g0 + cout]
+        wt = torch.ones(cin, cout, k, k)
+        for o, (ky, kx) in enumerate(grp):
+            wt[0, o, ky, kx] = BIG
+        y = F.conv_transpose2d(torch.ones(b, cin, h, w), wt, None, stride=2, padding=pad, output_padding=1)
+        for o, t in enumerate(grp):
+            res[t] = int(round((nv - 1 - float(y[0, o, oy, ox] - BIG) + 1) / cin))
+    return res
+
+
+def _dc_chain_order(cin, cout, k, h, w, oy, ox, chains, b=1):
+    """the order in which the chain sums are added: the LAST chain is the one whose value survives a +BIG / -BIG pair placed
+    in any two other chains; remove it and repeat"""
+    import itertools
+
+    pad = k // 2
+    rem, order = list(range(len(chains))), []
+    x = torch.ones(b, cin, h, w)
+    while len(rem) > 2:
+        found = None
+        for L in rem:
+            pairs = list(itertools.combinations([c for c in rem if c != L], 2))
+            ok = True
+            for g0 in range(0, len(pairs), cout):
+                grp = pairs[g0:g0 + cout]
+                wt = torch.zeros(cin, cout, k, k)
+                for o, (i, j) in enumerate(grp):
+                    wt[0, o, chains[i][0][0], chains[i][0][1]] = BIG
+                    wt[0, o, chains[j][0][0], chains[j][0][1]] = -BIG
+                    wt[0, o, chains[L][0][0], chains[L][0][1]] = 1.0
+                y = F.conv_transpose2d(x, wt, None, stride=2, padding=pad, output_padding=1)
+                if not all(float(y[0, o, oy, ox]) == 1.0 for o in range(len(grp))):
+                    ok = False
+                    break
+            if ok:
+                found = L
+                break
+        if found is None:
+            raise RuntimeError("deconv: no consistent chain order")
+        order.append(found)
+        rem.remove(found)
+    return rem + order[::-1]
+
+
+def _dc_recipe_at(cin, cout, k, h, w, oy, ox, b=1):
+    r = _dc_ranks_at(cin, cout, k, h, w, oy, ox, b)
+    taps = sorted(r)
+    kys = sorted(set(t[0] for t in taps))
+    kxs = sorted(set(t[1] for t in taps))
+    if all(v == 1 for v in r.values()):
+        chains = [[t] for t in taps]
+    else:  # chains are sets of whole kx columns walked ky -> kx: the last ky row's ranks tell which columns share one
+        last, groups, cur = kys[-1], [], []
+        for kx in kxs:
+            cur.append(kx)
+            if r[(last, kx)] == 1:
+                groups.append(cur)
+                cur = []
+        if cur:
+            raise RuntimeError(f"deconv: unexpected chain structure {r}")
+        chains = [[(ky, kx) for ky in kys for kx in g if (ky, kx) in r] for g in groups]
+        for ch in chains:
+            for i, t in enumerate(ch):
+                if r[t] != len(ch) - i:
+                    raise RuntimeError(f"deconv: unexpected chain structure {r}")
+    if len(chains) > 2:
+        chains = [chains[i] for i in _dc_chain_order(cin, cout, k, h, w, oy, ox, chains, b)]
+    return chains
+
+
+def probe_deconv_s2(cin, cout, k, h, w, b=1):
+    """recipe per (py, px, j = ox / 2): chains of taps in addition order, flattened as
+    [n, ky, kx, fresh, ky, kx, fresh, ...] for the 4 * w (phase, column) pairs in order; checked against torch on random data"""
+    import ctypes
+    from oracle import cpu_arith as ca
+
+    rec = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            rows = [2 * (h // 2) + py] if h > 3 else [2 * i + py for i in range(h)]
+            for j in range(w):
+                ox = 2 * j + px
+                per_row = [_dc_recipe_at(cin, cout, k, h, w, oy, ox, b) for oy in rows]
+                if len(per_row) == 1:
+                    rec[(py, px, j)] = per_row[0]
+                    continue
+                taps = sorted(set(t for ch in per_row for c in ch for t in c))
+                if all(all(len(c) == 1 for c in ch) for ch in per_row):
+                    rec[(py, px, j)] = [[t] for t in sorted(taps, key=lambda t: (t[1], t[0]))]
+                else:
+                    groups = []
+                    for ch in per_row:
+                        for c in ch:
+                            g = tuple(sorted(set(t[1] for t in c)))
+                            if g not in groups:
+                                groups.append(g)
+                    groups.sort()
+                    rec[(py, px, j)] = [[(ky, kx) for ky in sorted(set(t[0] for t in taps)) for kx in g if (ky, kx) in taps]
+                                        for g in groups]
+    flat, off = [], []
+    for py in (0, 1):
+        for px in (0, 1):
+            for j in range(w):
+                off.append(len(flat))
+                f = [(ky, kx, 1 if i == 0 else 0) for c in rec[(py, px, j)] for i, (ky, kx) in enumerate(c)]
+                flat += [len(f)] + [v for t in f for v in t]
+    # verify on random data
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    g = torch.Generator().manual_seed(cin + h * 131 + w)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, k, k, generator=g) / (cin * 6) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, wt, bias, stride=2, padding=k // 2, output_padding=1).numpy()
+    y = np.empty_like(ref)
+    offa, desca = np.array(off, np.int32), np.array(flat, np.int32)
+    ca.lib().orc_deconv_s2(P(np.ascontiguousarray(x.numpy())), b, cin, h, w, P(np.ascontiguousarray(wt.numpy())), cout, k,
+                           P(bias.numpy()), P(offa), P(desca), P(y))
+    if not np.array_equal(y, ref):
+        raise RuntimeError(f"deconv {cin}->{cout} {h}x{w}: the measured recipe does not reproduce torch")
+    return flat
+
+
 def collect_shapes(kind, H, W, B):
     """every conv call of one compress + decompress (and forward) of the oracle at this input shape"""
     from oracle import elic_oracle as eo
@@ -100,7 +266,7 @@ def collect_shapes(kind, H, W, B):
 
     def ld(sd, name, x, stride):
         w = sd[name + ".weight"]
-        calls.append(("deconv", tuple(x.shape), tuple(w.shape), stride, w.shape[-1] // 2))
+        calls.append(("deconv:" + name.split(".")[0], tuple(x.shape), tuple(w.shape), stride, w.shape[-1] // 2))
         return od(sd, name, x, stride)
 
     eo._conv, eo._deconv = lc, ld
@@ -139,8 +305,8 @@ def main():
         jobs = jobs[:1]
     tab = {"meta": {"torch": torch.__version__, "threads": torch.get_num_threads(),
                     "note": "measured by tools/refarith/discover.py on the machine that produced tests/golden/"},
-           "conv1x1": [], "im2col": []}
-    seen1, seen2 = set(), set()
+           "conv1x1": [], "im2col": [], "deconv_s2": []}
+    seen1, seen2, seen3 = set(), set(), set()
     for kind, H, W, B in jobs:
         try:
             shapes = collect_shapes(kind, H, W, B)
@@ -148,6 +314,12 @@ def main():
             print("skip", kind, H, W, B, repr(e)[:120])
             continue
         for (op, xs, ws, stride, pad) in shapes:
+            if op == "deconv:h_s" and stride == 2:  # the hyper-synthesis stages feed every entropy parameter
+                key = (xs[1], ws[1], ws[2], xs[2], xs[3], xs[0])
+                if key not in seen3:
+                    seen3.add(key)
+                    tab["deconv_s2"].append(list(key) + [probe_deconv_s2(*key)])
+                continue
             if op != "conv":
                 continue
             n, cin, h, w = xs
@@ -166,11 +338,31 @@ def main():
         print(kind, H, W, B, "->", len(tab["conv1x1"]), "1x1 entries,", len(tab["im2col"]), "im2col entries", flush=True)
     tab["conv1x1"].sort()
     tab["im2col"].sort()
+    # SE_Block Linear layers (batch 1): row classes per (K, J)
+    from rgbd_amd import synth
+    lin = set()
+    for name, t in synth.synthetic_state_dict(0).items():
+        if ".se.fc." in name and name.endswith(".weight"):
+            lin.add((int(t.shape[1]), int(t.shape[0])))
+    tab["linear"] = []
+    for K, J in sorted(lin):
+        cls = classify_linear_rows(K, J)
+        # run-length encoded: [class, count, class, count, ...]
+        rle = []
+        for c in cls:
+            if rle and rle[-2] == c:
+                rle[-1] += 1
+            else:
+                rle += [c, 1]
+        tab["linear"].append([K, J, rle])
+    print(len(tab["linear"]), "linear entries", flush=True)
     with open(OUT, "w") as f:
         f.write("{\n")
         f.write('"meta": ' + json.dumps(tab["meta"]) + ",\n")
-        for sect in ("conv1x1", "im2col"):
-            f.write(f'"{sect}": [\n' + ",\n".join(json.dumps(e) for e in tab[sect]) + "\n]" + ("," if sect == "conv1x1" else "") + "\n")
+        tab["deconv_s2"].sort()
+        sects = ("conv1x1", "im2col", "linear", "deconv_s2")
+        for sect in sects:
+            f.write(f'"{sect}": [\n' + ",\n".join(json.dumps(e) for e in tab[sect]) + "\n]" + ("," if sect != sects[-1] else "") + "\n")
         f.write("}\n")
     print("wrote", OUT)
 
