@@ -212,6 +212,7 @@ struct SmallConvArgs {
     float* y;
     float* y2;          // optional second destination
     int N, H, W, xcs, C, cin_pad, O, OH, OW, ycs, r1cs, mcs, r2cs, y2cs, K, stride, pad, act, nb;
+    int ckbd;           // 1 / 2: only the anchor / non-anchor positions are computed (ConvArgs::ckbd)
     int kb[17];         // K-block boundaries in k = c * K * K + ky * K + kx
 };
 int launch_small_conv_ref(const SmallConvArgs& a, hipStream_t s);

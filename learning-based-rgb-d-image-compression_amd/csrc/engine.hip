@@ -1264,7 +1264,7 @@ struct rgbd_elic {
         const int k = pc->k, OH = (x.h + 2 * pad - k) / stride + 1, OW = (x.w + 2 * pad - k) / stride + 1;
         Act y = dst ? *dst : alloc(x.n, OH, OW, pc->cout);
         if (dry() || rc) return y;
-        if (ep.ckbd || y.h != OH || y.w != OW || y.c != pc->cout) {
+        if (y.h != OH || y.w != OW || y.c != pc->cout || (ep.ckbd && stride != 1)) {
             fail(RGBD_EINVAL);
             return y;
         }
@@ -1287,6 +1287,7 @@ struct rgbd_elic {
         a.stride = stride;
         a.pad = pad;
         a.act = ep.act;
+        a.ckbd = ep.ckbd;
         if (ep.res1) a.res1 = ep.res1->p, a.r1cs = ep.res1->cs;
         if (ep.mul) a.mul = ep.mul->p, a.mcs = ep.mul->cs;
         if (ep.res2) a.res2 = ep.res2->p, a.r2cs = ep.res2->cs;
@@ -1319,6 +1320,10 @@ struct rgbd_elic {
         Act out;
         if (!fuse1x1 && conv_kpacked(name, x, stride, pad, ep, dst, &out)) return out;
         if (!fuse1x1 && small_tensor_layer(name, x)) return conv_small(name, x, stride, pad, ep, dst);
+        if (refnum && !fuse1x1 && !dst && stride == 2 && pad == 2 && !ep.res1 && !ep.mul && !ep.res2 && !ep.dup && !ep.ckbd) {
+            Act o;  // a stride-2 transposed conv with a measured recipe (the hyper-synthesis stages)
+            if (deconv_s2_ref(name, x, ep.act, &o)) return o;
+        }
         ConvPlan cp = conv_plan(name, x, stride, pad, ep, dst, fuse1x1, lead1x1, lead_dst);
         conv_issue(cp);
         return cp.y;
@@ -4137,25 +4142,23 @@ int rgbd_pointwise_nchw(int32_t op, const float* x_dev, int32_t n, int32_t c, in
     float *&xin = b.xin, *&yout = b.yout, *&aux = b.aux, *&dw0 = b.dw0, *&dw1 = b.dw1;
     HIP_TRY(hipMalloc((void**)&xin, (size_t)n * h * w * cs * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&yout, (size_t)n * oh * ow * cs * sizeof(float)));
-    int rc = launch_nchw_to_nhwc16(x_dev, n, c, h, w, xin, cs, s);
+    // (the operators as the codec runs them: channels stored permuted, the reference's CPU arithmetic -- DESIGN.md 4a)
+    int rc = launch_nchw_to_nhwc16(x_dev, n, c, h, w, xin, cs, s, 1);
     if (!rc && op == 0) rc = launch_maxpool7s3(xin, n, h, w, cs, yout, oh, ow, s);
-    if (!rc && op == 1) rc = launch_bilinear(xin, n, h, w, cs, yout, oh, ow, s);
+    if (!rc && op == 1) rc = launch_bilinear(xin, n, h, w, cs, yout, oh, ow, s, nullptr, nullptr, c);
     if (!rc && op >= 2) {
         const int hid = c / 16;
-        std::vector<float> w1t((size_t)c * hid);  // fc.2.weight [c][hid] -> [hid][c], as rgbd_elic_finalize stores it
-        for (int i = 0; i < c; ++i)
-            for (int j = 0; j < hid; ++j) w1t[(size_t)j * c + i] = w1[(size_t)i * hid + j];
         HIP_TRY(hipMalloc((void**)&aux, (size_t)n * (2 * c + hid + 1) * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&dw0, (size_t)c * hid * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&dw1, (size_t)c * hid * sizeof(float)));
         HIP_TRY(hipMemcpy(dw0, w0, (size_t)c * hid * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dw1, w1t.data(), (size_t)c * hid * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dw1, w1, (size_t)c * hid * sizeof(float), hipMemcpyHostToDevice));
         float *mean = aux, *sc = aux + (size_t)n * c, *hd = aux + (size_t)2 * n * c;
-        rc = launch_channel_mean(xin, n, h * w, cs, c, mean, s);
-        if (!rc) rc = launch_se_fc(mean, n, c, hid, dw0, dw1, hd, sc, s);
+        rc = launch_channel_mean_ref(xin, n, h * w, cs, c, mean, c, s);
+        if (!rc) rc = launch_se_fc_ref(mean, n, c, hid, dw0, dw1, nullptr, nullptr, hd, sc, s);  // (every row in the main order)
         if (!rc) rc = launch_channel_scale_to(xin, n, h * w, cs, c, sc, op == 3 ? 1 : 0, yout, cs, s);
     }
-    if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, c, oh, ow, cs, y_dev, 0, s);
+    if (!rc) rc = launch_nhwc_to_nchw_clamp(yout, n, c, oh, ow, cs, y_dev, 0, s, 1);
     const hipError_t e = hipStreamSynchronize(s);
     if (!rc && e != hipSuccess) rc = RGBD_EHIP;
     return rc;

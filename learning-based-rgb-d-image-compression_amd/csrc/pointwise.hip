@@ -408,6 +408,7 @@ __global__ void small_conv_ref_kernel(SmallConvArgs a)
         t /= a.OW;
         const int oy = (int)(t % a.OH);
         const size_t n = t / a.OH;
+        if (a.ckbd && ((oy + ox) & 1) != (a.ckbd == 1 ? 1 : 0)) continue;  // (the other half is left untouched)
         const int po = rgbd_cperm(o);
         const float* wrow = a.w + (size_t)po * taps * a.cin_pad;
         float tot = 0.f;

@@ -1,0 +1,147 @@
+"""oracle/cpu_arith.c -- the C restatement of the THIRD-PARTY CPU arithmetic the reference's float path ends in (oneDNN / MKL /
+Sleef / ATen accumulation orders) -- pinned two ways:
+
+  1. against torch CPU itself, bit for bit, on random data, with the measured structures of
+     learning-based-rgb-d-image-compression_amd/refarith_tables.json.  Meaningful where torch picks the kernels it picked in the
+     survey container (8 threads, AVX-512: the machine that produced tests/golden/); on another CPU a case whose torch result
+     differs is skipped, not failed -- the tables describe THAT machine's libraries;
+  2. against frozen hashes (tests/golden/refarith_pins.json, recorded in the survey container where (1) holds), so the C
+     code cannot drift on any machine.  RGBD_RECORD_PINS=1 re-records.
+
+The GPU kernels are compared with this file bit for bit in tests/test_gpu_refarith.py / test_gpu_pointwise.py, and end to end
+through the reference's golden streams in tests/test_gpu_parity_pinned.py."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_arith as ca
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = os.path.join(HERE, "golden", "refarith_pins.json")
+TABLES = json.load(open(os.path.join(os.path.dirname(HERE), "learning-based-rgb-d-image-compression_amd", "refarith_tables.json")))
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+_pins = {}
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a + np.float32(0.0)).tobytes()).hexdigest()[:16]
+
+
+def _same_or_skip(got, ref, what):
+    _pins[what] = _sha(got)
+    if not np.array_equal(got, ref):
+        if torch.get_num_threads() != TABLES["meta"]["threads"] or not torch.backends.mkldnn.is_available():
+            pytest.skip(f"{what}: this machine's torch differs from the survey container's (threads / kernels)")
+        rel = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert rel < 1e-5, (what, rel)
+        pytest.skip(f"{what}: torch on this CPU takes another accumulation order ({int((got != ref).sum())} of {got.size} "
+                    f"outputs differ by <= {rel:.1e}); the frozen pins below still hold the C code")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _threads():
+    old = torch.get_num_threads()
+    torch.set_num_threads(TABLES["meta"]["threads"])
+    yield
+    torch.set_num_threads(old)
+    if os.environ.get("RGBD_RECORD_PINS"):
+        json.dump(_pins, open(PINS, "w"), indent=1, sort_keys=True)
+
+
+def _rnd(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k,s,pad,h,w", [(96, 96, 3, 1, 1, 32, 40), (384, 192, 5, 2, 2, 32, 48), (3, 192, 5, 2, 2, 64, 64),
+                                                 (48, 48, 3, 2, 0, 33, 47), (213, 42, 3, 1, 1, 16, 16), (16, 224, 5, 1, 2, 16, 16)])
+def test_direct_conv_is_a_block_per_16_channels(cin, cout, k, s, pad, h, w):
+    x, wt, b = _rnd(1, 1, cin, h, w), _rnd(2, cout, cin, k, k, scale=(cin * k * k) ** -0.5), _rnd(3, cout)
+    got = ca.conv2d(x.numpy(), wt.numpy(), b.numpy(), s, pad)
+    _same_or_skip(got, F.conv2d(x, wt, b, stride=s, padding=pad).numpy(), f"direct_{cin}_{cout}_{k}_{s}_{h}x{w}")
+
+
+def test_one_by_one_conv_reduce_blocks_from_the_table():
+    rows = [r for r in TABLES["conv1x1"] if r[4] == 1 and r[0] * r[2] * r[3] > 20480]
+    pick = [r for r in rows if len(r[5]) > 1][:6] + [r for r in rows if len(r[5]) == 1][:3]
+    assert len(pick) >= 6
+    for cin, cout, h, w, b, blocks in pick:
+        x, wt, bias = _rnd(cin, b, cin, h, w), _rnd(cout, cout, cin, 1, 1, scale=cin ** -0.5), _rnd(7, cout)
+        got = ca.conv2d(x.numpy(), wt.numpy(), bias.numpy(), blocks=blocks, bias_mode=2)
+        _same_or_skip(got, F.conv2d(x, wt, bias).numpy(), f"1x1_{cin}_{cout}_{h}x{w}")
+
+
+def test_small_tensor_route_k_blocks_from_the_table():
+    for cin, cout, k, h, w, stride, pad, kblocks in TABLES["im2col"][:8]:
+        x, wt, bias = _rnd(cin + h, 1, cin, h, w), _rnd(cout, cout, cin, k, k, scale=(cin * k * k) ** -0.5), _rnd(5, cout)
+        got = ca.conv2d_im2col(x.numpy(), wt.numpy(), bias.numpy(), stride, pad, kblocks)
+        _same_or_skip(got, F.conv2d(x, wt, bias, stride=stride, padding=pad).numpy(), f"small_{cin}_{cout}_{k}_{h}x{w}_s{stride}")
+
+
+def test_deconv_stride1():
+    x, wt, b = _rnd(1, 1, 960, 8, 12), _rnd(2, 960, 640, 3, 3, scale=0.01), _rnd(3, 640)
+    got = ca.deconv2d_s1(x.numpy(), wt.numpy(), b.numpy(), 1)
+    _same_or_skip(got, F.conv_transpose2d(x, wt, b, padding=1).numpy(), "deconv_s1_960_640")
+
+
+def test_deconv_stride2_recipes_from_the_table():
+    for cin, cout, k, h, w, b, flat in [r for r in TABLES["deconv_s2"] if r[5] == 1][:4]:
+        off, pos = [], 0
+        for _ in range(4 * w):
+            off.append(pos)
+            pos += 1 + 3 * flat[pos]
+        assert pos == len(flat)
+        x, wt, bias = _rnd(cin, b, cin, h, w), _rnd(cout, cin, cout, k, k, scale=(cin * 6) ** -0.5), _rnd(9, cout)
+        ref = F.conv_transpose2d(x, wt, bias, stride=2, padding=k // 2, output_padding=1).numpy()
+        got = np.empty_like(ref)
+        ca.lib().orc_deconv_s2(P(x.numpy()), b, cin, h, w, P(wt.numpy()), cout, k, P(bias.numpy()), P(np.array(off, np.int32)),
+                               P(np.array(flat, np.int32)), P(got))
+        _same_or_skip(got, ref, f"deconv_s2_{cin}_{cout}_{h}x{w}")
+
+
+def test_sigmoid_vector_body():
+    x = _rnd(4, 1 << 18, scale=5.0)  # (a multiple of 8 x 32: no scalar tails in torch's parallel loop)
+    _same_or_skip(ca.sigmoid(x.numpy()), torch.sigmoid(x).numpy(), "sigmoid")
+
+
+@pytest.mark.parametrize("c,h,w,oh,ow", [(48, 9, 11, 64, 80), (48, 19, 25, 128, 160), (48, 9, 9, 64, 64), (48, 3, 3, 32, 32), (20, 7, 9, 20, 100)])
+def test_bilinear_both_kernels(c, h, w, oh, ow):
+    x = _rnd(c + h, 1, c, h, w)
+    got = np.empty((c, oh, ow), np.float32)
+    ca.lib().orc_bilinear(P(x[0].numpy()), c, h, w, P(got), oh, ow)
+    _same_or_skip(got, F.interpolate(x, (oh, ow), mode="bilinear", align_corners=False)[0].numpy(), f"bilinear_{c}_{h}x{w}_{oh}x{ow}")
+
+
+@pytest.mark.parametrize("c,h,w", [(384, 2, 3), (384, 4, 4), (640, 8, 8), (384, 8, 10), (960, 32, 40), (100, 7, 9)])
+def test_mean_is_the_cascade_sum(c, h, w):
+    x = _rnd(c, 1, c, h, w)
+    got = np.empty(c, np.float32)
+    ca.lib().orc_mean_rows(P(x[0].numpy()), c, h * w, P(got))
+    _same_or_skip(got, F.adaptive_avg_pool2d(x, 1)[0, :, 0, 0].numpy(), f"mean_{c}_{h}x{w}")
+
+
+def test_linear_row_classes_from_the_table():
+    for K, J, rle in TABLES["linear"][::5]:
+        cls = np.array([c for c, n in zip(rle[0::2], rle[1::2]) for _ in range(n)], np.int32)
+        assert len(cls) == J
+        x, W = _rnd(K, 1, K), _rnd(J, J, K, scale=K ** -0.5)
+        got = np.empty(J, np.float32)
+        ca.lib().orc_linear_b1(P(W.numpy()), P(x[0].numpy()), J, K, P(cls), P(got))
+        _same_or_skip(got, F.linear(x, W)[0].numpy(), f"linear_{K}_{J}")
+
+
+def test_frozen_pins():
+    """runs last in this module: every case above has left the hash of what the C code produced"""
+    if os.environ.get("RGBD_RECORD_PINS"):
+        pytest.skip("recording")
+    want = json.load(open(PINS))
+    common = {k for k in want if k in _pins}
+    assert len(common) >= 20, "run the whole module"
+    bad = {k: (_pins[k], want[k]) for k in common if _pins[k] != want[k]}
+    assert not bad, bad

@@ -292,6 +292,8 @@ def collect_shapes(kind, H, W, B):
             rp = eo.pad_replicate0(torch.from_numpy(r))
             out = c.compress(rp)
             c.decompress(out["strings"], out["shape"])
+        else:
+            raise ValueError(kind)
     finally:
         eo._conv, eo._deconv = oc, od
     return sorted(set(calls))
@@ -300,7 +302,7 @@ def collect_shapes(kind, H, W, B):
 def main():
     torch.set_num_threads(8)
     jobs = [("united", 128, 192, 1), ("united", 128, 128, 2), ("united", 128, 192, 2), ("united", 256, 256, 1),
-            ("united", 480, 640, 1)]
+            ("united", 480, 640, 1), ("single", 256, 256, 1), ("r2d", 128, 192, 1)]
     if "--quick" in sys.argv:
         jobs = jobs[:1]
     tab = {"meta": {"torch": torch.__version__, "threads": torch.get_num_threads(),
@@ -341,9 +343,11 @@ def main():
     # SE_Block Linear layers (batch 1): row classes per (K, J)
     from rgbd_amd import synth
     lin = set()
-    for name, t in synth.synthetic_state_dict(0).items():
-        if ".se.fc." in name and name.endswith(".weight"):
-            lin.add((int(t.shape[1]), int(t.shape[0])))
+    for model in (None, "ELIC", "ELIC_united_R2D"):
+        sd = synth.synthetic_state_dict(0) if model is None else synth.synthetic_state_dict(0, model=model)
+        for name, t in sd.items():
+            if ".se.fc." in name and name.endswith(".weight"):
+                lin.add((int(t.shape[1]), int(t.shape[0])))
     tab["linear"] = []
     for K, J in sorted(lin):
         cls = classify_linear_rows(K, J)
