@@ -67,6 +67,43 @@ int rgbd_rans_decoder_decode(rgbd_rans_decoder* d, const rgbd_tables* t, const i
                              int32_t* symbols_out);
 void rgbd_rans_decoder_destroy(rgbd_rans_decoder* d);
 
+/* The same coder with everything resident in HBM and many streams per launch -- what replaces a Python loop of
+ * encode_with_indexes() / decode_stream() calls over images and modalities (elic_united.py:374-401, 543-578;
+ * rans_interface.cpp:99-192, 286-351).  Every pointer is a DEVICE pointer; nothing is copied or allocated; the launch is
+ * asynchronous on `stream` (a hipStream_t; NULL = the default stream).  Indexes must lie in [0, n_cdf): the codec's own
+ * producer (rgbd_ckbd_quant_index) guarantees it, the kernels do not check.
+ *   encode: stream s codes counts_dev[s] (symbol, index) pairs starting at element sym_base_dev[s] of symbols_dev / indexes_dev
+ *           (both readable one element past the last pair).  out_dev holds nstreams slots of cap_words 32-bit words
+ *           (cap_words a multiple of 64, >= rgbd_rans_max_bytes(max count) / 4); stream s is the LAST out_words_dev[s] words of
+ *           slot s, byte for byte what RansEncoder.flush() returns.  *err_dev (zero it first) becomes non-zero if a slot
+ *           overflowed.
+ *   decode: stream s is stream_len_words_dev[s] words at word stream_off_words_dev[s] of streams_dev.  state_dev keeps two
+ *           uint64 per stream between calls; init != 0 starts from the head of each stream (set_stream()), init == 0
+ *           continues (the next decode_stream() on the same decoder).  Each call decodes `count` symbols per stream for the
+ *           indexes at indexes_dev[sym_base_dev[s] + part_off ...) into symbols_dev at the same positions. */
+int rgbd_rans_encode_batch_dev(const rgbd_tables* t, const int32_t* symbols_dev, const int32_t* indexes_dev,
+                               const int64_t* sym_base_dev, const int64_t* counts_dev, int32_t nstreams, uint32_t* out_dev,
+                               int64_t cap_words, int64_t* out_words_dev, int32_t* err_dev, void* stream);
+int rgbd_rans_decode_batch_dev(const rgbd_tables* t, const uint32_t* streams_dev, const int64_t* stream_off_words_dev,
+                               const int64_t* stream_len_words_dev, int32_t nstreams, uint64_t* state_dev, int32_t init,
+                               const int32_t* indexes_dev, int32_t* symbols_dev, const int64_t* sym_base_dev, int64_t part_off,
+                               int64_t count, void* stream);
+
+/* One checkerboard half of one channel slice on the encoder: utils/ckbd.py:83-105 (ckbd_anchor_sequeeze /
+ * ckbd_nonanchor_sequeeze of y, means and scales), entropy_models.py:118-146 (quantize(y, "symbols", means)), :561-568
+ * (build_indexes(scales)) and the scatter of y_hat = symbol + mean back onto the full grid (ckbd.py:107-125), as ONE pass.
+ * y_dev / means_dev / scales_dev / yhat_dev: NCHW fp32 [n][c][h][w] on the device, w even.  anchor != 0: the positions with
+ * (row + col) odd (ckbd.py:37-48), and the other half of yhat_dev is set to zero; anchor == 0: the positions with (row + col)
+ * even, the other half of yhat_dev is left as it is.  scale_table: the 64 entries of get_scale_table() (host).
+ * symbols_dev / indexes_dev: n * c * h * (w / 2) int32 each, in (n, c, h, w / 2) order -- the order the reference's
+ * .reshape(-1).tolist() feeds its encoder.  Synchronous.
+ * rgbd_ckbd_dequant is the decoder's half of the same step (elic_united.py:497-506, 529-538): yhat = symbol + mean. */
+int rgbd_ckbd_quant_index(const float* y_dev, const float* means_dev, const float* scales_dev, int32_t n, int32_t c, int32_t h,
+                          int32_t w, int32_t anchor, const float* scale_table, int32_t* symbols_dev, int32_t* indexes_dev,
+                          float* yhat_dev, void* stream);
+int rgbd_ckbd_dequant(const int32_t* symbols_dev, const float* means_dev, int32_t n, int32_t c, int32_t h, int32_t w, int32_t anchor,
+                      float* yhat_dev, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Single operators on device tensors (NCHW fp32, contiguous) -- used by the parity tests of the conv kernels.
  * Replaces torch.nn.functional.conv2d / conv_transpose2d as used by modules/layers/conv.py:7-34.
@@ -235,18 +272,22 @@ int rgbd_debug_force_pair(int32_t mode);
 int rgbd_elic_set_tile_mode(rgbd_elic* m, int32_t mode);
 int rgbd_debug_bench_streams(int32_t n); /* rgbd_conv_bench: issue every launch on n streams at once (1 = isolated) and
                                             report the time per launch -- the cost of a launch on a shared chip */
+int rgbd_debug_force_blocked(int32_t on); /* rgbd_conv_bench: time the blocked-accumulation kernels (tools/tune_tiles.py --blocked) */
 int rgbd_debug_force_ckbd(int32_t part); /* rgbd_conv2d_nchw / rgbd_conv_bench: 0 = all outputs, 1 = anchor positions only
                                            ((row + col) odd, utils/ckbd.py:37-48), 2 = non-anchor only; the rest reads 0 */
 int rgbd_debug_conv_log(int32_t on);                      /* record the shape of every conv launch (tools/tune_tiles.py) */
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap); /* CSV text of the recorded shapes; returns the size needed */
-int rgbd_debug_force_tile(const char* cfg); /* The pointwise operators of Bi-SPF / ESA / SE_Block alone (test hook; NCHW device tensors in and out, host weights):
+int rgbd_debug_force_tile(const char* cfg); /* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */
+
+/* The pointwise operators of Bi-SPF / ESA / SE_Block alone (test hook; NCHW device tensors in and out, host weights):
  * op 0 = F.max_pool2d(kernel 7, stride 3) (attention.py:87), 1 = F.interpolate(bilinear, align_corners=False) to (oh, ow)
  * (attention.py:91), 2 = SE_Block x * gate (attention.py:52-67; w0 = fc.0.weight [c/16][c], w1 = fc.2.weight [c][c/16]),
  * 3 = x + x * gate as the entropy-parameter nets use it (entropy.py:75). */
 int rgbd_pointwise_nchw(int32_t op, const float* x_dev, int32_t n, int32_t c, int32_t h, int32_t w, int32_t oh, int32_t ow,
                         const float* w0, const float* w1, float* y_dev, void* stream);
 
-/* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */
+/* Kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py, tools/tune_tiles.py): iters launches,
+ * *ms_out = milliseconds per launch. */
 int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                     int32_t transposed, int32_t with_residual, int32_t iters, float* ms_out);
 int rgbd_elic_profile_dump(rgbd_elic* m, const char* path);

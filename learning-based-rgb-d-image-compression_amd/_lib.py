@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librgbd_amd.so")
 _SO = os.environ.get("RGBD_AMD_LIB", _SO)  # A/B builds: point at another librgbd_amd.so
-_SRCS = ["conv_mfma.hip", "conv_mfma_blk.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "engine.hip"]
+_SRCS = ["conv_mfma.hip", "conv_mfma_blk.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "coder_abi.hip", "engine.hip"]
 _LIB = None
 
 ERRORS = {-22: "invalid argument", -12: "out of memory", -5: "HIP runtime error", -28: "buffer too small",
@@ -35,9 +35,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(csrc, "common.h"), os.path.join(csrc, "exact_math.h"),
             os.path.join(os.path.dirname(_HERE), "include", "rgbd_amd.h")]
     body = os.path.join(csrc, "conv_mfma_body.h")
-    extra = {"conv_mfma.hip": [body, os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h")],
+    extra = {"conv_mfma.hip": [body, os.path.join(csrc, "tile_table.h"), os.path.join(csrc, "tile_table_loaded.h"),
+                               os.path.join(csrc, "tile_table_blk.h"), os.path.join(csrc, "tile_table_blk_loaded.h")],
              "conv_mfma_blk.hip": [body]}
     hdrs.append(os.path.join(csrc, "splitk_table.h"))
+    extra["engine.hip"] = extra["coder_abi.hip"] = [os.path.join(csrc, "engine_internal.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(objdir, exist_ok=True)
     jobs, objs = [], []
@@ -85,6 +87,10 @@ def lib():
         "rgbd_rans_decoder_set_stream": (ctypes.c_int, [c_vp, u8p, c_i64]),
         "rgbd_rans_decoder_decode": (ctypes.c_int, [c_vp, c_vp, i32p, c_i64, i32p]),
         "rgbd_rans_decoder_destroy": (None, [c_vp]),
+        "rgbd_rans_encode_batch_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
+        "rgbd_rans_decode_batch_dev": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+        "rgbd_ckbd_quant_index": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, f32p, c_vp, c_vp, c_vp, c_vp]),
+        "rgbd_ckbd_dequant": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
         "rgbd_conv2d_nchw": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32, c_i32,
                                             c_i32, c_i32, c_vp, c_vp, c_vp]),
         "rgbd_conv2d_ref_nchw": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, f32p, f32p, c_i32, c_i32, c_i32, c_i32,
@@ -126,6 +132,7 @@ def lib():
         "rgbd_msssim_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, f32p, ctypes.c_float, c_i32, c_vp, c_vp, c_i64, c_vp]),
         "rgbd_debug_force_splitk": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_ckbd": (ctypes.c_int, [c_i32]),
+        "rgbd_debug_force_blocked": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_fuse": (ctypes.c_int, [c_i32]),
         "rgbd_debug_force_subpix": (ctypes.c_int, [c_i32]),
         "rgbd_layernorm": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
@@ -152,20 +159,34 @@ def lib():
 
 EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync", "rgbd_pmf_to_quantized_cdf", "rgbd_tables_create", "rgbd_tables_destroy",
            "rgbd_rans_max_bytes", "rgbd_rans_encode", "rgbd_rans_decoder_create", "rgbd_rans_decoder_set_stream",
-           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_conv2d_nchw", "rgbd_conv2d_ref_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
+           "rgbd_rans_decoder_decode", "rgbd_rans_decoder_destroy", "rgbd_rans_encode_batch_dev", "rgbd_rans_decode_batch_dev", "rgbd_ckbd_quant_index", "rgbd_ckbd_dequant", "rgbd_conv2d_nchw", "rgbd_conv2d_ref_nchw", "rgbd_pointwise_nchw", "rgbd_elic_create",
            "rgbd_elic_destroy", "rgbd_elic_set_ref_blocks", "rgbd_elic_get_refnum", "rgbd_elic_ref_table_misses", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats", "rgbd_layernorm", "rgbd_debug_force_layernorm_form",
-           "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
+           "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_force_blocked", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]
 
 
-def set_blocking_sync(on: bool) -> None:
-    """Switch the wait policy of this process's GPU (hipDeviceScheduleBlockingSync on / off) at a clean point: engine
-    instances that are already garbage are destroyed FIRST -- under the policy they ran with -- and the library drains the
-    device before the flag changes.  (An engine that had run under the spinning policy and was garbage-collected right
-    after a CodecPool had switched to the blocking one is what the round-4 `hipFree never returns` record shows.)"""
+_BS_HOLDERS = 0
+
+
+def set_blocking_sync(on: bool) -> bool:
+    """Hold (True) / release (False) the sleeping wait policy of this process's GPU (hipDeviceScheduleBlockingSync).
+
+    Since round 5 the library itself switches a device to that policy when the FIRST engine is created on it and refuses to
+    change it while any engine is alive (the round-4 `hipFree never returns` record needs work submitted under one policy and
+    waited for under the other; RGBD_SPIN_WAIT=1 opts out for the whole process).  Pools and the pipelined harness therefore
+    find it on; this function only counts holders -- the policy goes back to the runtime's default when the last holder lets
+    go AND no engine is left -- and never raises over a refusal.  Returns whether the policy now is what was asked for."""
+    global _BS_HOLDERS
     import gc
 
-    gc.collect()
-    check(lib().rgbd_set_blocking_sync(1 if on else 0), "set_blocking_sync")
+    L = lib()
+    if on:
+        _BS_HOLDERS += 1
+        return L.rgbd_set_blocking_sync(1) == 0
+    _BS_HOLDERS = max(0, _BS_HOLDERS - 1)
+    if _BS_HOLDERS:
+        return L.rgbd_get_blocking_sync() == 0
+    gc.collect()  # engines that are already garbage go first: they are destroyed under the policy they ran with
+    return L.rgbd_set_blocking_sync(0) == 0  # (refused -- and left alone -- while an engine is alive)

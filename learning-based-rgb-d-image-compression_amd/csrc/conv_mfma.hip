@@ -188,17 +188,20 @@ char g_conv_force[64] = {0};  // rgbd_debug_force_tile (tools/tile_sweep.py)
 // tile_table.h; a launch whose shape is listed takes the measured winner, everything else the cost model.  The choice
 // never changes results (every output keeps its fma chain), so the table is a pure performance database.
 struct TunedTile {
-    int N, H, W, cin_pad, cout_pad, ntaps, stride, nphase, splitk;  // key (nphase + 10 * ckbd for checkerboard launches)
+    int N, H, W, cin_pad, cout_pad, ntaps, stride, nphase, splitk;  // key (nphase + 10 * ckbd for checkerboard launches, + 100 for
+                                                                    // the blocked-accumulation kernels)
     int wm, mt, nt, kc, dma;                                        // measured best
 };
 static const TunedTile kTuned[] = {
 #include "tile_table.h"
+#include "tile_table_blk.h"
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 // the same shapes timed with 8 copies of the launch in flight (tools/tune_tiles.py --streams 8): what a launch costs in CU
 // time on a shared chip.  Engine instances of a pool use it (ConvArgs::loaded); the winners are larger tiles / fewer
 // workgroups than the isolated-launch winners (+2.7 % job throughput on c2, but 15 % slower launches on an idle chip).
 static const TunedTile kTunedLoaded[] = {
 #include "tile_table_loaded.h"
+#include "tile_table_blk_loaded.h"
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 // *measured: some entry of the table has this map size and batch size, i.e. a miss means "the cost model's pick won"
@@ -211,7 +214,7 @@ static const TunedTile* table_lookup(const TunedTile* table, const ConvArgs& a, 
     for (const TunedTile* t = table; t->N; ++t) {
         if (t->H == a.H && t->W == a.W && t->N == aN) *measured = true;
         if (t->H != a.H || t->W != a.W || t->cin_pad != a.cin_pad || t->cout_pad != a.cout_pad || t->ntaps != a.ntaps_total ||
-            t->stride != stride || t->nphase != a.nphase + 10 * a.ckbd || t->splitk != a.splitk)
+            t->stride != stride || t->nphase != a.nphase + 10 * a.ckbd + (a.blocked ? 100 : 0) || t->splitk != a.splitk)
             continue;
         if (t->N == aN) return t;
         if (!near || abs(t->N - aN) < abs(near->N - aN)) near = t;
@@ -319,7 +322,7 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
     if (g_log_on) {
         char key[160];
         snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", a.N * (a.groups == 2 ? 2 : 1), a.H, a.W, a.cin_pad, a.cout_pad, a.ntaps_total,
-                 a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd, a.splitk);
+                 a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd + (a.blocked ? 100 : 0), a.splitk);
         std::lock_guard<std::mutex> lk(g_log_mu);
         ++g_log[key];
     }

@@ -26,185 +26,13 @@
 
 #include "../../include/rgbd_amd.h"
 #include "common.h"
+#include "engine_internal.h"
+
+std::shared_mutex g_capture_mu;
+int64_t rgbd_enc_cap_words(int64_t n) { return ((5 * n + 32 + 704) + 63) & ~(int64_t)63; }
 
 namespace {
 
-// ------------------------------------------------------------------------------------------------
-// device tables
-// ------------------------------------------------------------------------------------------------
-// One generation of device buffers: freed when the last engine instance that still points into it lets go.  A parent
-// engine and its rgbd_elic_clone_shared() clones share generations, so re-uploading weights or tables on one of them
-// (finalize / set_tables / set_scale_table build a NEW generation) can never free memory another one still reads.
-struct DevGen {
-    std::vector<void*> p;
-    ~DevGen()
-    {
-        for (void* q : p) (void)hipFree(q);
-    }
-};
-
-struct TableSet {
-    DevTables d{};
-    void* blob = nullptr;
-    bool ready = false;
-    int stride_src = 0;
-    std::shared_ptr<DevGen> hold;  // owner of blob (engine table slots); rgbd_tables frees its blob itself
-};
-
-int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int32_t* offsets, int nrows, TableSet* ts)
-{
-    if (!cdf || !sizes || !offsets || nrows <= 0 || stride < 3) return RGBD_EINVAL;
-    std::vector<int32_t> row_off(nrows);
-    int total = 0;
-    for (int r = 0; r < nrows; ++r) {
-        if (sizes[r] < 3 || sizes[r] > stride) return RGBD_EINVAL;
-        row_off[r] = total;
-        total += sizes[r] - 1;  // final 65536 entry is implicit
-    }
-    std::vector<uint16_t> packed(total);
-    // bucket-table resolution: as fine as fits next to the packed rows in one CU's LDS (160 KiB)
-    int bits = 8;
-    while (bits > 4 &&
-           (size_t)nrows * ((1u << bits) + 1) * 8 + ((size_t)total + 64 * (size_t)nrows) * 2 + (size_t)nrows * 256 > 148 * 1024)
-        --bits;
-    const int LN = (1 << bits) + 1;
-    std::vector<uint32_t> lut((size_t)nrows * LN * 2);  // {j | row[j] << 16, freq_j}
-    for (int r = 0; r < nrows; ++r) {
-        const int32_t* row = cdf + (size_t)r * stride;
-        const int len = sizes[r];
-        if (row[0] != 0 || row[len - 1] != 65536) return RGBD_EINVAL;
-        for (int j = 0; j < len - 1; ++j) {
-            if (row[j] < 0 || row[j] > 65535 || row[j + 1] <= row[j]) return RGBD_EINVAL;
-            packed[row_off[r] + j] = (uint16_t)row[j];
-        }
-        int j = 0;
-        for (int b = 0; b < LN; ++b) {
-            const int64_t lim = (int64_t)b << (16 - bits);
-            while (j + 1 <= len - 2 && row[j + 1] <= lim) ++j;
-            lut[((size_t)r * LN + b) * 2] = (uint32_t)j | ((uint32_t)row[j] << 16);
-            // a candidate that is the row's escape slot gets frequency 0: the decoder's one range check then also routes
-            // escapes away from its fast path
-            lut[((size_t)r * LN + b) * 2 + 1] = j == len - 2 ? 0u : (uint32_t)(row[j + 1] - row[j]);
-        }
-    }
-    // encoder entries: m = ceil(2^(63+s) / freq), s = ceil(log2 freq): floor(x * m / 2^(63+s)) == x / freq for every
-    // x < 2^63 (the coder keeps x < freq << 47); freq == 1 uses m = 2^64 - 1 (q = x - 1) with the bias making up for it
-    std::vector<uint32_t> enc((size_t)total * 4);
-    for (int r = 0; r < nrows; ++r) {
-        const int32_t* row = cdf + (size_t)r * stride;
-        for (int j = 0; j < sizes[r] - 1; ++j) {
-            const uint32_t start = (uint32_t)row[j], freq = (uint32_t)(row[j + 1] - row[j]);
-            uint64_t m;
-            uint32_t shift, bias;
-            if (freq == 1) {
-                m = ~0ull;
-                shift = 0;
-                bias = start + 65535u;
-            } else {
-                int sl = 0;
-                while ((1u << sl) < freq) ++sl;
-                const unsigned __int128 num = ((unsigned __int128)1 << (63 + sl)) + freq - 1;
-                m = (uint64_t)(num / freq);
-                shift = (uint32_t)(sl - 1);
-                bias = start;
-            }
-            uint32_t* e = &enc[((size_t)row_off[r] + j) * 4];
-            e[0] = (uint32_t)m;
-            e[1] = (uint32_t)(m >> 32);
-            e[2] = bias | (shift << 17);
-            e[3] = freq;
-        }
-    }
-    // decoder probe array: every row again as cdf - 1 (entry 0: 0) followed by 64 pad entries 0xFFFF (= 65536 - 1), so a
-    // 64-wide "entry < cum" probe needs no bounds and a probe that ends on the pad has found the row's escape slot
-    std::vector<uint16_t> cm((size_t)total + 64 * (size_t)nrows, (uint16_t)0xFFFFu);
-    for (int r = 0; r < nrows; ++r) {
-        const int32_t* row = cdf + (size_t)r * stride;
-        for (int j = 0; j < sizes[r] - 1; ++j) cm[(size_t)row_off[r] + 64 * (size_t)r + j] = (uint16_t)(j ? row[j] - 1 : 0);
-    }
-    // first-level probe rows: slot i of a row's first 64 as {0xFFFF - cdf[i] << 16 | 0xFFFF - (cdf[i + 1] - 1)}.  One 16-bit
-    // compare of the low halves against 0xFFFF - cum counts the symbols below cum and ONE lane read then yields start and
-    // end of the symbol.  A low half of 0 means "not resolved here": the row's last (escape) slot, the pad behind it, and
-    // slot 63 of a row wider than the 64 lanes (the decoder sends index 63 to the bucket table, which knows which it is).
-    std::vector<uint32_t> pk((size_t)nrows * 64, 0u);
-    for (int r = 0; r < nrows; ++r) {
-        const int32_t* row = cdf + (size_t)r * stride;
-        const int n = sizes[r] - 1;  // slots
-        for (int j = 0; j < n && j < 64; ++j) {
-            if (j == 63 && n > 64) {  // the rest of a wide row: the identity step (freq 65536, start 0)
-                pk[(size_t)r * 64 + j] = 0xFFFF0000u;
-                continue;
-            }
-            pk[(size_t)r * 64 + j] = ((0xFFFFu - (uint32_t)row[j]) << 16) | (0x10000u - (uint32_t)row[j + 1]);
-        }
-    }
-    // coarse first level of the rows with 129 ... 4032 slots (the decoder's loop for batches with several symbols on such
-    // rows): slot j = the block of `stride` symbols from j * stride on, {cdf[first] << 16 | 0x10000 - cdf[end]} (the same
-    // 16-bit compare that resolves a narrow symbol yields the block; blocks behind the row's end never compare), followed
-    // in the decoder by ONE 64-wide probe of the block in the cdf - 1 array above.  Narrower wide rows stay with the bucket
-    // table: it resolves them in one hop.
-    std::vector<int32_t> coarse(nrows, -1);
-    std::vector<uint32_t> pkc;
-    // (the decoder's tables without any coarse row, as rans_decode_lds_bytes counts them: a table set that fits the LDS
-    // without coarse rows must keep fitting -- rows that would not fit stay with the bucket table)
-    const size_t lds_base = (((size_t)nrows * LN + 1) & ~(size_t)1) * 8 + (((size_t)nrows + 1) & ~(size_t)1) * 8 +
-                            ((((size_t)total + 64 * (size_t)nrows) * 2 + 15) & ~(size_t)15) + (size_t)nrows * 256;
-    const size_t lds_room = lds_base < 157 * 1024 ? (157 * 1024 - lds_base) / 256 : 0;
-    for (int r = 0; r < nrows; ++r) {
-        const int32_t* row = cdf + (size_t)r * stride;
-        const int n = sizes[r] - 1;
-        if (n <= 128 || n > 4032 || pkc.size() / 64 >= 255 || pkc.size() / 64 >= lds_room) continue;
-        coarse[r] = (int32_t)(pkc.size() / 64);
-        pkc.resize(pkc.size() + 64, 0u);
-        const int st = (n + 63) / 64;
-        for (int j = 0; j < 64 && j * st < n; ++j) {
-            const int s0 = j * st, e = std::min(s0 + st, n);
-            pkc[(size_t)coarse[r] * 64 + j] = ((uint32_t)row[s0] << 16) | ((0x10000u - (uint32_t)row[e]) & 0xFFFFu);
-        }
-    }
-    const size_t b_cm = (cm.size() * 2 + 15) & ~(size_t)15;
-    const size_t b_pk = pk.size() * 4;
-    const size_t b_pkc = pkc.size() * 4;
-    const size_t b_enc = (size_t)total * 16;
-    const size_t b_cdf = ((size_t)total * 2 + 15) & ~(size_t)15;
-    const size_t b_lut = ((size_t)nrows * LN * 8 + 15) & ~(size_t)15;
-    const size_t b_i32 = ((size_t)nrows * 4 + 15) & ~(size_t)15;
-    const size_t bytes = b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk + b_pkc + b_i32;
-    ts->blob = nullptr;  // a previous blob stays with its owner (TableSet::hold / rgbd_tables_destroy)
-    ts->ready = false;
-    HIP_TRY(hipMalloc(&ts->blob, bytes));
-    std::vector<unsigned char> host(bytes, 0);
-    unsigned char* p = host.data();
-    memcpy(p, packed.data(), (size_t)total * 2);
-    memcpy(p + b_cdf, lut.data(), (size_t)nrows * LN * 8);
-    memcpy(p + b_cdf + b_lut, row_off.data(), (size_t)nrows * 4);
-    memcpy(p + b_cdf + b_lut + b_i32, sizes, (size_t)nrows * 4);
-    memcpy(p + b_cdf + b_lut + 2 * b_i32, offsets, (size_t)nrows * 4);
-    memcpy(p + b_cdf + b_lut + 3 * b_i32, enc.data(), b_enc);
-    memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc, cm.data(), cm.size() * 2);
-    memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm, pk.data(), b_pk);
-    if (b_pkc) memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk, pkc.data(), b_pkc);
-    memcpy(p + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk + b_pkc, coarse.data(), (size_t)nrows * 4);
-    HIP_TRY(hipMemcpy(ts->blob, host.data(), bytes, hipMemcpyHostToDevice));
-    unsigned char* dp = (unsigned char*)ts->blob;
-    ts->d.cdf = (const uint16_t*)dp;
-    ts->d.lut = (const uint32_t*)(dp + b_cdf);
-    ts->d.lut_bits = bits;
-    ts->d.row_off = (const int32_t*)(dp + b_cdf + b_lut);
-    ts->d.sizes = (const int32_t*)(dp + b_cdf + b_lut + b_i32);
-    ts->d.offsets = (const int32_t*)(dp + b_cdf + b_lut + 2 * b_i32);
-    ts->d.enc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32);
-    ts->d.cm = (const uint16_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc);
-    ts->d.pk = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm);
-    ts->d.pkc = (const uint32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk);
-    ts->d.coarse = (const int32_t*)(dp + b_cdf + b_lut + 3 * b_i32 + b_enc + b_cm + b_pk + b_pkc);
-    ts->d.ncoarse = (int)(pkc.size() / 64);
-    ts->d.nrows = nrows;
-    ts->d.total = total;
-    ts->ready = true;
-    ts->stride_src = stride;
-    return RGBD_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // packed layers
@@ -384,11 +212,6 @@ void make_taps(const PackedConv& pc, int stride, int pad, ConvArgs* a)
     a->span_y = a->span_x = mx - mn + 1;
 }
 
-// Stream capture vs device-wide operations: a hipFree / hipDeviceSynchronize / synchronous hipMemcpy issued by ANY host
-// thread while another thread's stream is capturing fails ("operation not permitted when stream is capturing") and
-// poisons that capture.  Captures hold this lock shared (several engine instances may capture at once); everything that
-// frees or synchronises device-wide takes it exclusively.
-std::shared_mutex g_capture_mu;
 
 // ---- hang diagnostics (RGBD_DEBUG_DESTROY=1) -----------------------------------------------------------------------------
 // A HangWatch around a runtime call that may wait for the device (hipFree = implicit device synchronise): if the call has
@@ -422,14 +245,21 @@ struct HangWatch {
             std::unique_lock<std::mutex> lk(mu);
             if (cv.wait_for(lk, std::chrono::seconds(secs), [this] { return done; })) return;
             lk.unlock();
+            if (!g_dbg_destroy) {
+                // production (always-armed) mode is PASSIVE: one line naming the call.  Signalling every thread of the host
+                // application, replacing its SIGUSR2 handler and querying streams from here is for RGBD_DEBUG_DESTROY=1 only
+                // (round-4 advisor finding): hipFree legitimately waits for the device, a caller's long kernels can be the cause.
+                fprintf(stderr, "[rgbd_amd] %s has not returned after %d s (RGBD_DEBUG_DESTROY=1 prints host backtraces)\n", what, secs);
+                return;
+            }
             fprintf(stderr, "[watchdog] %s has not returned after %d s; host backtraces of every thread follow\n", what, secs);
             void* warm[4];
             (void)backtrace(warm, 4);  // loads libgcc outside the signal handler
-            struct sigaction sa;
+            struct sigaction sa, old_sa;
             memset(&sa, 0, sizeof(sa));
             sa.sa_handler = bt_handler;
             sa.sa_flags = SA_RESTART;
-            sigaction(SIGUSR2, &sa, nullptr);
+            sigaction(SIGUSR2, &sa, &old_sa);
             const long self = (long)syscall(SYS_gettid);
             if (DIR* d = opendir("/proc/self/task")) {
                 while (dirent* e = readdir(d)) {
@@ -456,6 +286,7 @@ struct HangWatch {
             const hipError_t e0 = hipStreamQuery(nullptr);
             fprintf(stderr, "[watchdog]   -> %s\n", hipGetErrorName(e0));
             fflush(stderr);
+            sigaction(SIGUSR2, &old_sa, nullptr);  // the host application's handler is back
             if (getenv("RGBD_DIAG_EXIT")) _exit(86);  // diagnostics runs end by themselves instead of at a time limit
         });
     }
@@ -479,6 +310,7 @@ int g_subpix = getenv("RGBD_NO_SUBPIX") ? 0 : 1;  // rgbd_debug_force_subpix: su
 int g_fail_captures = 0;  // rgbd_debug_fail_captures: the next n graph captures count as lost (test hook)
 int g_pair = getenv("RGBD_NO_PAIR") ? 0 : 1;  // rgbd_debug_force_pair: RGB / depth layer pairs as one grouped launch
 int g_force_ckbd = 0;    // test hook (rgbd_debug_force_ckbd): checkerboard output mode of rgbd_conv2d_nchw / rgbd_conv_bench
+int g_force_blocked = 0;  // rgbd_debug_force_blocked: rgbd_conv_bench launches the blocked-accumulation kernels (tile tuner)
 const bool g_ckbd_conv = !getenv("RGBD_NO_CKBD_CONV");  // A/B switch: checkerboard-restricted entropy-parameter convs
 
 // ------------------------------------------------------------------------------------------------
@@ -530,9 +362,6 @@ struct Epi {
 
 }  // namespace
 
-struct rgbd_tables {
-    TableSet ts;
-};
 
 struct rgbd_elic {
     int N = 192, M = 320;
@@ -3743,11 +3572,48 @@ int rgbd_abi_version(void) { return RGBD_AMD_ABI_VERSION; }
 // CodecPool had switched the policy): so the device is drained under the OLD policy before the flag changes, and the Python
 // side collects garbage engines first (pool.py).  (Measured and dropped: switching to the spinning policy around every
 // hipFree -- with a pool's other threads launching in that window it produced exactly such mixed waits, and the suite hung.)
+// Wait policy of the host threads (round 5; advisor findings on the round-4 `hipFree never returns` record).  The hang needs
+// work submitted under one policy and waited for under the other, so the policy no longer moves while an engine exists: the
+// FIRST engine created on a device switches that device to hipDeviceScheduleBlockingSync (sleeping waits: what every pooled
+// or pipelined user wants, and ~1 ms of a 190 ms call for a lone one) before it has launched anything, and
+// rgbd_set_blocking_sync() refuses (RGBD_ESTATE) to change the policy while any engine is alive.  RGBD_SPIN_WAIT=1 keeps the
+// runtime's default (spinning) policy for the whole process instead.
+static std::atomic<int> g_live_engines{0};
+static std::mutex g_policy_mu;
+static bool g_policy_done[64] = {false};
+
+static int ensure_wait_policy()
+{
+    static const bool spin = getenv("RGBD_SPIN_WAIT") != nullptr;
+    if (spin) return RGBD_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_policy_mu);
+    if (dev < 0 || dev >= 64 || g_policy_done[dev]) return RGBD_OK;
+    if (g_live_engines.load() == 0) {
+        std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
+        HIP_TRY(hipDeviceSynchronize());  // (whatever the caller's framework has in flight drains under the old policy)
+        HIP_TRY(hipSetDeviceFlags(hipDeviceScheduleBlockingSync));
+    }
+    g_policy_done[dev] = true;
+    return RGBD_OK;
+}
+
+int rgbd_get_blocking_sync(void);
 int rgbd_set_blocking_sync(int32_t on)
 {
+    const int cur = rgbd_get_blocking_sync();
+    if (cur < 0) return cur;
+    if ((on ? 1 : 0) == cur) return RGBD_OK;
+    if (g_live_engines.load() > 0) return RGBD_ESTATE;  // never under a live engine's feet
     std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // a device-wide wait: not while a stream of this process captures
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto));
+    if (!on) {
+        std::lock_guard<std::mutex> g(g_policy_mu);
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) g_policy_done[dev] = false;  // the next first engine decides again
+    }
     return RGBD_OK;
 }
 
@@ -3756,192 +3622,6 @@ int rgbd_get_blocking_sync(void)
     unsigned flags = 0;
     HIP_TRY(hipGetDeviceFlags(&flags));
     return (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync ? 1 : 0;
-}
-
-// ops.cpp:24-81 restated (host, one-off table construction)
-int rgbd_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, uint32_t* cdf_out)
-{
-    if (!pmf || !cdf_out || n <= 0 || precision < 1 || precision > 16) return RGBD_EINVAL;
-    std::vector<uint32_t> c((size_t)n + 1);
-    c[0] = 0;
-    const float scale = (float)(1 << precision);
-    for (int i = 0; i < n; ++i) c[(size_t)i + 1] = (uint32_t)std::round(pmf[i] * scale);
-    uint32_t total = 0;
-    for (uint32_t v : c) total += v;
-    if (!total) return RGBD_EINVAL;
-    for (uint32_t& v : c) v = (uint32_t)((((uint64_t)1 << precision) * v) / total);
-    for (size_t i = 1; i < c.size(); ++i) c[i] += c[i - 1];
-    c.back() = 1u << precision;
-    const int m = n + 1;
-    for (int i = 0; i < m - 1; ++i) {
-        if (c[i] != c[i + 1]) continue;
-        uint32_t best = ~0u;
-        int donor = -1;
-        for (int j = 0; j < m - 1; ++j) {
-            const uint32_t f = c[j + 1] - c[j];
-            if (f > 1 && f < best) {
-                best = f;
-                donor = j;
-            }
-        }
-        if (donor < 0) return RGBD_EINVAL;
-        if (donor < i)
-            for (int j = donor + 1; j <= i; ++j) c[j]--;
-        else
-            for (int j = i + 1; j <= donor; ++j) c[j]++;
-    }
-    memcpy(cdf_out, c.data(), sizeof(uint32_t) * c.size());
-    return RGBD_OK;
-}
-
-int rgbd_tables_create(const int32_t* cdf, int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
-                       int32_t n_cdf, rgbd_tables** out)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
-    if (!out) return RGBD_EINVAL;
-    std::unique_ptr<rgbd_tables> t(new rgbd_tables());
-    const int r = build_tables(cdf, cdf_stride, cdf_sizes, offsets, n_cdf, &t->ts);
-    if (r) {
-        if (t->ts.blob) (void)hipFree(t->ts.blob);
-        return r;
-    }
-    *out = t.release();
-    return RGBD_OK;
-}
-
-void rgbd_tables_destroy(rgbd_tables* t)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
-    if (!t) return;
-    if (t->ts.blob) (void)hipFree(t->ts.blob);
-    delete t;
-}
-
-static int64_t enc_cap_words(int64_t n) { return ((5 * n + 32 + 704) + 63) & ~(int64_t)63; }
-
-int64_t rgbd_rans_max_bytes(int64_t n) { return 4 * enc_cap_words(n); }
-
-int rgbd_rans_encode(const rgbd_tables* t, const int32_t* symbols, const int32_t* indexes, int64_t n, uint8_t* out,
-                     int64_t cap, int64_t* out_len)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
-    if (!t || !t->ts.ready || n < 0 || !out || !out_len || (n && (!symbols || !indexes))) return RGBD_EINVAL;
-    for (int64_t i = 0; i < n; ++i)
-        if (indexes[i] < 0 || indexes[i] >= t->ts.d.nrows) return RGBD_EINVAL;
-    const int64_t capw = enc_cap_words(n);
-    int32_t *dsym = nullptr, *didx = nullptr;
-    uint32_t* dout = nullptr;
-    int64_t* dmeta = nullptr;
-    int* derr = nullptr;
-    int rc = RGBD_OK;
-    auto cleanup = [&]() {
-        (void)hipFree(dsym);
-        (void)hipFree(didx);
-        (void)hipFree(dout);
-        (void)hipFree(dmeta);
-        (void)hipFree(derr);
-    };
-    HIP_TRY(hipMalloc((void**)&dsym, sizeof(int32_t) * (size_t)(n + 1)));
-    HIP_TRY(hipMalloc((void**)&didx, sizeof(int32_t) * (size_t)(n + 1)));
-    HIP_TRY(hipMalloc((void**)&dout, sizeof(uint32_t) * (size_t)capw));
-    HIP_TRY(hipMalloc((void**)&dmeta, sizeof(int64_t) * 4));
-    HIP_TRY(hipMalloc((void**)&derr, sizeof(int)));
-    const int64_t hmeta[4] = {0, n, 0, 0};
-    hipError_t e = hipSuccess;
-    if (n) {
-        e = hipMemcpy(dsym, symbols, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(didx, indexes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess) e = hipMemcpy(dmeta, hmeta, sizeof(hmeta), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(derr, 0, sizeof(int));
-    if (e != hipSuccess) {
-        cleanup();
-        return RGBD_EHIP;
-    }
-    rc = launch_rans_encode(dsym, didx, dmeta, dmeta + 1, 1, 1, t->ts.d, t->ts.d, dout, capw, dmeta + 2, derr, nullptr);
-    int64_t nw = 0;
-    int herr = 0;
-    if (!rc) {
-        e = hipMemcpy(&nw, dmeta + 2, sizeof(int64_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(&herr, derr, sizeof(int), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = RGBD_EHIP;
-        else if (herr) rc = RGBD_ENOSPC;
-        else if (nw * 4 > cap) rc = RGBD_ENOSPC;
-        else {
-            e = hipMemcpy(out, dout + (capw - nw), (size_t)nw * 4, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) rc = RGBD_EHIP;
-            *out_len = nw * 4;
-        }
-    }
-    cleanup();
-    return rc;
-}
-
-struct rgbd_rans_decoder {
-    uint32_t* words = nullptr;
-    int64_t nwords = 0;
-    int64_t* meta = nullptr;   // [off, len, base]
-    uint64_t* state = nullptr;  // [x, pos]
-    bool fresh = false;
-};
-
-int rgbd_rans_decoder_create(rgbd_rans_decoder** out)
-{
-    if (!out) return RGBD_EINVAL;
-    std::unique_ptr<rgbd_rans_decoder> d(new rgbd_rans_decoder());
-    HIP_TRY(hipMalloc((void**)&d->meta, sizeof(int64_t) * 4));
-    HIP_TRY(hipMalloc((void**)&d->state, sizeof(uint64_t) * 2));
-    *out = d.release();
-    return RGBD_OK;
-}
-
-int rgbd_rans_decoder_set_stream(rgbd_rans_decoder* d, const uint8_t* stream, int64_t nbytes)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
-    if (!d || !stream || nbytes < 8 || (nbytes & 3)) return RGBD_EINVAL;
-    if (d->words) (void)hipFree(d->words);
-    d->words = nullptr;
-    HIP_TRY(hipMalloc((void**)&d->words, (size_t)nbytes));
-    HIP_TRY(hipMemcpy(d->words, stream, (size_t)nbytes, hipMemcpyHostToDevice));
-    d->nwords = nbytes / 4;
-    const int64_t hm[4] = {0, d->nwords, 0, 0};
-    HIP_TRY(hipMemcpy(d->meta, hm, sizeof(hm), hipMemcpyHostToDevice));
-    d->fresh = true;
-    return RGBD_OK;
-}
-
-int rgbd_rans_decoder_decode(rgbd_rans_decoder* d, const rgbd_tables* t, const int32_t* indexes, int64_t n,
-                             int32_t* symbols_out)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
-    if (!d || !d->words || !t || !t->ts.ready || n < 0 || (n && (!indexes || !symbols_out))) return RGBD_EINVAL;
-    if (!n) return RGBD_OK;
-    for (int64_t i = 0; i < n; ++i)
-        if (indexes[i] < 0 || indexes[i] >= t->ts.d.nrows) return RGBD_EINVAL;
-    int32_t *didx = nullptr, *dsym = nullptr;
-    HIP_TRY(hipMalloc((void**)&didx, sizeof(int32_t) * (size_t)n));
-    HIP_TRY(hipMalloc((void**)&dsym, sizeof(int32_t) * (size_t)n));
-    int rc = RGBD_OK;
-    if (hipMemcpy(didx, indexes, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) rc = RGBD_EHIP;
-    if (!rc)
-        rc = launch_rans_decode(d->words, d->meta, d->meta + 1, 1, d->state, d->fresh ? 1 : 0, didx, dsym, d->meta + 2, 0, n,
-                                t->ts.d, nullptr);
-    if (!rc && hipMemcpy(symbols_out, dsym, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = RGBD_EHIP;
-    if (!rc) d->fresh = false;
-    (void)hipFree(didx);
-    (void)hipFree(dsym);
-    return rc;
-}
-
-void rgbd_rans_decoder_destroy(rgbd_rans_decoder* d)
-{
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
-    if (!d) return;
-    (void)hipFree(d->words);
-    (void)hipFree(d->meta);
-    (void)hipFree(d->state);
-    delete d;
 }
 
 // blocked accumulation for a layer of cin_pad channels: block boundaries (in channels, multiples of 16) -> ConvArgs::blk_end
@@ -4188,6 +3868,12 @@ int rgbd_debug_bench_streams(int32_t n)
     return RGBD_OK;
 }
 
+int rgbd_debug_force_blocked(int32_t on)
+{
+    g_force_blocked = on ? 1 : 0;
+    return RGBD_OK;
+}
+
 int rgbd_debug_force_ckbd(int32_t part)
 {
     if (part < 0 || part > 2) return RGBD_EINVAL;
@@ -4306,6 +3992,14 @@ int rgbd_conv_bench(int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, 
     }
     a.ckbd = g_force_ckbd;
     a.loaded = g_bench_streams > 1 ? 1 : 0;
+    if (g_force_blocked && a.splitk == 1) {  // blocked accumulation: a block per 16 channels (multi-tap) / per 96 (1x1)
+        std::vector<int32_t> bl;
+        if (k == 1)
+            for (int c = 0; c < pc.cin_pad; c += 96) bl.push_back(std::min(96, pc.cin_pad - c));
+        rc = set_blocks(&a, bl.empty() ? nullptr : bl.data(), (int)bl.size());
+        a.bias_mode = k == 1 ? 2 : (transposed ? 0 : 1);
+        if (rc) return rc;
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -4367,11 +4061,13 @@ int rgbd_elic_create(int32_t N, int32_t M, const int32_t* slice_ch, int32_t n_sl
         sum += slice_ch[i];
     }
     if (sum != M) return RGBD_EINVAL;
+    if (const int pr = ensure_wait_policy()) return pr;
     rgbd_elic* m = new rgbd_elic();
     m->N = N;
     m->M = M;
     m->slice_ch.assign(slice_ch, slice_ch + n_slices);
     *out = m;
+    ++g_live_engines;
     return RGBD_OK;
 }
 
@@ -4470,6 +4166,7 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
     m->finalized = true;
     m->is_clone = true;
     *out = m;
+    ++g_live_engines;
     return RGBD_OK;
 }
 
@@ -4499,6 +4196,7 @@ void rgbd_elic_destroy(rgbd_elic* m)
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (dbg) fprintf(stderr, "[destroy %p] events/streams gone\n", (void*)m);
     delete m;
+    --g_live_engines;
     if (dbg) fprintf(stderr, "[destroy] done\n");
 }
 

@@ -37,6 +37,9 @@ class CodecPool:
         # last recorded in a capturing stream")
         if workers > 32:
             raise ValueError(f"CodecPool: {workers} engine instances requested, at most 32 have a HIP stream of their own")
+        from .sched import check_hw_queues
+
+        check_hw_queues()  # (refuses a GPU_MAX_HW_QUEUES above the range launches were seen to survive)
 
         # Host threads that wait for this GPU sleep instead of spinning (hipDeviceScheduleBlockingSync): a pool keeps W
         # threads waiting on W streams.  Measured on c3 with 16 instances and HIP-graph launches: 15.1 -> 1.2 busy host
@@ -85,7 +88,8 @@ class CodecPool:
         return out, (rec["x_hat"]["r"], rec["x_hat"]["d"])
 
     def close(self):
-        """Drop the engine instances and give the device back its default (spinning) wait policy."""
+        """Drop the engine instances and let go of the sleeping wait policy (it returns to the runtime's default once no engine
+        of this process is left: the policy never changes under a live engine)."""
         self.nets, self.streams = [], []
         if self._blocking_sync:
             from ._lib import set_blocking_sync

@@ -203,6 +203,9 @@ class TesterUnited:
         pool = getattr(self, "_pool_nets", None)
         if pool is None or pool[0] is not self.net:
             pool = [self.net]
+        from .sched import check_hw_queues
+
+        check_hw_queues()  # refuses GPU_MAX_HW_QUEUES > 48: launches on other streams were seen to fail there
         while len(pool) < W:
             pool.append(self.net.clone_shared())
         self._pool_nets = pool

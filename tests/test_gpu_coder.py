@@ -241,3 +241,158 @@ def test_both_encoder_generations_make_the_same_stream(kat, gc_tables, gpu_table
             out = subprocess.run([sys.executable, "-c", prog, path], env=env, capture_output=True, text=True, timeout=120)
             assert out.returncode == 0, out.stderr[-2000:]
             assert out.stdout.split()[-1] == want, var
+
+
+# ---- the operator-level exports of SURVEY 8(b) row 3: device-resident, many streams per launch ------------------------------
+def _vp(t):
+    import ctypes
+
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_device_batched_coder_streams_equal_the_oracle_and_decode_in_parts(kat, gc_tables, gpu_tables):
+    """rgbd_rans_encode_batch_dev / rgbd_rans_decode_batch_dev: 7 ragged streams (one EMPTY) in one launch each; every stream byte
+    for byte what the oracle's single-stream coder (rans_interface.cpp:99-205) produces; decoded in three calls that continue
+    from the kept state (decode_stream after decode_stream, :286-351)."""
+    dev = require_gpu()
+    import torch
+
+    from rgbd_amd._lib import check, lib
+
+    rng = np.random.RandomState(77)
+    counts = [3000, 1, 0, 4097, 12000, 640, 2999]
+    step = 600  # every non-empty stream is decoded `step` symbols per call where it has them: use equal-length prefixes below
+    base = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n = int(base[-1])
+    idx = rng.randint(0, 64, n).astype(np.int32)
+    sym = np.rint(rng.standard_normal(n) * kat["scale_table"][idx] * (1 + 3 * (rng.rand(n) < 0.02))).astype(np.int32)
+    esc = rng.rand(n) < 0.01
+    sym[esc] = rng.randint(-50000, 50000, int(esc.sum()))
+    d_sym = torch.from_numpy(np.concatenate([sym, [0]]).astype(np.int32)).to(dev)  # (readable one element past the end)
+    d_idx = torch.from_numpy(np.concatenate([idx, [0]]).astype(np.int32)).to(dev)
+    d_base = torch.from_numpy(base[:-1].copy()).to(dev)
+    d_cnt = torch.tensor(counts, dtype=torch.int64, device=dev)
+    ns = len(counts)
+    cap = int(lib().rgbd_rans_max_bytes(max(counts))) // 4
+    assert cap % 64 == 0
+    d_out = torch.zeros(ns * cap, dtype=torch.int32, device=dev)
+    d_words = torch.zeros(ns, dtype=torch.int64, device=dev)
+    d_err = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    check(lib().rgbd_rans_encode_batch_dev(gpu_tables.handle, _vp(d_sym), _vp(d_idx), _vp(d_base), _vp(d_cnt), ns, _vp(d_out), cap,
+                                           _vp(d_words), _vp(d_err), stream.cuda_stream), "encode_batch_dev")
+    stream.synchronize()
+    assert int(d_err.item()) == 0
+    words = d_words.cpu().numpy()
+    out = d_out.cpu().numpy().view(np.uint32).reshape(ns, cap)
+    streams = []
+    for s_ in range(ns):
+        got = out[s_, cap - words[s_]:].tobytes()
+        want = coder.rans_encode(sym[base[s_]:base[s_ + 1]], idx[base[s_]:base[s_ + 1]], gc_tables)
+        assert got == want, f"stream {s_} ({counts[s_]} symbols)"
+        streams.append(got)
+    # decode: the streams back to back in one buffer; `count` symbols per stream and call, so streams of one length share a call
+    blob = np.frombuffer(b"".join(streams), dtype=np.uint32)
+    lens = np.array([len(s_) // 4 for s_ in streams], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    d_blob = torch.from_numpy(blob.view(np.int32).copy()).to(dev)
+    got_sym = torch.full((n + 1,), -12345, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):  # the small argument tensors are allocated, filled and freed in the order of THIS stream
+        for s_ in range(ns):
+            if not counts[s_]:
+                continue
+            d_off, d_len = torch.tensor([offs[s_]], device=dev), torch.tensor([lens[s_]], device=dev)
+            d_sb = torch.tensor([base[s_]], dtype=torch.int64, device=dev)
+            state = torch.zeros(2, dtype=torch.int64, device=dev)
+            cuts = sorted(set([0, min(step, counts[s_]), counts[s_] // 2, counts[s_]]))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                check(lib().rgbd_rans_decode_batch_dev(gpu_tables.handle, _vp(d_blob), _vp(d_off), _vp(d_len), 1, _vp(state),
+                                                       1 if a == 0 else 0, _vp(d_idx), _vp(got_sym), _vp(d_sb), a, b - a,
+                                                       stream.cuda_stream), "decode_batch_dev")
+    stream.synchronize()
+    assert np.array_equal(got_sym.cpu().numpy()[:n], sym)
+    # ... and several equal-length streams in ONE decode launch (what the codec does for the images of a batch)
+    k = 2048
+    eq = rng.randint(0, 64, (5, k)).astype(np.int32)
+    es = np.rint(rng.standard_normal((5, k)) * kat["scale_table"][eq]).astype(np.int32)
+    ss = [coder.rans_encode(es[i], eq[i], gc_tables) for i in range(5)]
+    blob = np.frombuffer(b"".join(ss), dtype=np.uint32)
+    lens = np.array([len(s_) // 4 for s_ in ss], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    with torch.cuda.stream(stream):
+        d_blob = torch.from_numpy(blob.view(np.int32).copy()).to(dev)
+        d_i = torch.from_numpy(eq.reshape(-1)).to(dev)
+        d_s = torch.zeros(5 * k, dtype=torch.int32, device=dev)
+        d_sb = torch.arange(5, dtype=torch.int64, device=dev) * k
+        state = torch.zeros(10, dtype=torch.int64, device=dev)
+        d_offs, d_lens = torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev)
+        for part, (a, b) in enumerate([(0, 1000), (1000, k)]):
+            check(lib().rgbd_rans_decode_batch_dev(gpu_tables.handle, _vp(d_blob), _vp(d_offs), _vp(d_lens), 5, _vp(state), 1 if part == 0 else 0, _vp(d_i),
+                                                   _vp(d_s), _vp(d_sb), a, b - a, stream.cuda_stream), "decode_batch_dev")
+            stream.synchronize()
+    assert np.array_equal(d_s.cpu().numpy().reshape(5, k), es)
+
+
+def test_device_batched_coder_refuses_bad_arguments(gpu_tables):
+    dev = require_gpu()
+    import torch
+
+    from rgbd_amd._lib import lib
+
+    t = torch.zeros(256, dtype=torch.int64, device=dev)
+    L = lib()
+    assert L.rgbd_rans_encode_batch_dev(None, _vp(t), _vp(t), _vp(t), _vp(t), 1, _vp(t), 64, _vp(t), _vp(t), None) == -22
+    assert L.rgbd_rans_encode_batch_dev(gpu_tables.handle, _vp(t), _vp(t), _vp(t), _vp(t), 1, _vp(t), 100, _vp(t), _vp(t), None) == -22
+    assert L.rgbd_rans_encode_batch_dev(gpu_tables.handle, None, _vp(t), _vp(t), _vp(t), 1, _vp(t), 64, _vp(t), _vp(t), None) == -22
+    assert L.rgbd_rans_decode_batch_dev(gpu_tables.handle, None, _vp(t), _vp(t), 1, _vp(t), 1, _vp(t), _vp(t), _vp(t), 0, 5, None) == -22
+    assert L.rgbd_rans_decode_batch_dev(gpu_tables.handle, _vp(t), _vp(t), _vp(t), 1, _vp(t), 1, _vp(t), _vp(t), _vp(t), 0, 0, None) == 0
+
+
+@pytest.mark.parametrize("n,c,h,w", [(1, 16, 8, 10), (2, 48, 16, 20), (1, 5, 3, 2), (3, 160, 30, 40)])
+def test_ckbd_quant_index_vs_oracle(n, c, h, w, kat):
+    """rgbd_ckbd_quant_index / rgbd_ckbd_dequant against the oracle's restatement of utils/ckbd.py:37-125 +
+    entropy_models.py:118-146,561-568 -- symbols, indexes (both in the reference's (n, c, h, w/2) order) and the scattered y_hat,
+    bit for bit; includes scales under the 0.11 bound, exactly on table entries, and x - mean on .5 ties."""
+    dev = require_gpu()
+    import torch
+
+    from oracle import elic_oracle as eo
+    from rgbd_amd._lib import check, lib
+
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    table = eo.scale_table()
+    y = torch.randn(n, c, h, w, generator=g) * 6
+    means = torch.randn(n, c, h, w, generator=g)
+    scales = torch.exp(torch.randn(n, c, h, w, generator=g) * 2 - 0.5)
+    scales.view(-1)[::7] = table[torch.randint(0, 64, ((scales.numel() + 6) // 7,), generator=g)]  # exactly on table entries
+    scales.view(-1)[3::11] = 0.05                                                                   # under the bound
+    scales.view(-1)[5::13] = -1.0
+    y.view(-1)[::5] = (means.view(-1)[::5] + torch.randint(-4, 5, ((y.numel() + 4) // 5,), generator=g).float() + 0.5)  # ties
+    tb = np.ascontiguousarray(table.numpy(), np.float32)
+    import ctypes
+
+    f32p = ctypes.POINTER(ctypes.c_float)
+    yd, md, sd = y.to(dev), means.to(dev), scales.to(dev)
+    yhat = torch.full((n, c, h, w), 7.0, device=dev)  # (the anchor half defines every position: the 7s must go)
+    m = n * c * h * (w // 2)
+    want_hat = torch.zeros(n, c, h, w)
+    for anchor in (1, 0):
+        sym = torch.zeros(m, dtype=torch.int32, device=dev)
+        idx = torch.zeros(m, dtype=torch.int32, device=dev)
+        check(lib().rgbd_ckbd_quant_index(_vp(yd), _vp(md), _vp(sd), n, c, h, w, anchor, tb.ctypes.data_as(f32p), _vp(sym), _vp(idx),
+                                          _vp(yhat), None), "ckbd_quant_index")
+        ws = eo.quantize_symbols(eo.pack(y, bool(anchor)), eo.pack(means, bool(anchor)))
+        wi = eo.scale_indexes(eo.pack(scales, bool(anchor)), table)
+        assert np.array_equal(sym.cpu().numpy(), ws.reshape(-1).numpy()), f"symbols, anchor={anchor}"
+        assert np.array_equal(idx.cpu().numpy(), wi.reshape(-1).numpy()), f"indexes, anchor={anchor}"
+        want_hat = want_hat + eo.unpack(ws.float() + eo.pack(means, bool(anchor)), bool(anchor))
+        assert np.array_equal(yhat.cpu().numpy(), want_hat.numpy()), f"y_hat, anchor={anchor}"
+        # the decoder's half of the step rebuilds the same y_hat from the symbols
+        back = torch.full((n, c, h, w), 7.0, device=dev) if anchor else prev.clone()
+        check(lib().rgbd_ckbd_dequant(_vp(sym), _vp(md), n, c, h, w, anchor, _vp(back), None), "ckbd_dequant")
+        assert np.array_equal(back.cpu().numpy(), want_hat.numpy())
+        prev = back
+    assert lib().rgbd_ckbd_quant_index(_vp(yd), _vp(md), _vp(sd), n, c, h, w + 1, 1, tb.ctypes.data_as(f32p), _vp(sym), _vp(idx),
+                                       _vp(yhat), None) == -22  # odd width: the reference's squeeze needs w even

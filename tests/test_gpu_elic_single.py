@@ -184,4 +184,4 @@ def test_single_modal_pool_matches_single_instance(net1, sd1):
         for out, mx in pool.roundtrip_many([(x,)] * 5):  # eager, captured, replayed on the pool's side streams
             assert out["strings"] == ref["strings"] and torch.equal(mx, ref_rec["x_hat"])
         assert all(n.graph_count() >= 2 for n in pool.nets)
-    assert lib().rgbd_get_blocking_sync() == 0 and pool.nets == []
+    assert pool.nets == []  # (the wait policy stays while other engines of this process are alive: DESIGN 3.5)

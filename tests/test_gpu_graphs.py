@@ -243,7 +243,8 @@ def test_caller_side_stream_next_to_pool_then_destroy_and_close(synth_sd):
     """VERDICT r3 (weak 5b): the located trigger of the round-2 hang was "a stream the caller's thread drives next to the pool's
     threads under blocking sync".  The NULL-stream case is the test above; this is the other one -- the caller's OWN
     torch.cuda.Stream() on the main thread, capturing and replaying graphs like the pool's instances do, then the same
-    destroy-one-use-the-rest sequence, then CodecPool.close(), which must hand the device its default wait policy back.
+    destroy-one-use-the-rest sequence, then CodecPool.close().  (Round 5: the wait policy is the sleeping one from the first
+    engine on and never changes under a live engine -- asserted along the way.)
     Run once under the per-test timeout; a wait inside the runtime fails it (profiles/r03_hang_diagnosis.txt tells where to
     look -- do not loop it)."""
     import gc
@@ -252,7 +253,6 @@ def test_caller_side_stream_next_to_pool_then_destroy_and_close(synth_sd):
     from rgbd_amd._lib import lib
 
     require_gpu()
-    assert lib().rgbd_get_blocking_sync() == 0, "an earlier test left the device in blocking-sync mode (a pool without close())"
     pool = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=3, device="cuda", per_image_streams=True)
     assert lib().rgbd_get_blocking_sync() == 1
     lone = pool.nets[0].clone_shared()
@@ -283,8 +283,9 @@ def test_caller_side_stream_next_to_pool_then_destroy_and_close(synth_sd):
         assert list(one["r_strings"][0]) == want
     pool.close()
     pool.close()                         # idempotent
-    assert lib().rgbd_get_blocking_sync() == 0 and pool.nets == []
-    with torch.cuda.stream(side):        # and the survivor works under the default policy
+    assert lib().rgbd_get_blocking_sync() == 1 and pool.nets == []  # (`lone` is alive: the policy stays)
+    assert lib().rgbd_set_blocking_sync(0) == -1                    # ... and a request to change it is refused, not obeyed
+    with torch.cuda.stream(side):        # and the survivor works on
         one = lone.compress(r, d)
     side.synchronize()
     assert list(one["r_strings"][0]) == want
@@ -293,12 +294,14 @@ def test_caller_side_stream_next_to_pool_then_destroy_and_close(synth_sd):
     torch.cuda.synchronize()
 
 
-def test_garbage_engine_is_gone_before_the_wait_policy_switches(synth_sd):
-    """Round 4's sighting of the `hipFree never returns` wait: an engine that had done its work under the SPINNING
-    policy sat in a reference cycle, and the cyclic collector destroyed it while a CodecPool -- which had just switched the
-    device to blocking sync -- was uploading its first instance.  The policy switch now collects garbage first and drains the
-    device: here the garbage engine must be gone (its destroy has run) by the time the pool's constructor returns, and
-    everything keeps working afterwards.  Run once under the per-test timeout; do not loop it."""
+def test_wait_policy_never_changes_under_a_live_engine(synth_sd):
+    """Round 4's sighting of the `hipFree never returns` wait was an engine that had worked under the SPINNING
+    policy and was destroyed -- by the cyclic collector, inside a CodecPool constructor -- under the BLOCKING one.  Round 5
+    removes the mixed state instead of sequencing around it (advisor finding): the first engine of a device switches it to
+    the sleeping policy before launching anything, and nothing changes the policy while an engine is alive.  Here: a lone
+    engine works, becomes cyclic garbage, a pool is built and closed next to it, a second engine spans all of it -- the policy
+    is the same at every point, a request to change it is refused, and everything keeps working.  Run once under the per-test
+    timeout; do not loop it."""
     import gc
     import weakref
 
@@ -306,27 +309,58 @@ def test_garbage_engine_is_gone_before_the_wait_policy_switches(synth_sd):
     from rgbd_amd._lib import lib
 
     require_gpu()
-    assert lib().rgbd_get_blocking_sync() == 0
     r, d = _pair(1, 128, 192, 84)
-    lone = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
-    lone.load_state_dict(synth_sd)
-    lone.update(force=True)
-    lone = lone.to("cuda")
-    for _ in range(3):                   # eager, capture, replay under the spinning policy
+
+    def fresh():
+        n = rgbd_amd.ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+        n.load_state_dict(synth_sd)
+        n.update(force=True)
+        return n.to("cuda")
+
+    span = fresh()                       # alive from here to the end
+    assert lib().rgbd_get_blocking_sync() == 1
+    lone = fresh()
+    for _ in range(3):                   # eager, capture, replay
         want = lone.compress(r, d)
     holder = {"net": lone}
     holder["self"] = holder              # a cycle: only the cyclic collector can free it
     alive = weakref.ref(lone)
     del lone, holder
     assert alive() is not None           # (still garbage-in-waiting)
+    assert lib().rgbd_set_blocking_sync(0) == -1 and lib().rgbd_get_blocking_sync() == 1  # refused: engines are alive
     pool = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=2, device="cuda", per_image_streams=False)
-    assert alive() is None               # destroyed before the switch, under the policy it ran with
+    gc.collect()
+    assert alive() is None               # the garbage engine went under the policy it had worked with
     assert lib().rgbd_get_blocking_sync() == 1
     outs, xr, xd = pool.roundtrip(torch.cat([r, r]), torch.cat([d, d]))
     assert all(o["shape"] == want["shape"] for o in outs)
     pool.close()
     gc.collect()
-    assert lib().rgbd_get_blocking_sync() == 0
+    assert lib().rgbd_get_blocking_sync() == 1
+    assert span.compress(r, d)["r_strings"] == want["r_strings"]
+    del span
+    gc.collect()
+    torch.cuda.synchronize()
+
+
+def test_two_pools_with_interleaved_close(synth_sd):
+    """Advisor finding (round 4): the wait policy was not reference-counted -- closing one of two pools switched the device back
+    to spinning under the other pool's worker threads.  Now close() never changes the policy while an engine is alive."""
+    import rgbd_amd
+    from rgbd_amd._lib import lib
+
+    require_gpu()
+    r, d = _pair(2, 128, 192, 85)
+    a = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=2, device="cuda", per_image_streams=True)
+    b = rgbd_amd.CodecPool(synth_sd, config=rgbd_amd.model_config(), workers=2, device="cuda", per_image_streams=True)
+    assert lib().rgbd_get_blocking_sync() == 1
+    wa, _, _ = a.roundtrip(r, d)
+    wb, _, _ = b.roundtrip(r, d)
+    a.close()
+    assert lib().rgbd_get_blocking_sync() == 1   # b's engines are alive
+    wb2, _, _ = b.roundtrip(r, d)
+    assert [o["r_strings"] for o in wb2] == [o["r_strings"] for o in wb] == [o["r_strings"] for o in wa]
+    b.close()
     torch.cuda.synchronize()
 
 

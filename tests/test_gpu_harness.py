@@ -147,7 +147,7 @@ def test_tester_united_images_in_flight(net, tmp_path, monkeypatch):
                 files[sub + "/" + fn] = open(os.path.join(rec_dir, sub, fn), "rb").read()
         res[exp] = (rows, meters, files)
         assert t.job_mpx_per_s > 0
-        assert lib().rgbd_get_blocking_sync() == 0  # the pipelined path hands the device its default wait policy back
+        assert lib().rgbd_get_blocking_sync() == 1  # (one sleeping wait policy from the first engine on: DESIGN 3.5)
     (r0, m0, f0), (r1, m1, f1) = res["seq"], res["par"]
     assert f0 == f1 and len(f0) == 5 * len(sizes)  # 2 containers + rgb PNG + 8- and 16-bit depth PNG per image
     for a, b in zip(r0, r1):

@@ -173,6 +173,7 @@ def test_bicee_alone(net, orc, name):
             net.per_image_streams = True
             pr, pd = net.compress_united(yr.cuda(), hr.cuda(), yd.cuda(), hd.cuda())
             assert len(pr) == B and len(pd) == B
+            yhat_pi = [net.debug_tensor("yhat_r").copy(), net.debug_tensor("yhat_d").copy()]
             for i in range(B):
                 one_r, one_d = net.compress_united(yr[i:i + 1].cuda(), hr[i:i + 1].cuda(), yd[i:i + 1].cuda(), hd[i:i + 1].cuda())
                 assert one_r[0] == pr[i] and one_d[0] == pd[i]
@@ -180,7 +181,6 @@ def test_bicee_alone(net, orc, name):
             # batch -- and the reference's own floats differ between the two (its CPU library picks other kernels and block
             # sizes for another batch size: SURVEY 7.3), so since the engine follows the reference's arithmetic the
             # two formats agree to float precision, not bit for bit; each decodes its own encoder's y_hat exactly.
-            yhat_pi = [net.debug_tensor("yhat_r").copy(), net.debug_tensor("yhat_d").copy()]
             yh_r, yh_d = net.decompress_united(pr, hr.cuda(), pd, hd.cuda())
             assert np.array_equal(yh_r.cpu().numpy(), yhat_pi[0]) and np.array_equal(yh_d.cpu().numpy(), yhat_pi[1])
             assert np.mean(np.abs(yhat_pi[0] - yhat_enc[0])) < 1e-2 and np.mean(np.abs(yhat_pi[1] - yhat_enc[1])) < 1e-2

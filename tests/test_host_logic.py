@@ -348,3 +348,16 @@ def test_bench_host_cpu_info_and_worker_rule(tmp_path, monkeypatch):
 
     assert balanced_workers is bw2
     assert [bw2(n) for n in (1, 5, 20, 21, 40, 48, 64)] == [1, 5, 20, 11, 20, 16, 16]
+
+
+def test_hw_queue_count_outside_the_tested_range_is_refused():
+    """64 hardware queues made launches on other streams fail; the pool / harness refuse it up front."""
+    from rgbd_amd.sched import MAX_SAFE_HW_QUEUES, check_hw_queues
+
+    assert check_hw_queues({}) == 0
+    assert check_hw_queues({"GPU_MAX_HW_QUEUES": "40"}) == 40
+    assert check_hw_queues({"GPU_MAX_HW_QUEUES": str(MAX_SAFE_HW_QUEUES)}) == MAX_SAFE_HW_QUEUES
+    with pytest.raises(ValueError, match="GPU_MAX_HW_QUEUES=64"):
+        check_hw_queues({"GPU_MAX_HW_QUEUES": "64"})
+    with pytest.raises(ValueError, match="not an integer"):
+        check_hw_queues({"GPU_MAX_HW_QUEUES": "many"})

@@ -33,6 +33,7 @@ args = [a for a in argv if not a.startswith("--")]
 WRITE = "--write" in sys.argv
 ONLY_CKBD = "--only-ckbd" in sys.argv  # only the checkerboard-output launches (key field nphase >= 10)
 ONLY_1X1 = "--only-1x1" in sys.argv    # only the single-tap layers (the ring staging modes 4 / 5 apply to them)
+BLOCKED = "--blocked" in sys.argv      # only the blocked-accumulation launches (key phase field >= 100) -> tile_table_blk*.h
 WORKLOADS = [tuple(int(v) for v in a.split(",")) for a in args] or [(8, 256, 256), (4, 512, 640), (1, 256, 256), (1, 512, 640)]
 L = lib()
 L.rgbd_debug_bench_streams(STREAMS)
@@ -69,6 +70,8 @@ def bench(key, iters):
     N, H, W, cin, cout, ntaps, stride, nphase, splitk = key
     k = int(round(ntaps ** 0.5))
     ms = ctypes.c_float(0)
+    L.rgbd_debug_force_blocked(1 if nphase >= 100 else 0)  # ... and 100 * blocked
+    nphase %= 100
     L.rgbd_debug_force_ckbd(nphase // 10)  # the key's phase field carries 10 * ckbd
     nphase %= 10
     rc = L.rgbd_conv_bench(N, cin, H, W, cout, k, stride, k // 2, 1 if nphase > 1 else 0, 0, iters, ctypes.byref(ms))
@@ -81,7 +84,9 @@ for B, H, W in WORKLOADS:
     w_auto = w_best = 0.0
     for row in rows:
         key, cnt = row[:9], row[9]
-        if ONLY_CKBD and key[7] < 10:
+        if ONLY_CKBD and key[7] % 100 < 10:
+            continue
+        if BLOCKED != (key[7] >= 100):
             continue
         if ONLY_1X1 and key[5] != 1:
             continue
@@ -118,8 +123,10 @@ for B, H, W in WORKLOADS:
 L.rgbd_debug_force_tile(b"")
 L.rgbd_debug_force_splitk(0)
 L.rgbd_debug_force_ckbd(0)
+L.rgbd_debug_force_blocked(0)
 print(f"total auto {tot_auto:.2f} ms -> tuned {tot_best:.2f} ms, {len(table)} table entries")
-TABLE_NAME = "tile_table.h" if STREAMS <= 1 else "tile_table_loaded.h"  # isolated-launch winners / shared-chip winners
+TABLE_NAME = ("tile_table_blk.h" if STREAMS <= 1 else "tile_table_blk_loaded.h") if BLOCKED else \
+    ("tile_table.h" if STREAMS <= 1 else "tile_table_loaded.h")  # isolated-launch winners / shared-chip winners
 TABLE = os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc", TABLE_NAME)
 if os.path.exists(TABLE):  # keep what earlier runs measured for other shapes
     for ln in open(TABLE):
