@@ -42,9 +42,15 @@ WORKLOADS = {
     # name: (batch per GPU, H, W, synthetic config id, model)
     "c2_8x256x256": (8, 256, 256, 2, "ELIC_united"),
     "c3_4x480x640": (4, 480, 640, 3, "ELIC_united"),   # BASELINE config 3: 32 images over 8 GPUs = 4 per GPU
+    "c3_8x480x640": (8, 480, 640, 3, "ELIC_united"),   # (W, B) sweep at constant pairs in flight (round-4 review, item 5):
+    "c3_16x480x640": (16, 480, 640, 3, "ELIC_united"),  # two / four / eight of c3's steps per engine call
+    "c3_32x480x640": (32, 480, 640, 3, "ELIC_united"),
     "c5_stf_1x512x512": (1, 512, 512, 5, "STF_united"),  # BASELINE config 5 (Swin transforms)
     "c5_stf_4x512x512": (4, 512, 512, 5, "STF_united"),  # ... four pairs per step: the step is not one serial coder chain
 }
+# steps coded per engine call by default (--steps-per-call 0): the (instances x batch) sweep at 80 pairs in flight,
+# profiles/r05_call_batch_sweep.txt -- 20 x 4, 10 x 8, 5 x 16, 3 x 32 images: 5-6 instances of 16 are the best point
+DEFAULT_STEPS_PER_CALL = {"c3_4x480x640": 4}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (dense f32 matrix)
 
 
@@ -242,6 +248,11 @@ def main():
     ap.add_argument("--workers", type=int, default=0,
                     help="engine instances (HIP streams) per GPU; 1 = no overlap; 0 = as few full rounds of at most 20 "
                          "instances as --steps allows (20 steps -> 20 instances, 48 -> 16)")
+    ap.add_argument("--steps-per-call", type=int, default=0,
+                    help="steps one engine call codes together (0 = the workload's measured best: 4 for c3, else 1).  A step stays "
+                         "one batch of the workload; G steps per call means calls of G x that batch on fewer engine "
+                         "instances at the same number of pairs in flight (profiles/r05_call_batch_sweep.txt).  Kernels are "
+                         "batch-invariant and streams are per image, so no output bit depends on it; reduced to a divisor of --steps")
     ap.add_argument("--tile-mode", default="auto", choices=["auto", "latency", "throughput"],
                     help="conv tile tables: auto = throughput tiles when >= 4 engine instances share the GPU (CodecPool's rule)")
     ap.add_argument("--rehearse", action="store_true", help=argparse.SUPPRESS)  # CPU test of the N-rank plumbing
@@ -265,6 +276,11 @@ def main():
         sys.exit(2)
     if args.rehearse:
         sys.exit(rehearse(args))
+    G = args.steps_per_call if args.steps_per_call > 0 else DEFAULT_STEPS_PER_CALL.get(args.workload, 1)
+    G = max(1, min(G, args.steps))
+    while args.steps % G:
+        G -= 1
+    calls = args.steps // G
     if args.workers <= 0:
         # rgbd_amd.pool.balanced_workers, loaded by file: nothing may load torch / HIP before GPU_MAX_HW_QUEUES is final
         import importlib.util
@@ -273,7 +289,7 @@ def main():
             "_rgbd_sched", os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "sched.py"))
         sched = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(sched)
-        args.workers = sched.balanced_workers(args.steps)
+        args.workers = sched.balanced_workers(calls)
     if not _USER_QUEUES:
         # hardware queues of this process (fixed when HIP starts).  ELIC_united with 20 instances, round-4 sweep of the driver's
         # command: 16 / 24 / 28 / 32 / 40 / 48 / 64 queues -> 58.8 / 56.9 / 56.3 / 56.0 / 55.9 / 56.4 / 55.6 ms per step (streams
@@ -320,7 +336,8 @@ def main():
 
     host = {}
 
-    def timed(pool, rgb, depth, nsteps, nwarm, rounds=1):
+    def timed(pool, rgb, depth, ncalls, nwarm, rounds=1, per_call=1):
+        """ncalls engine calls (each codes `per_call` steps' worth of images), nwarm untimed warm-up STEPS first"""
         def run(k):
             # every step codes one full batch (compress + decompress); the W engine instances keep W steps in flight, so
             # one step's serial coder phases overlap another step's convolutions.  All k steps finish before this returns.
@@ -368,16 +385,17 @@ def main():
         if nwarm:
             # every engine instance sizes its workspace on its first batch and captures its HIP graphs on the second: the
             # timed steps then run the way a long job runs (RGBD_BENCH_WARM_ROUNDS=1: time the capturing calls instead)
-            w = min(pool.workers, nsteps)
-            host["warmup_steps_run"] = max(nwarm, int(os.environ.get("RGBD_BENCH_WARM_ROUNDS", "2")) * w)
-            run(host["warmup_steps_run"])
+            w = min(pool.workers, ncalls)
+            wcalls = max(-(-nwarm // per_call), int(os.environ.get("RGBD_BENCH_WARM_ROUNDS", "2")) * w)
+            host["warmup_steps_run"] = wcalls * per_call
+            run(wcalls)
         out = []
         for _ in range(rounds):
             distributed.barrier()
             torch.cuda.synchronize()
             c0 = os.times()
             t0 = time.perf_counter()
-            res = run(nsteps)
+            res = run(ncalls)
             torch.cuda.synchronize()
             distributed.barrier()
             dt = time.perf_counter() - t0
@@ -387,13 +405,13 @@ def main():
         return out[0] if rounds == 1 else out
 
     gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    rgb, depth, padded = make_inputs(B, H, W, cid)
-    elapsed, last = timed(net, rgb, depth, args.steps, args.warmup)
+    rgb, depth, padded = make_inputs(B * G, H, W, cid)  # one engine call codes G steps (G x B distinct images)
+    elapsed, last = timed(net, rgb, depth, calls, args.warmup, per_call=G)
     host_cores = host.get("cores_busy")
     # sustained: three more rounds of --steps steps on the same instances, timed as one region (what a long job settles at)
     sustained = None
     if not args.no_extras:
-        sus = timed(net, rgb, depth, args.steps, 0, rounds=3)
+        sus = timed(net, rgb, depth, calls, 0, rounds=3, per_call=G)
         t_sus = sum(e for e, _ in sus)
         sustained = {"steps": 3 * args.steps, "ms_per_step": round(t_sus / (3 * args.steps) * 1e3, 3),
                      "value": round(world * B * H * W * 3 * args.steps / t_sus / 1e6, 4), "unit": "Mpx/s",
@@ -423,8 +441,9 @@ def main():
     prof1 = conv_pass(tile_mode)
     prof_lat = prof1 if tile_mode == "latency" else conv_pass("latency")
     solo.set_tile_mode(tile_mode)
-    flops_step = prof1["flops"] / 2.0
-    launches_step = prof1["launches"] // 2
+    flops_step = prof1["flops"] / 2.0 / G        # (the pass runs two calls of G steps each)
+    launches_call = prof1["launches"] // 2
+    launches_step = launches_call / G
 
     extras = world == 1 and not args.no_extras
     latency = latency_tl = latency_hr = None
@@ -455,8 +474,96 @@ def main():
                 "definition": "sum(H*W) / (sum(enc) + sum(dec)), torch.cuda.synchronize() around compress() and "
                               "decompress() as in testing/tester_united.py:142-147,180-186"}
 
+    def entropy_stage(one):
+        """SURVEY 8(d), second regime: the entropy stage is not MFMA work.  Timed live with HIP events on the stream the kernels
+        are launched on, through the C ABI's device-resident entry points, on the model's OWN symbols of one 480x640 pair:
+        the two rANS kernels are one serial chain per stream (one wavefront each: ns per symbol is their figure of merit, not
+        bytes/s), the checkerboard quantise / index pass is HBM-bound (algorithmic bytes: y, mean, scale in, symbol, index,
+        y_hat out = 24 B per coded position, + 4 B per position of the other half the anchor pass zeroes)."""
+        import ctypes
+
+        import numpy as np
+
+        from rgbd_amd import ans
+        from rgbd_amd._lib import check, lib
+        from rgbd_amd.entropy_models import GaussianConditional, get_scale_table
+
+        L = lib()
+
+        def vp(t):
+            return ctypes.c_void_p(t.data_ptr())
+
+        rl, dl, _ = make_inputs(1, H, W, cid + 100)
+        one.compress(rl, dl)
+        pairs = [one.debug_symbols(m_) for m_ in (0, 1)]
+        T = int(pairs[0][0].size)
+        gcm = GaussianConditional()
+        gcm.update_scale_table(get_scale_table(), force=True)
+        cdf, sizes, offsets = gcm.numpy_tables()
+        tb = ans.Tables(cdf, sizes, offsets)
+        st = torch.cuda.Stream(device=dev)
+        sym = torch.from_numpy(np.concatenate([pairs[0][0], pairs[1][0], [0]]).astype(np.int32)).to(dev)
+        idx = torch.from_numpy(np.concatenate([pairs[0][1], pairs[1][1], [0]]).astype(np.int32)).to(dev)
+        base = torch.tensor([0, T], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([T, T], dtype=torch.int64, device=dev)
+        cap = int(L.rgbd_rans_max_bytes(T)) // 4
+        out = torch.zeros(2 * cap, dtype=torch.int32, device=dev)
+        words = torch.zeros(2, dtype=torch.int64, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+
+        def timed_launch(fn, reps=3):
+            best = None
+            with torch.cuda.stream(st):
+                for _ in range(reps):
+                    e0.record(st)
+                    fn()
+                    e1.record(st)
+                    st.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    best = ms if best is None else min(best, ms)
+            return best
+
+        enc_ms = timed_launch(lambda: check(L.rgbd_rans_encode_batch_dev(tb.handle, vp(sym), vp(idx), vp(base), vp(cnt), 2, vp(out), cap,
+                                                                         vp(words), vp(err), st.cuda_stream), "encode_batch_dev"))
+        assert int(err.item()) == 0
+        wn = words.cpu().numpy()
+        offs = torch.tensor([cap - int(wn[0]), 2 * cap - int(wn[1])], dtype=torch.int64, device=dev)
+        lens = torch.tensor([int(wn[0]), int(wn[1])], dtype=torch.int64, device=dev)
+        state = torch.zeros(4, dtype=torch.int64, device=dev)
+        got = torch.zeros_like(sym)
+        dec_ms = timed_launch(lambda: check(L.rgbd_rans_decode_batch_dev(tb.handle, vp(out), vp(offs), vp(lens), 2, vp(state), 1, vp(idx),
+                                                                         vp(got), vp(base), 0, T, st.cuda_stream), "decode_batch_dev"))
+        assert torch.equal(got[:2 * T], sym[:2 * T]), "device-batched decode did not return the encoder's symbols"
+        # checkerboard quantise / index pass on a 16-image latent batch (what one engine call of the timed region codes per slice)
+        n_, c_, h_, w_ = B * G, 192, padded[0] // 16, padded[1] // 16
+        gq = torch.Generator(device="cpu").manual_seed(3)
+        y_ = (torch.randn(n_, c_, h_, w_, generator=gq) * 6).to(dev)
+        mu = torch.randn(n_, c_, h_, w_, generator=gq).to(dev)
+        sc = torch.exp(torch.randn(n_, c_, h_, w_, generator=gq)).to(dev)
+        m_ = n_ * c_ * h_ * (w_ // 2)
+        qs, qi = torch.zeros(m_, dtype=torch.int32, device=dev), torch.zeros(m_, dtype=torch.int32, device=dev)
+        yh = torch.zeros_like(y_)
+        tabf = np.ascontiguousarray(get_scale_table().numpy(), np.float32)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        q_ms = timed_launch(lambda: check(L.rgbd_ckbd_quant_index(vp(y_), vp(mu), vp(sc), n_, c_, h_, w_, 1, tabf.ctypes.data_as(f32p),
+                                                                  vp(qs), vp(qi), vp(yh), st.cuda_stream), "ckbd_quant_index"), reps=5)
+        q_bytes = m_ * 28.0
+        return {"bound": "latency (rANS: one wavefront per stream) / hbm (checkerboard pass)",
+                "rans_encode_ns_per_symbol": round(enc_ms * 1e6 / T, 1), "rans_decode_ns_per_symbol": round(dec_ms * 1e6 / T, 1),
+                "symbols_per_stream": T, "streams": 2, "bytes_per_symbol": round(float(wn.sum()) * 4 / (2 * T), 3),
+                "ckbd_quant_index": {"achieved": round(q_bytes / (q_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(q_bytes / (q_ms * 1e-3) / 8e12, 4), "launch_us": round(q_ms * 1e3, 1),
+                                     "algorithmic_bytes": int(q_bytes), "positions": m_},
+                "note": "HIP events on the launch stream, C-ABI device entry points (rgbd_rans_*_batch_dev, "
+                        "rgbd_ckbd_quant_index), the model's own symbols of one 480x640 pair (stress recipe); separate pass, "
+                        "nothing else on the chip"}
+
+    entropy = None
     if extras:
         solo.set_tile_mode("latency")
+        entropy = entropy_stage(solo)
         latency = tester_latency(solo)
         latency["weights"] = "synthetic seed 0 (stress recipe: ~22 bpp, wide CDF rows, 17 % escapes)"
         solo.set_tile_mode(tile_mode)
@@ -484,14 +591,7 @@ def main():
 
     second = None
     others = []
-    if extras and args.workload == "c3_4x480x640":
-        B2, H2, W2, cid2, _m = WORKLOADS["c2_8x256x256"]
-        r2, d2, _p2 = make_inputs(B2, H2, W2, cid2)
-        e2, _ = timed(net, r2, d2, args.steps, args.warmup)
-        second = {"workload": "c2_8x256x256", "value": round(B2 * H2 * W2 * args.steps / e2 / 1e6, 4), "unit": "Mpx/s",
-                  "ms_per_step": round(e2 / args.steps * 1e3, 3), "images_per_gpu": B2, "image": [H2, W2]}
-        del r2, d2
-    pairs_in_flight = min(args.workers, args.steps) * B
+    pairs_in_flight = min(args.workers, calls) * B * G
     sd_main = sd
     net.close()  # (also hands the device its default wait policy back; the STF pool below sets its own)
     if extras and args.workload == "c3_4x480x640" and not os.environ.get("RGBD_BENCH_NO_C5"):
@@ -502,6 +602,22 @@ def main():
         # the runtime starts, and 16 instances of this model want fewer than the headline's 20 -- 13.1 vs 10.3 Mpx/s).
         del solo
         torch.cuda.empty_cache()
+        # BASELINE config 2 (8 x 256x256 per step) rides along the same way: its own process, its own instance count
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES",) or _USER_QUEUES}
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c2_8x256x256", "--steps", str(args.steps), "--warmup",
+                   str(args.warmup), "--no-extras", "--no-cpu-baseline"]
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode != 0 or not line:
+                raise RuntimeError(f"exit {cp.returncode}: {cp.stderr[-500:]}")
+            c = json.loads(line[-1])
+            second = {"workload": "c2_8x256x256", "value": c["value"], "unit": "Mpx/s", "ms_per_step": c["ms_per_step"],
+                      "images_per_gpu": c["config"]["images_per_gpu"], "image": c["config"]["image"],
+                      "engine_instances": c["config"]["engine_instances"], "job_level_frac": c["roofline"]["frac"]}
+        except Exception as e:
+            print(f"[bench] secondary workload c2_8x256x256 failed: {e}", file=sys.stderr)
+            second = {"workload": "c2_8x256x256", "error": str(e)[:300]}
         cpu5 = None
         for name5 in ("c5_stf_1x512x512", "c5_stf_4x512x512"):
             env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES",) or _USER_QUEUES}
@@ -536,7 +652,7 @@ def main():
             others.append(w)
 
     traffic = None
-    for rnd in ("r04", "r03", "r02", "r01"):  # HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+    for rnd in ("r05",):  # (the call shape of rounds 1-4 was one step per call: their per-launch bytes do not apply)  # HBM bytes per conv launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
             name = {"c2_8x256x256": f"{rnd}_pmc_traffic.json", "c3_4x480x640": f"{rnd}_c3_pmc_traffic.json"}[args.workload]
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -565,7 +681,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload,
                        "codec": "ELIC_united ch4 q=2_2 (N=192,M=320)" if model == "ELIC_united" else "STF_united ch4 (N=192,M=384)",
-                       "images_per_gpu": B, "image": [H, W], "padded": list(padded), "weights": f"synthetic seed 0 ({recipe} recipe)",
+                       "images_per_gpu": B, "steps_per_call": G, "images_per_call": B * G, "calls": calls,
+                       "image": [H, W], "padded": list(padded), "weights": f"synthetic seed 0 ({recipe} recipe)",
                        "streams": "per image", "y_bytes_last_batch": bytes_y, "engine_instances": args.workers,
                        "conv_tiles": tile_mode, "host_cores_busy_per_rank": host_cores,
                        "warmup_steps_run": host.get("warmup_steps_run", 0),
@@ -587,21 +704,24 @@ def main():
                                          "(not collectable from inside this process)",
                          "definition": "algorithmic conv FLOPs of the timed steps / wall time of the timed region, per GPU",
                          "hbm": None if traffic is None else {
-                             "achieved": round(traffic * launches_step / (elapsed / args.steps) / 1e9, 1), "peak": 8000.0,
-                             "unit": "GB/s", "frac": round(traffic * launches_step / (elapsed / args.steps) / 8e12, 4),
+                             "achieved": round(traffic * launches_call / (elapsed / calls) / 1e9, 1), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(traffic * launches_call / (elapsed / calls) / 8e12, 4),
                              "note": "PMC HBM bytes of the conv launches of one step / step time: the path is MFMA-bound"},
-                         "launches_per_step": launches_step, "gflop_per_step": round(flops_step / 1e9, 2),
+                         "launches_per_call": launches_call, "launches_per_step": round(launches_step, 2),
+                         "gflop_per_step": round(flops_step / 1e9, 2),
                          "isolated": {"achieved": round(iso_tflops, 3), "frac": round(iso_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                                       "avg_launch_us": round(prof_lat["conv_ms"] * 1e3 / max(prof_lat["launches"], 1), 2),
-                                      "conv_ms_per_step": round(prof_lat["conv_ms"] / 2, 3), "conv_tiles": "latency",
+                                      "conv_ms_per_step": round(prof_lat["conv_ms"] / 2 / G, 3), "conv_tiles": "latency",
                                       "note": "HIP events around every conv launch on its stream, single engine instance, "
                                               "no concurrent kernels, separate pass after the timed region, latency tiles "
                                               "(what a lone instance runs); profiles/r04_bench_w1_summary.txt"},
                          "isolated_timed_tiles": {"achieved": round(iso_tp_tflops, 3),
                                                   "frac": round(iso_tp_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                                                  "conv_ms_per_step": round(prof1["conv_ms"] / 2, 3), "conv_tiles": tile_mode,
+                                                  "conv_ms_per_step": round(prof1["conv_ms"] / 2 / G, 3), "conv_tiles": tile_mode,
                                                   "note": "the same pass with the tiles the timed region ran"}},
         }
+        if entropy is not None:
+            res["roofline"]["entropy"] = entropy
         if sustained is not None:
             res["sustained"] = sustained
         if latency is not None:
@@ -626,7 +746,7 @@ def main():
                                      "rANS state per modality, and Bi-CEE (models/elic_united.py:454-541) decodes the two "
                                      "modalities' 20 parts strictly one after the other, ~0.8 M serial symbol steps per "
                                      "480x640 pair"}
-            if second is not None:
+            if second is not None and "value" in second:
                 cpu2 = cpu_baseline(sd_main, 256, 256, 2, model, seconds_budget=8.0, batch8=False)
                 second["cpu_baseline"] = cpu2
                 second["vs_cpu"] = round(second["value"] / cpu2["value"], 2)

@@ -96,7 +96,8 @@ int rgbd_rans_decode_batch_dev(const rgbd_tables* t, const uint32_t* streams_dev
  * (row + col) odd (ckbd.py:37-48), and the other half of yhat_dev is set to zero; anchor == 0: the positions with (row + col)
  * even, the other half of yhat_dev is left as it is.  scale_table: the 64 entries of get_scale_table() (host).
  * symbols_dev / indexes_dev: n * c * h * (w / 2) int32 each, in (n, c, h, w / 2) order -- the order the reference's
- * .reshape(-1).tolist() feeds its encoder.  Synchronous.
+ * .reshape(-1).tolist() feeds its encoder.  One kernel, in place on the caller's tensors, asynchronous on `stream` (a hipStream_t;
+ * NULL = the default stream) like the coder entry points above; 8-byte aligned tensors take the vectorised form.
  * rgbd_ckbd_dequant is the decoder's half of the same step (elic_united.py:497-506, 529-538): yhat = symbol + mean. */
 int rgbd_ckbd_quant_index(const float* y_dev, const float* means_dev, const float* scales_dev, int32_t n, int32_t c, int32_t h,
                           int32_t w, int32_t anchor, const float* scale_table, int32_t* symbols_dev, int32_t* indexes_dev,
@@ -247,6 +248,15 @@ int rgbd_elic_debug_symbols(rgbd_elic* m, int32_t modality, int32_t* symbols, in
  * the first symbol where the two streams part (tests/test_gpu_parity_pinned.py). */
 int rgbd_elic_set_debug_floats(rgbd_elic* m, int32_t on);
 int rgbd_elic_debug_floats(rgbd_elic* m, int32_t modality, float* x, float* scale, int64_t cap, int64_t* n);
+/* Teacher forcing (parity bookkeeping; tests/test_gpu_parity_pinned.py::test_teacher_forced_*): the following compress() /
+ * compress_united() calls still take every decision from their own floats -- debug_symbols / debug_floats / the streams
+ * are the GPU's -- but the context later parts see is rebuilt from the symbols given here, in stream order (what
+ * models/elic_united.py:265-348 would have fed forward had it taken exactly these decisions): z_hat = z_sym + median
+ * after the z stage (entropy_models.py:437-446), y_hat = y_sym + mean after each of the 20 coding parts.  With the
+ * reference's symbols (tests/golden/margins_*.npz) every part BEHIND a first flip is compared under the reference's
+ * context.  n_y = B * M * h * w per modality (n_z = B * N * zh * zw; 0 = this stage is not forced); n_y = n_z = 0 clears. */
+int rgbd_elic_set_forced_symbols(rgbd_elic* m, int32_t modality, const int32_t* y_sym, int64_t n_y, const int32_t* z_sym,
+                                 int64_t n_z);
 
 /* Test hooks: force a split-K factor for rgbd_conv2d_nchw / the codec's entropy-model layers (0 = automatic) and
  * kernel-only timing of one convolution shape on NHWC scratch buffers (tools/conv_sweep.py). */

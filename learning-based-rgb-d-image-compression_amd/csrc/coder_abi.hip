@@ -170,83 +170,95 @@ int build_tables(const int32_t* cdf, int stride, const int32_t* sizes, const int
 // ---- checkerboard quantise / index ----------------------------------------------------------------------------------------
 namespace {
 
-// scales | means (two NCHW tensors) -> the [pixel][2C] parameter layout the entropy-parameter nets leave in HBM
-__global__ void pack_params_kernel(const float* __restrict__ scales, const float* __restrict__ means, int N, int C, int HW,
-                                   float* __restrict__ dst)
+struct ScaleTable64 {
+    float v[64];
+};
+
+// One checkerboard half of an NCHW slice in ONE pass, in place on the caller's tensors (no staging copies): thread i owns the
+// packed position (n, c, row, k) -- the order of the reference's .reshape(-1) of the squeezed tensor (ckbd.py:83-105) -- i.e.
+// the column pair (2k, 2k + 1) of that row.  VEC: the pair is read / written as one 8-byte access (every row starts on an even
+// element because w is even; needs 8-byte aligned tensors), so a wavefront's loads cover 512 contiguous bytes per operand.
+// MODE 0: symbol = rint(y - mean), index = build_indexes(scale), y_hat = symbol + mean (entropy_models.py:118-146,561-568);
+// MODE 2: y_hat = symbol + mean.  The anchor pass also writes the zero of the pair's other column (ckbd.py:66-72).
+// Same operations, in the same order, as ckbd_part_kernel (entropy.hip) performs on the codec's own layout.
+template <int MODE, bool VEC>
+__global__ void ckbd_nchw_kernel(const float* __restrict__ y, const float* __restrict__ means, const float* __restrict__ scales,
+                                 float* __restrict__ yhat, ScaleTable64 table, int rows, int h, int w2, int anchor,
+                                 int32_t* __restrict__ sym, int32_t* __restrict__ idx)
 {
-    const size_t total = (size_t)N * HW * 2 * C;
+    __shared__ float tbl[64];
+    if (threadIdx.x < 64) tbl[threadIdx.x] = table.v[threadIdx.x];
+    __syncthreads();
+    const size_t total = (size_t)rows * w2;  // rows = n * c * h
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c2 = (int)(i % (2 * C));
-        const size_t pix = i / (2 * C);
-        const size_t n = pix / HW, hw = pix % HW;
-        const float* src = c2 < C ? scales : means;
-        dst[i] = src[(n * C + (c2 < C ? c2 : c2 - C)) * (size_t)HW + hw];
+        const size_t r = i / w2;
+        const int k = (int)(i - r * w2);
+        const int row = (int)(r % h);
+        const int par = ckbd_col(row, 0, anchor);  // 0 / 1: which column of the pair this half codes
+        const size_t p0 = (r * w2 + k) * 2;        // element index of column 2k
+        float mean, scale = 0.f, yv = 0.f;
+        if (VEC) {
+            const float2 m2 = *reinterpret_cast<const float2*>(means + p0);
+            mean = par ? m2.y : m2.x;
+            if (MODE == 0) {
+                const float2 y2 = *reinterpret_cast<const float2*>(y + p0);
+                const float2 s2 = *reinterpret_cast<const float2*>(scales + p0);
+                yv = par ? y2.y : y2.x;
+                scale = par ? s2.y : s2.x;
+            }
+        } else {
+            mean = means[p0 + par];
+            if (MODE == 0) {
+                yv = y[p0 + par];
+                scale = scales[p0 + par];
+            }
+        }
+        int s;
+        if (MODE == 0) {
+            s = (int)rintf(yv - mean);  // round half to even, like torch.round
+            sym[i] = s;
+            idx[i] = scale_to_index(tbl, scale);
+        } else {
+            s = sym[i];
+        }
+        const float out = (float)s + mean;
+        if (anchor) {
+            if (VEC) {
+                *reinterpret_cast<float2*>(yhat + p0) = par ? make_float2(0.f, out) : make_float2(out, 0.f);
+            } else {
+                yhat[p0 + par] = out;
+                yhat[p0 + (par ^ 1)] = 0.f;
+            }
+        } else {
+            yhat[p0 + par] = out;
+        }
     }
 }
-
-struct DevTmp {  // frees on every exit path
-    std::vector<void*> p;
-    ~DevTmp()
-    {
-        for (void* q : p) (void)hipFree(q);
-    }
-    template <class T>
-    int get(T** out, size_t n)
-    {
-        void* q = nullptr;
-        if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return RGBD_EHIP;
-        p.push_back(q);
-        *out = (T*)q;
-        return RGBD_OK;
-    }
-};
 
 int ckbd_op(int mode, const float* y_dev, const float* means_dev, const float* scales_dev, int32_t n, int32_t c, int32_t h, int32_t w,
             int32_t anchor, const float* scale_table, int32_t* symbols_dev, int32_t* indexes_dev, float* yhat_dev, void* stream)
 {
-    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);  // frees / synchronous copies: not while a stream captures
     if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || (w & 1) || !means_dev || !yhat_dev || !symbols_dev) return RGBD_EINVAL;
     if (mode == 0 && (!y_dev || !scales_dev || !scale_table || !indexes_dev)) return RGBD_EINVAL;
     if ((int64_t)n * c * h * w >= ((int64_t)1 << 31)) return RGBD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int cs = (c + 3) & ~3;
-    const size_t npix = (size_t)n * h * w;
-    DevTmp tmp;
-    float *y = nullptr, *prm = nullptr, *yh = nullptr, *tbl = nullptr;
-    int64_t* base = nullptr;
-    int rc = tmp.get(&prm, npix * 2 * c);
-    if (!rc) rc = tmp.get(&yh, npix * cs);
-    if (!rc) rc = tmp.get(&base, 1);
-    if (!rc && mode == 0) rc = tmp.get(&y, npix * cs);
-    if (!rc && mode == 0) rc = tmp.get(&tbl, 64);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(base, 0, sizeof(int64_t), s));
+    ScaleTable64 tb{};
+    if (mode == 0) memcpy(tb.v, scale_table, sizeof(tb.v));
+    const int rows = n * c * h, w2 = w / 2;
+    const size_t total = (size_t)rows * w2;
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 8192);  // (grid-stride: ~32 workgroups per CU at most)
+    auto al8 = [](const void* p) { return ((uintptr_t)p & 7u) == 0; };
+    const bool vec = al8(means_dev) && al8(yhat_dev) && (mode != 0 || (al8(y_dev) && al8(scales_dev)));
+    const int an = anchor ? 1 : 0;
     if (mode == 0) {
-        HIP_TRY(hipMemcpyAsync(tbl, scale_table, 64 * sizeof(float), hipMemcpyHostToDevice, s));
-        rc = launch_nchw_to_nhwc16(y_dev, n, c, h, w, y, cs, s);
-        if (rc) return rc;
+        if (vec) hipLaunchKernelGGL((ckbd_nchw_kernel<0, true>), dim3(grid), dim3(256), 0, s, y_dev, means_dev, scales_dev, yhat_dev, tb, rows, h, w2, an, symbols_dev, indexes_dev);
+        else hipLaunchKernelGGL((ckbd_nchw_kernel<0, false>), dim3(grid), dim3(256), 0, s, y_dev, means_dev, scales_dev, yhat_dev, tb, rows, h, w2, an, symbols_dev, indexes_dev);
+    } else {
+        if (vec) hipLaunchKernelGGL((ckbd_nchw_kernel<2, true>), dim3(grid), dim3(256), 0, s, y_dev, means_dev, scales_dev, yhat_dev, tb, rows, h, w2, an, symbols_dev, indexes_dev);
+        else hipLaunchKernelGGL((ckbd_nchw_kernel<2, false>), dim3(grid), dim3(256), 0, s, y_dev, means_dev, scales_dev, yhat_dev, tb, rows, h, w2, an, symbols_dev, indexes_dev);
     }
-    const size_t work = npix * 2 * c;
-    hipLaunchKernelGGL(pack_params_kernel, dim3((unsigned)std::min<size_t>((work + 255) / 256, 4096)), dim3(256), 0, s,
-                       mode == 0 ? scales_dev : means_dev, means_dev, n, c, h * w, prm);
     HIP_TRY(hipGetLastError());
-    // the non-anchor half lands in the y_hat that already holds the anchors (ckbd.py:107-125); the anchor half defines all of it
-    rc = anchor ? RGBD_OK : launch_nchw_to_nhwc16(yhat_dev, n, c, h, w, yh, cs, s);
-    if (rc) return rc;
-    PartGeom g{};
-    g.B = n;
-    g.h = h;
-    g.w = w;
-    g.C = c;
-    g.anchor = anchor ? 1 : 0;
-    g.per_image = 0;
-    g.perm = 0;
-    rc = mode == 0 ? launch_ckbd_encode_part(y, cs, prm, 2 * c, yh, cs, tbl, g, symbols_dev, indexes_dev, base, 0, s)
-                   : launch_ckbd_decode_part(prm, 2 * c, yh, cs, g, symbols_dev, base, 0, s);
-    if (!rc) rc = launch_nhwc_to_nchw_clamp(yh, n, c, h, w, cs, yhat_dev, 0, s);
-    const hipError_t e = hipStreamSynchronize(s);
-    if (!rc && e != hipSuccess) rc = RGBD_EHIP;
-    return rc;
+    return RGBD_OK;
 }
 
 }  // namespace

@@ -271,6 +271,27 @@ struct PartGeom {
     int perm;       // 1: the tensors store channels at their permuted positions (rgbd_cperm); symbols stay in logical order
 };
 
+// checkerboard helpers: column of packed index k on a given row (utils/ckbd.py:51-64), and build_indexes
+// (entropy_models.py:561-568) as a binary search of the 64-entry scale table
+__device__ __forceinline__ int ckbd_col(int row, int k, int anchor)
+{
+    return 2 * k + (anchor ? (1 - (row & 1)) : (row & 1));
+}
+
+__device__ __forceinline__ int scale_to_index(const float* tbl, float s)
+{
+    // #{i < 63 : table[i] < max(s, 0.11)}  ==  63 - #{i < 63 : max(s, 0.11) <= table[i]}
+    s = fmaxf(s, 0.11f);
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tbl[mid] < s) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+
 int launch_ckbd_encode_part(const float* y, int ycs, const float* params, int pcs, float* yhat, int yhcs,
                             const float* table, PartGeom g, int32_t* sym, int32_t* idx, const int64_t* stream_base,
                             int64_t part_off_per_image, hipStream_t s, float* dbg_x = nullptr, float* dbg_s = nullptr);

@@ -395,6 +395,12 @@ struct rgbd_elic {
     float* dbg_x = nullptr;
     float* dbg_s = nullptr;
 
+    // rgbd_elic_set_forced_symbols (teacher forcing, parity bookkeeping): the next compress() calls still take every decision
+    // from their own floats (symbols / indexes / streams are the GPU's), but what later contexts see is rebuilt from THESE
+    // symbols -- z_hat = forced z symbol + median after the z stage, y_hat = forced symbol + mean after every coding part --
+    // so that the parts behind a first flip are evaluated under the reference's context (elic_united.py:265-348)
+    std::vector<int32_t> force_y[2], force_z[2];
+
     bool is_clone = false;  // created by rgbd_elic_clone_shared: shares the parent's buffer generations (DevGen)
 
     // ---- reference arithmetic ----------------------------------------------------------------------
@@ -2099,6 +2105,7 @@ struct rgbd_elic {
         int32_t* sym = nullptr;       // [2][B*per_image_total]
         int32_t* idx = nullptr;
         const int64_t* stream_base = nullptr;  // device [B] symbol base of each stream inside a modality region
+        const int32_t* force = nullptr;        // teacher forcing: [2][B*per_image_total] symbols later contexts are built from
         // decode side
         const uint32_t* words = nullptr;
         const int64_t* stream_off = nullptr;  // device [2][nstreams]
@@ -2133,6 +2140,8 @@ struct rgbd_elic {
             r = launch_ckbd_encode_part(y_slice.p, y_slice.cs, params.p, params.cs, yhat_slice.p, yhat_slice.cs,
                                         scale_table, g, sym, idx, sb, part_off, s, dbg_x ? dbg_x + mod_off : nullptr,
                                         dbg_s ? dbg_s + mod_off : nullptr);
+            if (!r && cd.force)  // y_hat of this part again, from the forced symbols (symbol + mean, as the decoder forms it)
+                r = launch_ckbd_decode_part(params.p, params.cs, yhat_slice.p, yhat_slice.cs, g, cd.force + mod_off, sb, part_off, s);
         } else {
             r = launch_ckbd_index_part(params.p, params.cs, scale_table, g, idx, sb, part_off, s);
             const int64_t count = (int64_t)g.C * g.h * (g.w / 2) * (cd.per_image ? 1 : g.B);
@@ -2741,6 +2750,21 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
         dbg_x = (float*)arena.take(sizeof(float) * (size_t)(2 * B * T));
         dbg_s = (float*)arena.take(sizeof(float) * (size_t)(2 * B * T));
     }
+    int32_t *fy = nullptr, *fz = nullptr;  // teacher forcing (rgbd_elic_set_forced_symbols)
+    if (!force_y[0].empty() || !force_y[1].empty()) {
+        if (force_y[0].size() != (size_t)(B * T) || force_y[1].size() != (size_t)(B * T)) return RGBD_EINVAL;
+        fy = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * T));
+        if (!dry())
+            for (int m = 0; m < 2; ++m)
+                HIP_TRY(hipMemcpyAsync(fy + (size_t)m * B * T, force_y[m].data(), sizeof(int32_t) * (size_t)(B * T), hipMemcpyHostToDevice, s));
+    }
+    if (!lat && (!force_z[0].empty() || !force_z[1].empty())) {
+        if (force_z[0].size() != (size_t)(B * Tz) || force_z[1].size() != (size_t)(B * Tz)) return RGBD_EINVAL;
+        fz = (int32_t*)arena.take(sizeof(int32_t) * (size_t)(2 * B * Tz));
+        if (!dry())
+            for (int m = 0; m < 2; ++m)
+                HIP_TRY(hipMemcpyAsync(fz + (size_t)m * B * Tz, force_z[m].data(), sizeof(int32_t) * (size_t)(B * Tz), hipMemcpyHostToDevice, s));
+    }
 
     // meta64 layout: [0,B) y stream_base inside a modality region (checkerboard kernels) ; [2B,3B) z base ;
     //   [3B,4B) z counts ; [6B,8B) z out_words ; from 8B: y encoder bases [2ny] (absolute), counts [2ny], out_words [2ny]
@@ -2827,7 +2851,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
                     if (!r)
                         r = launch_rans_encode(zs, zi, meta64 + 2 * B, meta64 + 3 * B, B, B, tables[2 + m].d, tables[2 + m].d,
                                                zwords + (size_t)m * B * zcap, zcap, meta64 + 6 * B + (size_t)m * B, err, s);
-                    if (!r) r = launch_z_dequant(zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s, perm());
+                    if (!r) r = launch_z_dequant(fz ? fz + (size_t)m * B * Tz : zs, B, zh, zw, N, md, zo[m]->p, zo[m]->cs, s, perm());
                     if (r) fail(r);
                 }
             }
@@ -2855,6 +2879,7 @@ int rgbd_elic::run_compress(const float* rgb_dev, const float* depth_dev, int B,
         cd.sym = sym;
         cd.idx = idx;
         cd.stream_base = meta64;
+        cd.force = fy;
         if (variant == 3) bicee_r2d(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
         else bicee(cd, &y_r, &y_d, hyp_r, hyp_d, yhat_r, yhat_d);
 
@@ -4609,6 +4634,17 @@ int rgbd_elic_set_debug_floats(rgbd_elic* m, int32_t on)
     if (!m) return RGBD_EINVAL;
     if (m->debug_floats != (on != 0)) m->graphs_invalidate();  // the workspace layout changes
     m->debug_floats = on != 0;
+    return RGBD_OK;
+}
+
+int rgbd_elic_set_forced_symbols(rgbd_elic* m, int32_t modality, const int32_t* y_sym, int64_t n_y, const int32_t* z_sym, int64_t n_z)
+{
+    std::unique_lock<std::shared_mutex> cap_lk(g_capture_mu);
+    if (!m || modality < 0 || modality > 1 || n_y < 0 || n_z < 0 || (n_y && !y_sym) || (n_z && !z_sym)) return RGBD_EINVAL;
+    if (m->variant == 1) return RGBD_EINVAL;  // (the two-modality codecs only)
+    m->graphs_invalidate();  // the workspace layout and the launch list change
+    m->force_y[modality].assign(y_sym, y_sym + n_y);
+    m->force_z[modality].assign(z_sym, z_sym + n_z);
     return RGBD_OK;
 }
 

@@ -18,26 +18,7 @@
 #define RANS_LOW (1ull << 31)
 
 
-// ---------------------------------------------------------------------------------------------
-// checkerboard helpers: column of packed index k on a given row (utils/ckbd.py:51-64)
-__device__ __forceinline__ int ckbd_col(int row, int k, int anchor)
-{
-    return 2 * k + (anchor ? (1 - (row & 1)) : (row & 1));
-}
-
-__device__ __forceinline__ int scale_to_index(const float* tbl, float s)
-{
-    // #{i < 63 : table[i] < max(s, 0.11)}  ==  63 - #{i < 63 : max(s, 0.11) <= table[i]}
-    s = fmaxf(s, 0.11f);
-    int lo = 0, hi = 63;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (tbl[mid] < s) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-
+// (ckbd_col / scale_to_index: common.h -- shared with the C ABI's stand-alone checkerboard operators, coder_abi.hip)
 __device__ __forceinline__ int64_t sym_pos(const PartGeom& g, const int64_t* stream_base, int64_t part_off, int b,
                                            int c, int row, int k)
 {

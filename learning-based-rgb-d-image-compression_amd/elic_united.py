@@ -425,6 +425,16 @@ class ELIC_united:
                                            ctypes.byref(n)), "debug_floats")
         return x, sc
 
+    def set_forced_symbols(self, modality: int, y_sym=None, z_sym=None):
+        """Teacher forcing (include/rgbd_amd.h: rgbd_elic_set_forced_symbols): later contexts of the following compress()
+        calls are rebuilt from these symbols (int32, stream order); None / empty clears that stage."""
+        self._ready()
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        ys = np.ascontiguousarray(y_sym if y_sym is not None else [], dtype=np.int32)
+        zs = np.ascontiguousarray(z_sym if z_sym is not None else [], dtype=np.int32)
+        check(lib().rgbd_elic_set_forced_symbols(self._h, modality, ys.ctypes.data_as(i32p), ys.size, zs.ctypes.data_as(i32p),
+                                                 zs.size), "set_forced_symbols")
+
     def clone_shared(self):
         """Another engine instance on the same GPU that borrows this one's device weights and tables (own workspace and
         stream).  The clone keeps a reference to its parent so the weights outlive it."""

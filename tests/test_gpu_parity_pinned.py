@@ -78,6 +78,9 @@ def _check(case, **vals):
             continue
         c = _clause(k)
         if c is None:
+            if k.startswith("forced_"):  # decisions that differ under the reference's context: a recorded ceiling, always
+                assert k in fl and v <= fl[k], (case, k, v, fl.get(k))
+                continue
             if k in fl:
                 assert v <= fl[k], (case, k, v, fl[k])  # (yhat_rel: float-stage ceiling)
             continue
@@ -437,10 +440,120 @@ def test_stf_vs_reference_golden(kat):
     _check("stf_c5_256x256", **vals)
 
 
+# ---- teacher forcing: every part of the goldens that are NOT identical, under the reference's context ------------------------
+def _forced_census(m, margins_name, run, medians=None):
+    """Round-4 review, item 2.  A first flip changes every later context, so the parts behind it were never compared with the
+    reference.  Here the engine rebuilds z_hat / y_hat after the z stage and after each coding part from the REFERENCE's
+    symbols (rgbd_elic_set_forced_symbols; tests/golden/margins_*.npz), while its decisions still come from its own floats:
+    all 20 parts (and z) are then decided under exactly the context the reference decided them under
+    (models/elic_united.py:265-348), and every decision that differs is counted.  Each one must be a decision the reference
+    itself took within its window of a boundary (the near-boundary list), with the GPU's float within FLOAT_TOL of the
+    reference's there."""
+    mg = np.load(os.path.join(GOLDEN, f"margins_{margins_name}.npz"))
+    tags = ("r", "d")
+    for mod, tag in enumerate(tags):
+        zs = mg[f"ref_zsym_{tag}"].astype(np.int32) if (medians is not None and f"ref_zsym_{tag}" in mg.files) else None
+        m.set_forced_symbols(mod, mg[f"ref_sym_{tag}"].astype(np.int32), zs)
+    m.set_debug_floats(True)
+    try:
+        run()
+        gsym, gidx = _symbols(m)
+        floats = [m.debug_floats(mod) for mod in range(2)]
+        zt = [m.debug_tensor(f"z_{tag}") for tag in tags] if medians is not None else None
+    finally:
+        m.set_debug_floats(False)
+        for mod in range(2):
+            m.set_forced_symbols(mod)
+    table = m.scale_table_numpy()
+    flips = decisions = zflips = zdec = 0
+    dirty = set()
+    worst = 0.0
+    for mod, tag in enumerate(tags):
+        rs, ri = mg[f"ref_sym_{tag}"].astype(np.int32), mg[f"ref_idx_{tag}"].astype(np.int32)
+        assert rs.shape == gsym[mod].shape
+        bs, bi = gsym[mod] != rs, gidx[mod] != ri
+        decisions += 2 * rs.size  # one rounding and one table-row decision per element
+        flips += int(bs.sum()) + int(bi.sum())
+        bad = np.nonzero(bs | bi)[0]
+        if not len(bad):
+            continue
+        ends = np.cumsum(mg[f"parts_{tag}"])
+        nb = mg[f"nb_pos_{tag}"]
+        j = np.searchsorted(nb, bad)
+        assert (j < len(nb)).all() and (nb[np.minimum(j, len(nb) - 1)] == bad).all(), \
+            (margins_name, tag, "a forced-context decision differs where the reference was NOT near a boundary", bad[:8])
+        xg, sg = floats[mod]
+        for pos, jj in zip(bad, j):
+            part = int(np.searchsorted(ends, pos, side="right"))
+            dirty.add((part, mod))
+            lo, hi = (int(ends[part - 1]) if part else 0), int(ends[part])
+            if bs[pos]:
+                d = abs(float(xg[pos]) - float(mg[f"nb_x_{tag}"][jj])) / max(float(np.abs(xg[lo:hi]).max()), 1.0)
+            else:
+                d = abs(float(sg[pos]) - float(mg[f"nb_s_{tag}"][jj])) / max(float(np.abs(sg[lo:hi]).max()), 1.0)
+            worst = max(worst, d)
+            assert d <= FLOAT_TOL, (margins_name, tag, int(pos), d)
+    if zt is not None:
+        for mod, tag in enumerate(tags):
+            if f"ref_zsym_{tag}" not in mg.files:
+                continue
+            zx = (zt[mod] - medians[mod].reshape(1, -1, 1, 1)).astype(np.float32).reshape(-1)
+            zb = np.rint(zx) != mg[f"ref_zsym_{tag}"].astype(np.float32)
+            zdec += zx.size
+            zflips += int(zb.sum())
+            for i in np.nonzero(zb)[0]:
+                ref = float(mg[f"ref_zx_{tag}"][i])
+                assert 0.5 - abs(ref - float(np.rint(ref))) <= float(mg["round_window"]) * max(1.0, abs(ref)), (margins_name, "z", tag, int(i))
+                worst = max(worst, abs(float(zx[i]) - ref) / max(float(np.abs(zx).max()), 1.0))
+    nparts = 2 * len(mg["parts_r"])
+    return {"forced_flips": flips, "forced_z_flips": zflips, "_forced_decisions": decisions + zdec,
+            "_forced_parts": nparts, "_forced_parts_clean": nparts - len(dirty), "_forced_worst_rel": worst,
+            "_forced_flips_per_million": 1e6 * (flips + zflips) / max(decisions + zdec, 1)}
+
+
+@pytest.mark.parametrize("name", ["c4_b2_8x12"])
+def test_teacher_forced_bicee(net, name):
+    from rgbd_amd import synth
+
+    g = np.load(os.path.join(GOLDEN, f"bicee_{name}.npz"))
+    B, h, w = int(g["B"]), int(g["h"]), int(g["w"])
+    yr, hr, yd, hd = [torch.from_numpy(a).cuda() for a in synth.synthetic_latents(B, h, w, 320, int(g["seed"]))]
+    net.per_image_streams = False
+    vals = _forced_census(net, "bicee_" + name, lambda: net.compress_united(yr, hr, yd, hd))
+    print("forced bicee", name, vals)
+    _check("forced_bicee_" + name, **vals)
+
+
+def test_teacher_forced_identical_golden_is_a_no_op(net):
+    """On a golden whose streams are identical, forcing the reference's symbols must change nothing: no decision differs and
+    the stream is still the reference's (the hook rebuilds y_hat as symbol + mean, exactly what the encoder had written)."""
+    g = load_golden("d_256x256")
+    r, d, rp, dp = _pad_inputs(1, 256, 256, int(g["config_id"]))
+    net.per_image_streams = False
+    out = {}
+    vals = _forced_census(net, "d_256x256", lambda: out.update(net.compress(rp.cuda(), dp.cuda())), medians=net.eb_medians_numpy())
+    assert vals["forced_flips"] == 0 and vals["forced_z_flips"] == 0, vals
+    assert out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes()
+
+
+def test_teacher_forced_stf():
+    from rgbd_amd import synth
+
+    require_gpu()
+    m = _model("STF_united", synth.synthetic_state_dict(0, model="STF_united"))
+    g = np.load(os.path.join(GOLDEN, "stf_c5_256x256.npz"))
+    r, d = synth.synthetic_batch(1, 256, 256, config_id=int(g["config_id"]))
+    vals = _forced_census(m, "stf_c5_256x256", lambda: m.compress(torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()),
+                          medians=m.eb_medians_numpy())
+    print("forced stf", vals)
+    _check("forced_stf_c5_256x256", **vals)
+
+
 # ---- the bench's batch shapes ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W,cid", [(8, 256, 256, 2), (4, 480, 640, 3)])
+@pytest.mark.parametrize("B,H,W,cid", [(8, 256, 256, 2), (4, 480, 640, 3), (16, 480, 640, 3)])
 def test_bench_shapes_batch_and_tile_invariance(net, gc, B, H, W, cid):
-    """bench.py's workloads (c2: 8x256x256, c3: 4x480x640 -> 512x640) in the tile mode the bench times (throughput tiles)
+    """bench.py's workloads (c2: 8x256x256, c3: 4x480x640 -> 512x640, and c3's engine-call shape since round 5: four steps =
+    16 images per call, bench.py --steps-per-call) in the tile mode the bench times (throughput tiles)
     against B=1 calls with the latency tiles: the per-image streams, the decoder's y_hat and x_hat must not move by a bit."""
     r, d, rp, dp = _pad_inputs(B, H, W, cid)
     rp, dp = rp.cuda(), dp.cuda()

@@ -44,6 +44,25 @@ def _cases():
                                     torch.cuda.current_stream().cuda_stream) == 0
         torch.cuda.synchronize()
         out[f"layernorm_{C}"] = _sha(y)
+    # round-4 review, item 3: the kernels behind a decision or a reported number that are not convolutions -- the factorised
+    # prior (eb_forward, entropy_models.py:391-428), the Gaussian likelihoods of the checkerboard parts (ckbd_estimate,
+    # entropy_models.py:534-558; its quantiser is ckbd_part's), x_hat of the eval forward, and the metric kernel
+    import rgbd_amd
+    from rgbd_amd import ELIC_united, metrics, synth
+
+    net = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
+    net.load_state_dict(synth.synthetic_state_dict(0))
+    net.update(force=True)
+    net = net.to("cuda")
+    r, d = synth.synthetic_batch(1, 128, 128, config_id=3)
+    rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
+    fw = net(rgb, depth)
+    for m in ("r", "d"):
+        out[f"forward_lik_y_{m}"] = _sha(fw[f"{m}_likelihoods"]["y"])
+        out[f"forward_lik_z_{m}"] = _sha(fw[f"{m}_likelihoods"]["z"])
+        out[f"forward_xhat_{m}"] = _sha(fw["x_hat"][m])
+    out["msssim_kernel_2x3x192x176"] = _sha(metrics.ms_ssim_gpu(torch.rand(2, 3, 192, 176, generator=g).cuda(),
+                                                                 torch.rand(2, 3, 192, 176, generator=g).cuda()))
     return out
 
 
