@@ -50,7 +50,7 @@ WORKLOADS = {
 }
 # steps coded per engine call by default (--steps-per-call 0): the (instances x batch) sweep at 80 pairs in flight,
 # profiles/r05_call_batch_sweep.txt -- 20 x 4, 10 x 8, 5 x 16, 3 x 32 images: 5-6 instances of 16 are the best point
-DEFAULT_STEPS_PER_CALL = {"c3_4x480x640": 4}
+DEFAULT_STEPS_PER_CALL = {"c3_4x480x640": 4, "c2_8x256x256": 4}  # (c2, same box: 20 x 8 28.0 ms, 10 x 16 26.1, 5 x 32 25.4-25.6)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (dense f32 matrix)
 
 
@@ -249,7 +249,7 @@ def main():
                     help="engine instances (HIP streams) per GPU; 1 = no overlap; 0 = as few full rounds of at most 20 "
                          "instances as --steps allows (20 steps -> 20 instances, 48 -> 16)")
     ap.add_argument("--steps-per-call", type=int, default=0,
-                    help="steps one engine call codes together (0 = the workload's measured best: 4 for c3, else 1).  A step stays "
+                    help="steps one engine call codes together (0 = the workload's measured best: 4 for c3 and c2, else 1).  A step stays "
                          "one batch of the workload; G steps per call means calls of G x that batch on fewer engine "
                          "instances at the same number of pairs in flight (profiles/r05_call_batch_sweep.txt).  Kernels are "
                          "batch-invariant and streams are per image, so no output bit depends on it; reduced to a divisor of --steps")
@@ -714,7 +714,7 @@ def main():
                                       "conv_ms_per_step": round(prof_lat["conv_ms"] / 2 / G, 3), "conv_tiles": "latency",
                                       "note": "HIP events around every conv launch on its stream, single engine instance, "
                                               "no concurrent kernels, separate pass after the timed region, latency tiles "
-                                              "(what a lone instance runs); profiles/r04_bench_w1_summary.txt"},
+                                              "(what a lone instance runs); profiles/r05_bench_w1_summary.txt"},
                          "isolated_timed_tiles": {"achieved": round(iso_tp_tflops, 3),
                                                   "frac": round(iso_tp_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                                                   "conv_ms_per_step": round(prof1["conv_ms"] / 2 / G, 3), "conv_tiles": tile_mode,

@@ -5,8 +5,8 @@ many ms of the round have >= 10 conv kernels in flight, 1-10, only coder kernels
 
     phase_table.py <rocprof dir> <stats.log with the bench's JSON line> [bin_ms=2]
 
-The timed round is located from the trace itself: the pooled part of the run is where >= 8 hardware queues have kernels in
-flight; its last `ms_per_step x steps` milliseconds (from the JSON line) are the timed region (the warm-up rounds precede it,
+The timed round is located from the trace itself: the pooled part of the run is where most of the engine instances' hardware
+queues (>= 8, or all but one of fewer instances) have kernels in flight; its last `ms_per_step x steps` milliseconds (from the JSON line) are the timed region (the warm-up rounds precede it,
 the single-instance conv passes follow it)."""
 import csv
 import glob
@@ -38,20 +38,24 @@ for s, e, k, q in ev:
         queues[b].add(q)
 # end of the pooled part: the last bin of a 40 ms window in which >= 8 queues were active
 win = max(1, int(40 / bin_ms))
-end = max(b for b in range(nb) if len(set().union(*queues[max(0, b - win):b + 1])) >= 8)
+inst = int(line["config"]["engine_instances"])
+need_q = min(8, max(2, inst - 1))
+end = max(b for b in range(nb) if len(set().union(*queues[max(0, b - win):b + 1])) >= need_q)
+many = 10 if inst >= 16 else max(2, inst // 2)  # "most instances are in a transform phase": 10 of 20, 2 of 5
 start = max(0, end - int(dur_ms / bin_ms) + 1)
 cls = defaultdict(float)
+K_MANY, K_FEW = f">= {many} conv kernels in flight", f"1 - {many} conv kernels in flight"
 for b in range(start, end + 1):
     c, r_ = fl["conv"][b], fl["coder"][b]
-    key = ">= 10 conv kernels in flight" if c >= 10 else ("1 - 10 conv kernels in flight" if c >= 1 else
+    key = K_MANY if c >= many else (K_FEW if c >= 1 else
                                                          ("coder kernels only (< 1 conv)" if r_ >= 0.5 else "neither (transitions, host)"))
     cls[key] += bin_ms
 span = (end - start + 1) * bin_ms
 print(f"timed round: {span:.0f} ms of trace ({line['steps']} steps x {line['ms_per_step']} ms = {dur_ms:.0f} ms by the bench's clock), "
       f"{line['config']['engine_instances']} engine instances, bins of {bin_ms:g} ms")
-for k in (">= 10 conv kernels in flight", "1 - 10 conv kernels in flight", "coder kernels only (< 1 conv)", "neither (transitions, host)"):
+for k in (K_MANY, K_FEW, "coder kernels only (< 1 conv)", "neither (transitions, host)"):
     print(f"  {k:34s} {cls[k]:8.0f} ms  {100 * cls[k] / span:5.1f} %")
-conv_ms = cls[">= 10 conv kernels in flight"] + cls["1 - 10 conv kernels in flight"]
+conv_ms = cls[K_MANY] + cls[K_FEW]
 tf = gflop_step * line["steps"] / conv_ms if conv_ms else 0.0
 print(f"conv FLOPs of the round / time with conv kernels in flight: {gflop_step * line['steps'] / 1e3:.1f} TFLOP / {conv_ms:.0f} ms = "
       f"{tf:.1f} TFLOP/s = {tf / 157.3:.3f} of the fp32 MFMA peak; / the whole round: "

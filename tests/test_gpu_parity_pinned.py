@@ -550,10 +550,10 @@ def test_teacher_forced_stf():
 
 
 # ---- the bench's batch shapes ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W,cid", [(8, 256, 256, 2), (4, 480, 640, 3), (16, 480, 640, 3)])
+@pytest.mark.parametrize("B,H,W,cid", [(8, 256, 256, 2), (4, 480, 640, 3), (16, 480, 640, 3), (32, 256, 256, 2)])
 def test_bench_shapes_batch_and_tile_invariance(net, gc, B, H, W, cid):
     """bench.py's workloads (c2: 8x256x256, c3: 4x480x640 -> 512x640, and c3's engine-call shape since round 5: four steps =
-    16 images per call, bench.py --steps-per-call) in the tile mode the bench times (throughput tiles)
+    16 images per call for c3, 32 for c2, bench.py --steps-per-call) in the tile mode the bench times (throughput tiles)
     against B=1 calls with the latency tiles: the per-image streams, the decoder's y_hat and x_hat must not move by a bit."""
     r, d, rp, dp = _pad_inputs(B, H, W, cid)
     rp, dp = rp.cuda(), dp.cuda()
