@@ -703,6 +703,11 @@ def main():
                          "traffic_note": "HBM bytes per conv launch, rocprofv3 PMC passes committed under profiles/ "
                                          "(not collectable from inside this process)",
                          "definition": "algorithmic conv FLOPs of the timed steps / wall time of the timed region, per GPU",
+                         # FLOPs the launches execute / algorithmic FLOPs: < 1 because a checkerboard-output launch computes one
+                         # half of its layer and an anchor-input launch half of the taps as well (what the MFMA-busy counter
+                         # sees is `frac` x this)
+                         "executed_over_algorithmic": round(prof1["flops_executed"] / max(prof1["flops"], 1.0), 4),
+                         "executed_frac": round(job_tflops / PEAK_FP32_MFMA_TFLOPS * prof1["flops_executed"] / max(prof1["flops"], 1.0), 4),
                          "hbm": None if traffic is None else {
                              "achieved": round(traffic * launches_call / (elapsed / calls) / 1e9, 1), "peak": 8000.0,
                              "unit": "GB/s", "frac": round(traffic * launches_call / (elapsed / calls) / 8e12, 4),
@@ -711,6 +716,7 @@ def main():
                          "gflop_per_step": round(flops_step / 1e9, 2),
                          "isolated": {"achieved": round(iso_tflops, 3), "frac": round(iso_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                                       "avg_launch_us": round(prof_lat["conv_ms"] * 1e3 / max(prof_lat["launches"], 1), 2),
+                                      "executed_frac": round(prof_lat["flops_executed"] / (prof_lat["conv_ms"] / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                       "conv_ms_per_step": round(prof_lat["conv_ms"] / 2 / G, 3), "conv_tiles": "latency",
                                       "note": "HIP events around every conv launch on its stream, single engine instance, "
                                               "no concurrent kernels, separate pass after the timed region, latency tiles "

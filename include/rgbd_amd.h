@@ -341,6 +341,11 @@ int rgbd_elic_graph_count(const rgbd_elic* m);
 int rgbd_debug_fail_captures(int32_t n);
 int rgbd_elic_set_profile(rgbd_elic* m, int32_t on);
 int rgbd_elic_profile_read(rgbd_elic* m, double* conv_ms, int64_t* launches, double* flops);
+/* `flops` above are ALGORITHMIC: the FLOPs of the reference's layers (what bench.py's roofline divides by time).  A launch that
+ * computes one checkerboard half of a layer's outputs (the entropy-parameter nets' last layer, utils/ckbd.py:83-125) or meets
+ * only half of the taps with non-zero inputs (local-context convs on an anchor-only slice) EXECUTES fewer: this is their sum,
+ * so that executed FLOP/s -- what the MFMA-busy counter sees -- can be reported beside the algorithmic figure. */
+int rgbd_elic_profile_read_executed(rgbd_elic* m, double* flops_executed);
 
 #ifdef __cplusplus
 }

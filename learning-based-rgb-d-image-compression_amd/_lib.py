@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "librgbd_amd.so")
 _SO = os.environ.get("RGBD_AMD_LIB", _SO)  # A/B builds: point at another librgbd_amd.so
-_SRCS = ["conv_mfma.hip", "conv_mfma_blk.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "coder_abi.hip", "engine.hip"]
+_SRCS = ["conv_mfma.hip", "conv_mfma_blk.hip", "pointwise.hip", "swin.hip", "entropy.hip", "metrics.hip", "coder_abi.hip", "engine.hip", "engine_abi.hip"]
 _LIB = None
 
 ERRORS = {-22: "invalid argument", -12: "out of memory", -5: "HIP runtime error", -28: "buffer too small",
@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                                os.path.join(csrc, "tile_table_blk.h"), os.path.join(csrc, "tile_table_blk_loaded.h")],
              "conv_mfma_blk.hip": [body]}
     hdrs.append(os.path.join(csrc, "splitk_table.h"))
-    extra["engine.hip"] = extra["coder_abi.hip"] = [os.path.join(csrc, "engine_internal.h")]
+    extra["coder_abi.hip"] = [os.path.join(csrc, "engine_internal.h")]
+    extra["engine.hip"] = extra["engine_abi.hip"] = [os.path.join(csrc, "engine_internal.h"), os.path.join(csrc, "engine.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(objdir, exist_ok=True)
     jobs, objs = [], []
@@ -149,6 +150,7 @@ def lib():
         "rgbd_elic_profile_dump": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
         "rgbd_elic_profile_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), i64p,
                                                   ctypes.POINTER(ctypes.c_double)]),
+        "rgbd_elic_profile_read_executed": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export what include/rgbd_amd.h declares
@@ -164,7 +166,7 @@ EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync
            "rgbd_elic_destroy", "rgbd_elic_set_ref_blocks", "rgbd_elic_get_refnum", "rgbd_elic_ref_table_misses", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_forced_symbols", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats", "rgbd_layernorm", "rgbd_debug_force_layernorm_form",
-           "rgbd_elic_profile_read", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_force_blocked", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
+           "rgbd_elic_profile_read", "rgbd_elic_profile_read_executed", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_force_blocked", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]
 
 

@@ -1,4 +1,4 @@
-// Shared between the translation units of the host runtime (engine.hip: the codec; coder_abi.hip: the stand-alone coder and
+// Shared between the translation units of the host runtime (engine.h / engine.hip / engine_abi.hip: the codec; coder_abi.hip: the stand-alone coder and
 // checkerboard operators of the C ABI).  Not part of the ABI.
 #pragma once
 #include <memory>

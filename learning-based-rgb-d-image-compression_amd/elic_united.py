@@ -471,7 +471,9 @@ class ELIC_united:
     def profile_read(self):
         ms, n, fl = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
         check(lib().rgbd_elic_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
-        return {"conv_ms": ms.value, "launches": n.value, "flops": fl.value}
+        fx = ctypes.c_double(0)
+        check(lib().rgbd_elic_profile_read_executed(self._h, ctypes.byref(fx)), "profile_read_executed")
+        return {"conv_ms": ms.value, "launches": n.value, "flops": fl.value, "flops_executed": fx.value}
 
     def __del__(self):
         try:

@@ -4,7 +4,8 @@ Layered contract:
   * integer stages are bit-exact: the oracle coder reproduces the GPU streams from the GPU's own symbols/indexes,
     the oracle's z quantiser reproduces the GPU z-streams from the GPU's z floats, and the GPU decoder reproduces the
     encoder's y_hat bit for bit;
-  * float stages agree with the oracle to 2e-5 relative (different fp32 summation order than oneDNN);
+  * float stages agree with the oracle run on THIS box to 1e-5 relative (its CPU blocks the sums for its own thread count;
+    bitwise equality with the reference's own tensors: tests/test_gpu_refbits.py);
   * symbol flips against the oracle's float path are counted and bounded; PSNR within 1e-4 dB of the oracle whenever
     the streams coincide, bpp identical then.
 """
@@ -95,8 +96,8 @@ def test_case_a_layers_and_streams(net, orc):
     # float stages vs oracle (and vs the reference's own tensors in the golden file)
     for name in ("y_r", "y_d", "z_r", "z_d", "hyper_r", "hyper_d"):
         got = net.debug_tensor(name)
-        assert _rel(got, tr[name].numpy()) < 2e-5, name
-        assert _rel(got, g[name]) < 2e-5, name
+        assert _rel(got, tr[name].numpy()) < 1e-5, name  # (this box's CPU: its own thread count / blocking)
+        assert _rel(got, g[name]) < 1e-5, name
     # integer stage 1: z streams from the GPU's own z floats
     for mod, key, zname in (("rgb", "r_strings", "z_r"), ("depth", "d_strings", "z_d")):
         strings, _ = orc._z_compress(mod, torch.from_numpy(net.debug_tensor(zname)))
@@ -167,7 +168,7 @@ def test_bicee_alone(net, orc, name):
         yhat_r, yhat_d = net.decompress_united(sr[0], hr.cuda(), sdp[0], hd.cuda())
         assert np.array_equal(yhat_r.cpu().numpy(), yhat_enc[0]) and np.array_equal(yhat_d.cpu().numpy(), yhat_enc[1])
         if same:
-            assert _rel(yhat_enc[0], g["yhat_r"]) < 2e-5 and _rel(yhat_enc[1], g["yhat_d"]) < 2e-5
+            assert _rel(yhat_enc[0], g["yhat_r"]) < 1e-5 and _rel(yhat_enc[1], g["yhat_d"]) < 1e-5
         # per-image streams == B separate calls
         if B > 1:
             net.per_image_streams = True

@@ -49,8 +49,8 @@ def test_r2d_128x192(net_r2d, sd_r2d):
     tr, orc.trace = orc.trace, None
     for name in ("y_r", "y_d", "z_r", "z_d"):
         got = net_r2d.debug_tensor(name)
-        assert _rel(got, tr[name].numpy()) < 2e-5, name
-    assert _rel(net_r2d.debug_tensor("y_r"), g["y_r"]) < 2e-5 and _rel(net_r2d.debug_tensor("y_d"), g["y_d"]) < 2e-5
+        assert _rel(got, tr[name].numpy()) < 1e-5, name
+    assert _rel(net_r2d.debug_tensor("y_r"), g["y_r"]) < 1e-5 and _rel(net_r2d.debug_tensor("y_d"), g["y_d"]) < 1e-5
     for mod, key, zname in (("rgb", "r_strings", "z_r"), ("depth", "d_strings", "z_d")):
         strings, _ = orc._z_compress(mod, torch.from_numpy(net_r2d.debug_tensor(zname)))
         assert strings == out[key][1]

@@ -39,7 +39,7 @@ L.rgbd_elic_profile_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
 path = "/tmp/layers.csv"
 L.rgbd_elic_profile_dump(net._h, path.encode())
 rows = [l.strip().split(",") for l in open(path)][1:]
-groups = collections.defaultdict(lambda: [0, 0.0, 0.0])
+groups = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
 
 
 def group(name):
@@ -49,17 +49,19 @@ def group(name):
     return re.sub(r"\.\d+$", ".N", name)
 
 
-for name, cnt, ms, gf, tf in rows:
+for name, cnt, ms, gf, tf, gfx, tfx in rows:
     g = groups[group(name)]
     g[0] += int(cnt)
     g[1] += float(ms)
     g[2] += float(gf)
+    g[3] += float(gfx)
 tot = sum(g[1] for g in groups.values())
-print(f"total conv ms/step {tot/N:.2f}")
+print(f"total conv ms/step {tot/N:.2f}   (TF/s: algorithmic = the reference's layer FLOPs / time; executed = what the launches compute / time --")
+print("   lower where a launch computes one checkerboard half of its layer or meets only half of the taps with non-zero inputs)")
 for k, g in sorted(groups.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"{k:62s} n={g[0]//N:4d} {g[1]/N:7.3f} ms/step {g[2]/max(g[1],1e-9):7.1f} TF/s {100*g[1]/tot:5.1f}%")
+    print(f"{k:62s} n={g[0]//N:4d} {g[1]/N:7.3f} ms/step {g[2]/max(g[1],1e-9):7.1f} TF/s  executed {g[3]/max(g[1],1e-9):6.1f}  {100*g[1]/tot:5.1f}%")
 if os.environ.get("LAYER_RAW"):  # LAYER_RAW=<regex>: the individual layers behind the groups
     pat = re.compile(os.environ["LAYER_RAW"])
-    for name, cnt, ms, gf, tf in sorted(rows, key=lambda r: r[0]):
+    for name, cnt, ms, gf, tf, gfx, tfx in sorted(rows, key=lambda r: r[0]):
         if pat.search(name):
-            print(f"  {name:70s} n={int(cnt)//N:3d} {float(ms)/N*1e3:8.1f} us/step {float(gf)/max(float(ms),1e-9):7.1f} TF/s")
+            print(f"  {name:70s} n={int(cnt)//N:3d} {float(ms)/N*1e3:8.1f} us/step {float(gf)/max(float(ms),1e-9):7.1f} TF/s  executed {float(gfx)/max(float(ms),1e-9):6.1f}")
