@@ -173,6 +173,10 @@ int launch_conv_fused(const ConvArgs& a, hipStream_t s);
 int conv_log_enable(int on);            // shape log for tools/tune_tiles.py
 long conv_log_read(char* buf, long cap);  // CSV text; returns the size needed
 
+// y = mul * sigmoid(t) + res2 with the reference's per-element choice of sigmoid form (vector / scalar tail of torch's CPU loop)
+int launch_sigmoid_gate_ref(const float* t, int tcs, const float* mul, int mcs, const float* res2, int r2cs, float* y, int ycs,
+                            int N, int HW, int C, int per_image, int threads, hipStream_t s);
+
 // ---- pointwise kernels (pointwise.hip) --------------------------------------------------------
 int launch_nchw_to_nhwc16(const float* src, int N, int C, int H, int W, float* dst, int cs, hipStream_t s, int perm = 0);
 int launch_nhwc_to_nchw_clamp(const float* src, int N, int C, int H, int W, int cs, float* dst, int clamp01,

@@ -416,6 +416,7 @@ struct rgbd_elic {
     // the reference machine (tools/refarith/discover.py -> refarith_tables.json -> rgbd_elic_set_ref_blocks).
     bool refnum = getenv("RGBD_LEGACY_NUMERICS") == nullptr;
     int ref_batch = 1;  // the batch size of the reference call this call stands for (per-image streams: 1)
+    int ref_threads = 8;  // CPU threads of the reference run the tables describe (refarith_tables.json "meta"; set_ref_blocks kind 4)
     struct RefTables {
         // kind 0 (1x1 reduce blocks): {0, cin, cout, h, w, batch} -> channels per block
         // kind 1 (small-tensor path, im2col + sgemm): {1, cin, cout, h, w, k * 100 + stride * 10 + pad} -> K-block lengths
@@ -1166,10 +1167,50 @@ struct rgbd_elic {
         return y;
     }
 
+    // torch.sigmoid on the CPU is not one function: the last len % 32 elements of every parallel chunk of the
+    // tensor go through the scalar path (libm's expf instead of Sleef's vector exp).  A tensor that has such elements -- e.g.
+    // the 320 x 16 x 16 attention map of a 256 x 256 image: three chunks of 27307 -- cannot take its gate in the conv epilogue,
+    // which knows no flat index: the conv then writes its plain output and sigmoid_gate_ref_kernel applies a * sigmoid(b) + x.
+    bool sigmoid_scalar_tails(long numel) const
+    {
+        long tasks = 1;
+        if (numel >= 32768 && ref_threads > 1) tasks = std::min<long>(ref_threads, (numel + 32767) / 32768);
+        const long chunk = (numel + tasks - 1) / tasks;
+        return chunk % 32 != 0 || (numel - (tasks - 1) * chunk) % 32 != 0;
+    }
+    bool gate_needs_own_pass(const std::string& name, const Act& x, int stride, int pad, const Epi& ep)
+    {
+        if (!refnum || ep.act != ACT_SIGMOID) return false;
+        auto it = convs.find(name + ".weight");
+        if (it == convs.end() || it->second.transposed) return false;
+        const PackedConv& pc = it->second;
+        const int OH = (x.h + 2 * pad - pc.k) / stride + 1, OW = (x.w + 2 * pad - pc.k) / stride + 1;
+        return sigmoid_scalar_tails((long)(ref_batch == 1 ? 1 : x.n) * pc.cout * OH * OW);
+    }
+    Act conv_gated_ref(const std::string& name, const Act& x, int stride, int pad, const Epi& ep, const Act* dst)
+    {
+        const PackedConv& pc = convs.find(name + ".weight")->second;
+        const int OH = (x.h + 2 * pad - pc.k) / stride + 1, OW = (x.w + 2 * pad - pc.k) / stride + 1;
+        Act out = dst ? *dst : alloc(x.n, OH, OW, pc.cout);
+        const size_t mark = arena.top;
+        Epi plain;
+        plain.res1 = ep.res1;
+        const Act t = conv(name, x, stride, pad, plain);
+        if (!dry() && !rc) {
+            const int r = launch_sigmoid_gate_ref(t.p, t.cs, ep.mul ? ep.mul->p : nullptr, ep.mul ? ep.mul->cs : 0,
+                                                  ep.res2 ? ep.res2->p : nullptr, ep.res2 ? ep.res2->cs : 0, out.p, out.cs, x.n,
+                                                  OH * OW, pc.cout, ref_batch == 1 ? 1 : 0, ref_threads, s);
+            if (r) fail(r);
+        }
+        arena.top = mark;
+        return out;
+    }
+
     Act conv(const std::string& name, const Act& x, int stride, int pad, Epi ep = Epi(), const Act* dst = nullptr,
              const std::string* fuse1x1 = nullptr, const std::string* lead1x1 = nullptr, const Act* lead_dst = nullptr)
     {
         Act out;
+        if (!fuse1x1 && !ep.dup && !ep.ckbd && gate_needs_own_pass(name, x, stride, pad, ep)) return conv_gated_ref(name, x, stride, pad, ep, dst);
         if (!fuse1x1 && conv_kpacked(name, x, stride, pad, ep, dst, &out)) return out;
         if (!fuse1x1 && small_tensor_layer(name, x)) return conv_small(name, x, stride, pad, ep, dst);
         if (refnum && !fuse1x1 && !dst && stride == 2 && pad == 2 && !ep.res1 && !ep.mul && !ep.res2 && !ep.dup && !ep.ckbd) {
@@ -1225,6 +1266,10 @@ struct rgbd_elic {
                const std::string* const fuse1x1[2] = nullptr, const std::string* const lead1x1[2] = nullptr,
                const Act* const lead_dst[2] = nullptr)
     {
+        if (!fuse1x1 && (gate_needs_own_pass(n[0], x[0], stride, pad, ep[0]) || gate_needs_own_pass(n[1], x[1], stride, pad, ep[1]))) {
+            for (int m = 0; m < 2; ++m) out[m] = conv(n[m], x[m], stride, pad, ep[m], dst ? dst[m] : nullptr);
+            return;
+        }
         if (!fuse1x1) {
             Act o0;
             if (conv_kpacked(n[0], x[0], stride, pad, ep[0], dst ? dst[0] : nullptr, &o0)) {  // (the depth twin is of that kind too)

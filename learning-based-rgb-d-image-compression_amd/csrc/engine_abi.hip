@@ -601,6 +601,7 @@ int rgbd_elic_clone_shared(const rgbd_elic* src, rgbd_elic** out)
     m->variant = src->variant;
     m->in_ch = src->in_ch;
     m->refnum = src->refnum;
+    m->ref_threads = src->ref_threads;
     m->ref_tab = src->ref_tab;
     m->convs = src->convs;    // device pointers are shared, read-only; the generations below keep them alive
     m->dense = src->dense;
@@ -703,6 +704,11 @@ static bool ends_with(const std::string& s, const char* suf)
 int rgbd_elic_set_ref_blocks(rgbd_elic* m, int32_t kind, int32_t cin, int32_t cout, int32_t h, int32_t w, int32_t batch,
                              const int32_t* blocks, int32_t nblocks)
 {
+    if (m && kind == 4 && blocks && nblocks == 1 && blocks[0] >= 1 && blocks[0] <= 4096) {  // CPU threads of the reference run
+        m->ref_threads = blocks[0];
+        m->graphs_invalidate();
+        return RGBD_OK;
+    }
     if (!m || !blocks || nblocks <= 0 || nblocks > (kind >= 2 ? 65536 : 64) || kind < 0 || kind > 3) return RGBD_EINVAL;
     int sum = 0;
     for (int i = 0; i < nblocks; ++i) {

@@ -695,3 +695,43 @@ int launch_scatter_phase(const float* src, int B, int h, int jw, int scs, int j0
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }
+
+
+// ---- sigmoid gate of a tensor whose reference sigmoid has scalar tails ----------------------------------------
+// y = mul * sigmoid(t) + res2, element by element over NHWC tensors whose channels are stored permuted (rgbd_cperm): what the
+// conv epilogue does for ACT_SIGMOID + mul + res2 (layers.py:198-213 a * sigmoid(b) + x; attention.py:84-97 x * sigmoid(.)),
+// except that the sigmoid of element (n, c, h, w) is the one torch's CPU kernel applies at flat index i of the reference's
+// contiguous [batch, C, H, W] tensor: the Sleef vector form, or -- in the last len % 32 elements of each parallel chunk --
+// the scalar form on the C library's expf (exact_math.h).  per_image: the reference codes image by image (batch 1).
+__global__ void sigmoid_gate_ref_kernel(const float* __restrict__ t, int tcs, const float* __restrict__ mul, int mcs,
+                                        const float* __restrict__ res2, int r2cs, float* __restrict__ y, int ycs, int N, int HW,
+                                        int C, int per_image, int threads)
+{
+    const int C16 = (C + 15) & ~15;
+    const size_t total = (size_t)N * HW * C16;
+    const long numel = (long)(per_image ? 1 : N) * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int sc = (int)(i % C16);       // stored channel
+        const size_t pix = i / C16;          // n * HW + hw
+        const int c = rgbd_cperm(sc);        // logical channel (the permutation is an involution)
+        if (c >= C) continue;
+        const long n = (long)(pix / HW), hw = (long)(pix % HW);
+        const long flat = ((per_image ? 0 : n) * C + c) * HW + hw;
+        const float v = t[pix * tcs + sc];
+        float g = rgbd_aten_scalar_tail(flat, numel, threads) ? rgbd_sigmoid_ref_scalar(v) : rgbd_sigmoid_ref(v);
+        if (mul) g = __fmul_rn(g, mul[pix * mcs + sc]);
+        if (res2) g = __fadd_rn(g, res2[pix * r2cs + sc]);
+        y[pix * ycs + sc] = g;
+    }
+}
+
+int launch_sigmoid_gate_ref(const float* t, int tcs, const float* mul, int mcs, const float* res2, int r2cs, float* y, int ycs,
+                            int N, int HW, int C, int per_image, int threads, hipStream_t s)
+{
+    if (!t || !y || N <= 0 || HW <= 0 || C <= 0) return RGBD_EINVAL;
+    const size_t total = (size_t)N * HW * ((C + 15) & ~15);
+    hipLaunchKernelGGL(sigmoid_gate_ref_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, t, tcs,
+                       mul, mcs, res2, r2cs, y, ycs, N, HW, C, per_image, threads);
+    HIP_TRY(hipGetLastError());
+    return RGBD_OK;
+}

@@ -22,6 +22,9 @@ def push(L, handle, check):
     if L.rgbd_elic_get_refnum(handle) != 1:
         return 0
     n = 0
+    # kind 4: the thread count of the reference run the tables were measured under (torch.sigmoid's chunking depends on it)
+    thr = (ctypes.c_int32 * 1)(int(tables()["meta"].get("threads", 8)))
+    check(L.rgbd_elic_set_ref_blocks(handle, 4, 0, 0, 0, 0, 0, thr, 1), "set_ref_blocks")
     for cin, cout, h, w, b, blocks in tables()["conv1x1"]:
         arr = (ctypes.c_int32 * len(blocks))(*blocks)
         check(L.rgbd_elic_set_ref_blocks(handle, 0, cin, cout, h, w, b, arr, len(blocks)), "set_ref_blocks")

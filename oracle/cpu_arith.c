@@ -202,6 +202,61 @@ void orc_sigmoid(const float* x, float* y, int64_t n)
     for (int64_t i = 0; i < n; i++) y[i] = 1.0f / (1.0f + orc_expf_u10(0.0f - x[i]));
 }
 
+/* expf as the C library computes it (glibc >= 2.27, sysdeps/ieee754/flt-32/e_expf.c = the published ARM optimized-routines
+ * algorithm): x * 32 / ln 2 = k + r, exp(x) = 2^(k/32) * p(r) in double, one rounding to float at the end.  The 32-entry table
+ * is bits(2^(i/32)) - (i << 47).  Checked against this container's libm on 4 x 10^8 random arguments in [-30, 30]: no
+ * difference (tests/test_oracle_arith.py checks a sample).  Behind torch.sigmoid's SCALAR path, see orc_sigmoid_tensor. */
+static const uint64_t orc_exp2f_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+float orc_expf_libm(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283f) return INFINITY;
+    if (x < -103.97208f) return 0.0f;
+    const double z0 = (0x1.71547652b82fep+0 * 32) * (double)x;
+    double kd = z0 + 0x1.8p+52;
+    uint64_t ki;
+    memcpy(&ki, &kd, 8);
+    kd -= 0x1.8p+52;
+    const double r = z0 - kd;
+    uint64_t t = orc_exp2f_tab[ki % 32] + (ki << 47);
+    double sc;
+    memcpy(&sc, &t, 8);
+    const double z = (0x1.c6af84b912394p-5 / 32 / 32 / 32) * r + (0x1.ebfce50fac4f3p-3 / 32 / 32);
+    const double r2 = r * r;
+    double y = (0x1.62e42ff0c52d6p-1 / 32) * r + 1.0;
+    y = z * r2 + y;
+    return (float)(y * sc);
+}
+/* Is element i of a contiguous tensor of n elements handled by the SCALAR tail of an ATen vectorised elementwise loop?
+ * TensorIterator::for_each runs serially below 32768 elements (or with one thread); otherwise at::parallel_for gives
+ * min(threads, ceil(n / 32768)) tasks ceil(n / tasks) elements each (ParallelOpenMP.h).  Inside a task's range
+ * vectorized_loop (cpu/Loops.h) takes two 16-lane vectors per step and hands the last len % 32 elements to the scalar op. */
+int orc_aten_scalar_tail(int64_t i, int64_t n, int threads)
+{
+    int64_t tasks = 1;
+    if (n >= 32768 && threads > 1) {
+        tasks = (n + 32767) / 32768;
+        if (tasks > threads) tasks = threads;
+    }
+    const int64_t chunk = (n + tasks - 1) / tasks, c0 = (i / chunk) * chunk;
+    const int64_t len = (n - c0 < chunk) ? n - c0 : chunk;
+    return (i - c0) >= len - (len % 32);
+}
+/* torch.sigmoid over a whole contiguous tensor, as `threads` CPU threads compute it: Sleef's vector exp everywhere except in the
+ * scalar tails, where it is 1 / (1 + expf(-x)) with the C library's expf (UnaryOpsKernel.cpp sigmoid_kernel: the scalar lambda) */
+void orc_sigmoid_tensor(const float* x, float* y, int64_t n, int threads)
+{
+    for (int64_t i = 0; i < n; i++)
+        y[i] = orc_aten_scalar_tail(i, n, threads) ? 1.0f / (1.0f + orc_expf_libm(-x[i])) : 1.0f / (1.0f + orc_expf_u10(0.0f - x[i]));
+}
+
 /* ---- torch's CPU bilinear upsampling (UpSampleKernel.cpp), align_corners = False -------------------------------------------
  * x [C][h][w] -> y [C][H][W].  The source index is one fused multiply-add; the taps are combined in one of two ways:
  *   H + W > 128  (generic separable kernel):      t_k = fma(v_k0, lx0, v_k1 * lx1);  out = fma(t_0, ly0, t_1 * ly1)

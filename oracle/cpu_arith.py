@@ -88,8 +88,13 @@ def deconv2d_s1(x, w, b, pad):
     return y
 
 
-def sigmoid(x):
+def sigmoid(x, threads=None):
+    """torch.sigmoid of a contiguous tensor.  threads=None: the vector body everywhere (what a tensor without scalar tails gets);
+    threads=T: as T CPU threads compute it, scalar tails of the parallel chunks included (orc_sigmoid_tensor)."""
     x = _f32(x)
     y = np.empty_like(x)
-    lib().orc_sigmoid(_p(x), _p(y), ctypes.c_int64(x.size))
+    if threads is None:
+        lib().orc_sigmoid(_p(x), _p(y), ctypes.c_int64(x.size))
+    else:
+        lib().orc_sigmoid_tensor(_p(x), _p(y), ctypes.c_int64(x.size), ctypes.c_int(threads))
     return y

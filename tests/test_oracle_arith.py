@@ -110,6 +110,37 @@ def test_sigmoid_vector_body():
     _same_or_skip(ca.sigmoid(x.numpy()), torch.sigmoid(x).numpy(), "sigmoid")
 
 
+
+@pytest.mark.parametrize("shape", [(1, 320, 16, 16), (2, 320, 8, 8), (1, 320, 8, 12), (3, 7, 11, 13), (1, 100003)])
+def test_sigmoid_of_a_whole_tensor_scalar_tails_included(shape):
+    """torch.sigmoid is not one function on the CPU: the last len % 32 elements of every parallel chunk go through the scalar
+    path (libm's expf instead of Sleef's vector exp).  orc_sigmoid_tensor applies ATen's chunking rule -- the 320 x 16 x 16 case
+    is the attention map of a 256 x 256 image: three chunks of 27307 elements, 11 / 11 / 10 scalar ones -- and must equal torch
+    everywhere; the vector-only form must equal it everywhere else."""
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 4
+    ref = torch.sigmoid(x).numpy()
+    assert np.array_equal(ca.sigmoid(x.numpy(), threads=8), ref)
+    n = x.numel()
+    tail = np.array([ca.lib().orc_aten_scalar_tail(ctypes.c_int64(i), ctypes.c_int64(n), 8) for i in range(n)], bool).reshape(shape) \
+        if n <= 100003 else None
+    assert np.array_equal(ca.sigmoid(x.numpy())[~tail], ref[~tail])
+
+
+def test_libm_expf_restatement():
+    """orc_expf_libm (glibc's table-driven expf, the scalar path's exp) against this container's C library"""
+    L = ca.lib()
+    L.orc_expf_libm.restype = ctypes.c_float
+    L.orc_expf_libm.argtypes = [ctypes.c_float]
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-30, 30, 20000), rng.normal(0, 2, 20000), [0.0, -0.0, 1.0, -1.0, 88.0, -87.0, 100.0, -110.0]]).astype(np.float32)
+    for v in xs:
+        assert np.float32(L.orc_expf_libm(float(v))) == np.float32(libm.expf(float(v))), float(v)
+
 @pytest.mark.parametrize("c,h,w,oh,ow", [(48, 9, 11, 64, 80), (48, 19, 25, 128, 160), (48, 9, 9, 64, 64), (48, 3, 3, 32, 32), (20, 7, 9, 20, 100)])
 def test_bilinear_both_kernels(c, h, w, oh, ow):
     x = _rnd(c + h, 1, c, h, w)
