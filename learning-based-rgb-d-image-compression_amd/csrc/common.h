@@ -200,7 +200,7 @@ int launch_se_fc(const float* mean, int N, int C, int hidden, const float* w0, c
 // fc.2.weight as stored ([C][hidden]); cls0 / cls1: per-row dot-product class of the two layers (device, nullptr = all main)
 int launch_channel_mean_ref(const float* x, int N, int HW, int cs, int C, float* mean, int mstride, hipStream_t s);
 int launch_se_fc_ref(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, const int* cls0,
-                     const int* cls1, float* hid, float* scale, hipStream_t s, int mstride = 0);
+                     const int* cls1, float* hid, float* scale, hipStream_t s, int mstride = 0, int form = -1);
 // mode 0: y = x*s ; mode 1: y = x + x*s   (s per (n, c))
 int launch_channel_scale_to(const float* x, int N, int HW, int xcs, int C, const float* scale, int mode, float* y, int ycs,
                             hipStream_t s);

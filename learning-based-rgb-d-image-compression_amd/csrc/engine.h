@@ -759,6 +759,9 @@ struct rgbd_elic {
         auto it = dense.find(wname + ".rowclass");
         return (it == dense.end() || ref_batch != 1) ? nullptr : reinterpret_cast<const int*>(it->second);
     }
+    // the SE Linear layers of a reference call on a batch of two vectors take MKL's n = 2 form for every row (se_linear_ref_kernel
+    // form 3; measured for batch 2 only: other batch sizes keep the "main" order and make no bit-level claim)
+    int se_form() const { return ref_batch == 2 ? 3 : -1; }
     float* dense_of(const std::string& name)
     {
         auto it = dense.find(name);
@@ -1767,7 +1770,7 @@ struct rgbd_elic {
         const float* mu = means ? means : mean;
         if (!r && refnum)
             r = launch_se_fc_ref(mu, x.n, x.c, x.c / 16, w0, w1, cls_of(p + ".fc.0.weight"), cls_of(p + ".fc.2.weight"), hid, sc, s,
-                                 means ? mstride : 0);
+                                 means ? mstride : 0, se_form());
         else if (!r) r = launch_se_fc(mu, x.n, x.c, x.c / 16, w0, w1, hid, sc, s, means ? mstride : 0, perm());
         if (!r) r = launch_channel_scale_to(x.p, x.n, HW, x.cs, x.c, sc, mode, y.p, y.cs, s);
         if (r) fail(r);
@@ -1794,7 +1797,7 @@ struct rgbd_elic {
             r = refnum ? launch_channel_mean_ref(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s)
                        : launch_channel_mean_strided(other.p, other.n, HW, other.cs, other.c, mean + own.c, C, s);
         if (!r && refnum)
-            r = launch_se_fc_ref(mean, own.n, C, C / 16, w0, w1, cls_of(p + ".fc.0.weight"), cls_of(p + ".fc.2.weight"), hid, sc, s);
+            r = launch_se_fc_ref(mean, own.n, C, C / 16, w0, w1, cls_of(p + ".fc.0.weight"), cls_of(p + ".fc.2.weight"), hid, sc, s, 0, se_form());
         else if (!r) r = launch_se_fc(mean, own.n, C, C / 16, w0, w1, hid, sc, s, 0, perm());
         if (!r) r = launch_channel_scale_to_strided(own.p, own.n, HW, own.cs, own.c, sc, C, 0, f.p, f.cs, s);
         if (!r) r = launch_channel_scale_to_strided(other.p, other.n, HW, other.cs, other.c, sc + own.c, C, 0, f.p + own.c, f.cs, s);

@@ -525,18 +525,40 @@ __device__ __forceinline__ float hred16(float v, int lane)
     return v;
 }
 
+// form >= 0 overrides the per-row classes.  Form 3 = the reference's nn.Linear on a batch of TWO vectors (MKL sgemm with n = 2;
+// measured like the batch-1 classes, oracle/cpu_arith.c orc_linear_b2): K < 48: one k-ordered fma chain from 0; otherwise lane l
+// of ONE 16-lane accumulator takes elements 16 v + l (the K % 16 tail as one more masked step), and the lanes are reduced as
+// q_i = ((a_i + a_{i+4}) + a_{i+8}) + a_{i+12}, (q_0 + q_1) + (q_2 + q_3).
 __global__ __launch_bounds__(64) void se_linear_ref_kernel(const float* __restrict__ w, const float* __restrict__ x, int K, int J,
                                                            int xstride, int xperm, const int* __restrict__ row_class, int act,
-                                                           float* __restrict__ y, int ystride, int yperm)
+                                                           float* __restrict__ y, int ystride, int yperm, int form)
 {
     const int j = blockIdx.x, lane = threadIdx.x;
     const size_t n = blockIdx.y;
     const float* wr = w + (size_t)j * K;
     const float* xv = x + n * xstride;
     auto X = [&](int k) { return xv[rgbd_cperm(k, xperm)]; };
-    const int cls = row_class ? row_class[j] : 0;
+    const int cls = form >= 0 ? form : (row_class ? row_class[j] : 0);
     float out;
-    if (cls == 0) {
+    if (cls == 3) {
+        if (K < 48) {
+            float acc = 0.f;
+            if (lane == 0)
+                for (int k = 0; k < K; ++k) acc = __fmaf_rn(wr[k], X(k), acc);
+            out = acc;
+        } else {
+            const int nb = K / 16, nt = K % 16;
+            float acc = 0.f;
+            if (lane < 16) {
+                for (int v = 0; v < nb; ++v) acc = __fmaf_rn(wr[v * 16 + lane], X(v * 16 + lane), acc);
+                if (lane < nt) acc = __fmaf_rn(wr[nb * 16 + lane], X(nb * 16 + lane), acc);
+            }
+            const float a4 = __shfl_down(acc, 4, 64), a8 = __shfl_down(acc, 8, 64), a12 = __shfl_down(acc, 12, 64);
+            const float q = __fadd_rn(__fadd_rn(__fadd_rn(acc, a4), a8), a12);  // lanes 0..3: q_i
+            const float h = __fadd_rn(q, __shfl_down(q, 1, 64));                // lanes 0, 2: q_0 + q_1, q_2 + q_3
+            out = __fadd_rn(h, __shfl_down(h, 2, 64));
+        }
+    } else if (cls == 0) {
         const int nb = (K - 1) / 16, nt = (K - 1) % 16;
         float acc = 0.f;
         if (lane == 0) acc = __fmul_rn(wr[0], X(0));
@@ -583,13 +605,13 @@ __global__ __launch_bounds__(64) void se_linear_ref_kernel(const float* __restri
 }
 
 int launch_se_fc_ref(const float* mean, int N, int C, int hidden, const float* w0, const float* w1, const int* cls0,
-                     const int* cls1, float* hid, float* scale, hipStream_t s, int mstride)
+                     const int* cls1, float* hid, float* scale, hipStream_t s, int mstride, int form)
 {
     // fc.0: [hidden][C] on the means (by position) -> ReLU -> hid[n][hidden];  fc.2: [C][hidden] (NOT transposed) -> sigmoid
     hipLaunchKernelGGL(se_linear_ref_kernel, dim3(hidden, N), dim3(64), 0, s, w0, mean, C, hidden, mstride > 0 ? mstride : C, 1,
-                       cls0, ACT_RELU, hid, hidden, 0);
+                       cls0, ACT_RELU, hid, hidden, 0, form);
     hipLaunchKernelGGL(se_linear_ref_kernel, dim3(C, N), dim3(64), 0, s, w1, hid, hidden, C, hidden, 0, cls1, ACT_SIGMOID, scale,
-                       C, 1);
+                       C, 1, form);
     HIP_TRY(hipGetLastError());
     return RGBD_OK;
 }

@@ -428,6 +428,35 @@ void orc_linear_b1(const float* W, const float* x, int J, int K, const int* row_
     }
 }
 
+/* ---- y = x W^T for a batch of TWO vectors (nn.Linear, bias-free: MKL sgemm with n = 2; measured like the batch-1 classes: lane
+ * membership with the absorbing probe, the reduction tree with +BIG / -BIG / 1 triples): every output, both batch rows alike --
+ *   K < 48:  one k-ordered fma chain from 0;
+ *   else:    lane l of ONE 16-lane accumulator takes elements 16 v + l, the K % 16 tail as one more (masked) fma step; then
+ *            q_i = ((a_i + a_{i+4}) + a_{i+8}) + a_{i+12} for i = 0..3, and (q_0 + q_1) + (q_2 + q_3).
+ * Batches of 3 and more follow other forms (not measured: no reference golden has them). */
+float orc_dot_b2(const float* w, const float* x, int K)
+{
+    if (K < 48) {
+        float s = 0.f;
+        for (int k = 0; k < K; k++) s = fmaf(w[k], x[k], s);
+        return s;
+    }
+    float a[16];
+    memset(a, 0, sizeof(a));
+    const int nb = K / 16;
+    for (int v = 0; v < nb; v++)
+        for (int l = 0; l < 16; l++) a[l] = fmaf(w[16 * v + l], x[16 * v + l], a[l]);
+    for (int l = 0; l < K - 16 * nb; l++) a[l] = fmaf(w[16 * nb + l], x[16 * nb + l], a[l]);
+    float q[4];
+    for (int i = 0; i < 4; i++) q[i] = ((a[i] + a[i + 4]) + a[i + 8]) + a[i + 12];
+    return (q[0] + q[1]) + (q[2] + q[3]);
+}
+void orc_linear_b2(const float* W, const float* x, int J, int K, float* y)
+{
+    for (int b = 0; b < 2; b++)
+        for (int j = 0; j < J; j++) y[(size_t)b * J + j] = orc_dot_b2(W + (size_t)j * K, x + (size_t)b * K, K);
+}
+
 /* ---- conv_transpose2d, stride 2, kernel k, padding k/2, output_padding 1 (oneDNN brg_deconv + brgconv_strided) ----------------
  * w [C][O][k][k].  Output pixel (oy, ox) of phase (py, px) = (oy & 1, ox & 1) gathers the taps with (oy + pad - ky) even and
  * (ox + pad - kx) even.  The taps are accumulated in CHAINS: inside a chain every tap continues the fma chain of the previous

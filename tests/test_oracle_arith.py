@@ -128,6 +128,23 @@ def test_sigmoid_of_a_whole_tensor_scalar_tails_included(shape):
     assert np.array_equal(ca.sigmoid(x.numpy())[~tail], ref[~tail])
 
 
+def test_linear_on_a_batch_of_two():
+    """nn.Linear(bias=False) on [2, K] (the SE blocks of a reference call on a batch of two images): orc_linear_b2 == torch for
+    every SE shape of the models, and for K on both sides of the 48-element switch."""
+    L = ca.lib()
+    shapes = [(K, J) for K, J, _ in TABLES["linear"]] + [(44, 64), (45, 64), (47, 64), (48, 64), (49, 64)]
+    torch.set_num_threads(8)
+    for K, J in shapes:
+        g = torch.Generator().manual_seed(K * 3 + J)
+        W = (torch.randn(J, K, generator=g) / K ** 0.5).contiguous()
+        x = torch.randn(2, K, generator=g).contiguous()
+        ref = F.linear(x, W).numpy()
+        y = np.empty((2, J), np.float32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        L.orc_linear_b2(P(W.numpy()), P(x.numpy()), J, K, P(y))
+        assert np.array_equal(y, ref), (K, J, int((y != ref).sum()))
+
+
 def test_libm_expf_restatement():
     """orc_expf_libm (glibc's table-driven expf, the scalar path's exp) against this container's C library"""
     L = ca.lib()
