@@ -137,7 +137,7 @@ def parity_state():
         with open(os.path.join(ROOT, "tests", "golden", "parity_floors.json")) as f:
             sm = json.load(f)["_summary"]
         return {k: sm[k] for k in ("goldens_identical", "of", "bpp_identical", "dpsnr_within_1e-4", "max_dbpp", "max_dpsnr",
-                                   "operating_point") if k in sm}
+                                   "operating_point", "forced_context") if k in sm}
     except (OSError, KeyError, ValueError):
         return None
 
