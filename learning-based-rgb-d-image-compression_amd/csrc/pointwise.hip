@@ -736,7 +736,10 @@ __global__ void sigmoid_gate_ref_kernel(const float* __restrict__ t, int tcs, co
         const int sc = (int)(i % C16);       // stored channel
         const size_t pix = i / C16;          // n * HW + hw
         const int c = rgbd_cperm(sc);        // logical channel (the permutation is an involution)
-        if (c >= C) continue;
+        if (c >= C) {                        // pad channels hold zeros
+            y[pix * ycs + sc] = 0.f;
+            continue;
+        }
         const long n = (long)(pix / HW), hw = (long)(pix % HW);
         const long flat = ((per_image ? 0 : n) * C + c) * HW + hw;
         const float v = t[pix * tcs + sc];

@@ -205,6 +205,11 @@ def main():
         united_case(ELIC, model_config, synth, "g_256x256_s1", 1, 256, 256, 2, seed=1, new=True)
     if on("h_256x256_s2"):
         united_case(ELIC, model_config, synth, "h_256x256_s2", 1, 256, 256, 2, seed=2, new=True)
+    # round 5: a HELD-OUT case -- an image size (192x256) and a weight seed (3) no table entry, kernel or test had seen when the
+    # reference-arithmetic path was written; its layer shapes were then measured with `tools/refarith/discover.py --add
+    # united:192:256:1` and nothing else changed.  (Named explicitly only: not part of the default run.)
+    if "j_192x256_s3" in want:
+        united_case(ELIC, model_config, synth, "j_192x256_s3", 1, 192, 256, 12, seed=3, new=True)
     if on("i_128x192_hr"):  # the high_rate weights (wide CDF rows); golden from make_golden.py --only-hr
         united_case(ELIC, model_config, synth, "i_128x192_hr", 1, 128, 192, 41, recipe="high_rate")
     if on("bicee_c4_b2_8x12"):

@@ -287,9 +287,11 @@ def test_elic_united_vs_reference_golden(net, gc, name):
     _vs_golden(net, gc, name)
 
 
-@pytest.mark.parametrize("name,seed", [("g_256x256_s1", 1), ("h_256x256_s2", 2)])
+@pytest.mark.parametrize("name,seed", [("g_256x256_s1", 1), ("h_256x256_s2", 2), ("j_192x256_s3", 3)])
 def test_elic_united_other_weight_seeds_vs_reference_golden(gc, name, seed):
-    """The flip census seeds (profiles/r02_flip_census.json was against the box's oracle) against the reference itself."""
+    """The flip census seeds (profiles/r02_flip_census.json was against the box's oracle) against the reference itself.
+    j_192x256_s3 (round 5) is the HELD-OUT case: an image size and a weight seed nothing had seen when the reference-arithmetic
+    path was written; only its layer shapes were measured afterwards (tools/refarith/discover.py --add united:192:256:1)."""
     from rgbd_amd import synth
 
     require_gpu()

@@ -10,7 +10,10 @@ accumulator) survives.  The output then tells how many terms follow the probed t
 probe over the input channels gives the chains ("blocks") and their order.  oracle/cpu_arith.c executes the structures found,
 and tests/test_oracle_arith.py checks them against torch bit for bit on random data.
 
-usage: python tools/refarith/discover.py            (all golden / bench shapes; ~10 min)
+usage: python tools/refarith/discover.py                       (all golden / bench shapes; ~10 min)
+       python tools/refarith/discover.py --add united:H:W:B ...   (measure the layer shapes of further image sizes -- kind is
+                                                                   united / single / r2d -- and MERGE them into the committed
+                                                                   tables: what a user of another image size runs once)
 """
 import json
 import os
@@ -309,6 +312,24 @@ def main():
                     "note": "measured by tools/refarith/discover.py on the machine that produced tests/golden/"},
            "conv1x1": [], "im2col": [], "deconv_s2": []}
     seen1, seen2, seen3 = set(), set(), set()
+    old = None
+    if "--add" in sys.argv:  # only the named image sizes, merged into what is committed
+        jobs = []
+        for a in sys.argv[sys.argv.index("--add") + 1:]:
+            if a.startswith("--"):
+                break
+            kind, H, W, B = a.split(":")
+            jobs.append((kind, int(H), int(W), int(B)))
+        with open(OUT) as f:
+            old = json.load(f)
+        if old["meta"].get("threads") != torch.get_num_threads():
+            raise SystemExit(f"the committed tables were measured with {old['meta'].get('threads')} threads, this process has "
+                             f"{torch.get_num_threads()}: the CPU kernels block differently, do not mix")
+        tab["meta"] = old["meta"]
+        tab["conv1x1"], tab["im2col"], tab["deconv_s2"] = list(old["conv1x1"]), list(old["im2col"]), list(old.get("deconv_s2", []))
+        seen1 = {tuple(e[:5]) for e in tab["conv1x1"]}
+        seen2 = {tuple(e[:7]) for e in tab["im2col"]}
+        seen3 = {tuple(e[:6]) for e in tab["deconv_s2"]}
     for kind, H, W, B in jobs:
         try:
             shapes = collect_shapes(kind, H, W, B)
@@ -359,6 +380,8 @@ def main():
             else:
                 rle += [c, 1]
         tab["linear"].append([K, J, rle])
+    if old is not None:  # (--add: the SE shapes do not depend on the image size)
+        tab["linear"] = old["linear"]
     print(len(tab["linear"]), "linear entries", flush=True)
     with open(OUT, "w") as f:
         f.write("{\n")
