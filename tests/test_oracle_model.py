@@ -69,6 +69,15 @@ def test_streams_other_cases(codec, name):
     _streams_case(codec, name)
 
 
+def test_streams_held_out_case():
+    """j_192x256_s3 (round 5): image size and weight seed chosen after the fact (tests/golden/make_margins.py)"""
+    from rgbd_amd import synth
+
+    c = eo.OracleCodec(synth.synthetic_state_dict(3))
+    assert c.update()
+    _streams_case(c, "j_192x256_s3")
+
+
 def _streams_case(codec, name):
     g = load_golden(name)
     r, d, rp, dp = _inputs(g)
