@@ -287,15 +287,18 @@ def test_elic_united_vs_reference_golden(net, gc, name):
     _vs_golden(net, gc, name)
 
 
-@pytest.mark.parametrize("name,seed", [("g_256x256_s1", 1), ("h_256x256_s2", 2), ("j_192x256_s3", 3)])
-def test_elic_united_other_weight_seeds_vs_reference_golden(gc, name, seed):
+@pytest.mark.parametrize("name,seed,recipe", [("g_256x256_s1", 1, None), ("h_256x256_s2", 2, None), ("j_192x256_s3", 3, None),
+                                              ("k_200x300_tl_s4", 4, "trained_like")])
+def test_elic_united_other_weight_seeds_vs_reference_golden(gc, name, seed, recipe):
     """The flip census seeds (profiles/r02_flip_census.json was against the box's oracle) against the reference itself.
-    j_192x256_s3 (round 5) is the HELD-OUT case: an image size and a weight seed nothing had seen when the reference-arithmetic
-    path was written; only its layer shapes were measured afterwards (tools/refarith/discover.py --add united:192:256:1)."""
+    j_192x256_s3 and k_200x300_tl_s4 (round 5) are HELD-OUT cases: image sizes (the second one needs padding, -> 256 x 320, and
+    runs the trained-like weights) and weight seeds nothing had seen when the reference-arithmetic path was written; only their
+    layer shapes were measured afterwards (tools/refarith/discover.py --add united:H:W:1)."""
     from rgbd_amd import synth
 
     require_gpu()
-    _vs_golden(_model("ELIC_united", synth.synthetic_state_dict(seed)), gc, name)
+    sd = synth.synthetic_state_dict(seed) if recipe is None else synth.synthetic_state_dict(seed, recipe=recipe)
+    _vs_golden(_model("ELIC_united", sd), gc, name)
 
 
 def _vs_golden(net, gc, name):
