@@ -210,6 +210,8 @@ def main():
     # united:192:256:1` and nothing else changed.  (Named explicitly only: not part of the default run.)
     if "j_192x256_s3" in want:
         united_case(ELIC, model_config, synth, "j_192x256_s3", 1, 192, 256, 12, seed=3, new=True)
+    if "l_b2_192x256_s5" in want:  # third held-out case: the reference's batched calling convention (one stream per batch of two)
+        united_case(ELIC, model_config, synth, "l_b2_192x256_s5", 2, 192, 256, 14, seed=5, new=True)
     if "k_200x300_tl_s4" in want:  # a second held-out case: a size that needs padding (-> 256 x 320), trained-like weights, seed 4
         united_case(ELIC, model_config, synth, "k_200x300_tl_s4", 1, 200, 300, 13, seed=4, recipe="trained_like", new=True)
     if on("i_128x192_hr"):  # the high_rate weights (wide CDF rows); golden from make_golden.py --only-hr
