@@ -288,6 +288,10 @@ int rgbd_debug_force_ckbd(int32_t part); /* rgbd_conv2d_nchw / rgbd_conv_bench: 
 int rgbd_debug_conv_log(int32_t on);                      /* record the shape of every conv launch (tools/tune_tiles.py) */
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap); /* CSV text of the recorded shapes; returns the size needed */
 int rgbd_debug_force_tile(const char* cfg); /* "wm,mt,nt,kc,dma" or "" = automatic (tools/tile_sweep.py) */
+/* In-situ tuning (tools/tune_insitu.py): tile / staging form per layer-shape key, lines of
+ * "N,H,W,cin_pad,cout_pad,ntaps,stride,nphase,splitk,wm,mt,nt,kc,dma"; "" clears.  rgbd_elic_set_profile(m, 2) makes the profile's
+ * layer names carry the shape key of every launch, so one codec call times every layer under its candidate. */
+int rgbd_debug_tile_override(const char* csv);
 
 /* The pointwise operators of Bi-SPF / ESA / SE_Block alone (test hook; NCHW device tensors in and out, host weights):
  * op 0 = F.max_pool2d(kernel 7, stride 3) (attention.py:87), 1 = F.interpolate(bilinear, align_corners=False) to (oh, ow)

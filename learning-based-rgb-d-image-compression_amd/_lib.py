@@ -146,6 +146,7 @@ def lib():
         "rgbd_debug_force_tile": (ctypes.c_int, [ctypes.c_char_p]),
         "rgbd_debug_conv_log": (ctypes.c_int, [c_i32]),
         "rgbd_debug_conv_log_read": (c_i64, [ctypes.c_char_p, c_i64]),
+        "rgbd_debug_tile_override": (ctypes.c_int, [ctypes.c_char_p]),
         "rgbd_conv_bench": (ctypes.c_int, [c_i32] * 11 + [f32p]),
         "rgbd_elic_profile_dump": (ctypes.c_int, [c_vp, ctypes.c_char_p]),
         "rgbd_elic_profile_read": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), i64p,
@@ -166,7 +167,7 @@ EXPORTS = ["rgbd_abi_version", "rgbd_set_blocking_sync", "rgbd_get_blocking_sync
            "rgbd_elic_destroy", "rgbd_elic_set_ref_blocks", "rgbd_elic_get_refnum", "rgbd_elic_ref_table_misses", "rgbd_elic_clone_shared", "rgbd_elic_set_tensor", "rgbd_elic_set_tables", "rgbd_elic_set_scale_table",
            "rgbd_elic_finalize", "rgbd_elic_compress", "rgbd_elic_forward", "rgbd_elic_stream_count", "rgbd_elic_stream",
            "rgbd_elic_decompress", "rgbd_elic_create_r2d", "rgbd_elic_create_stf", "rgbd_elic_create_single", "rgbd_elic_compress_single", "rgbd_elic_decompress_single", "rgbd_elic_forward_single", "rgbd_elic_compress_united", "rgbd_elic_decompress_united", "rgbd_elic_debug_tensor", "rgbd_elic_debug_symbols", "rgbd_elic_set_debug_floats", "rgbd_elic_debug_floats", "rgbd_elic_set_forced_symbols", "rgbd_elic_set_profile", "rgbd_elic_graph_count", "rgbd_elic_workspace_bytes", "rgbd_msssim_workspace_bytes", "rgbd_msssim_stats", "rgbd_layernorm", "rgbd_debug_force_layernorm_form",
-           "rgbd_elic_profile_read", "rgbd_elic_profile_read_executed", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_force_blocked", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_conv_bench",
+           "rgbd_elic_profile_read", "rgbd_elic_profile_read_executed", "rgbd_debug_force_splitk", "rgbd_debug_force_fuse", "rgbd_debug_force_subpix", "rgbd_debug_force_pair", "rgbd_debug_fail_captures", "rgbd_debug_force_ckbd", "rgbd_debug_force_blocked", "rgbd_debug_bench_streams", "rgbd_elic_set_tile_mode", "rgbd_debug_force_tile", "rgbd_debug_conv_log", "rgbd_debug_conv_log_read", "rgbd_debug_tile_override", "rgbd_conv_bench",
            "rgbd_elic_profile_dump"]
 
 

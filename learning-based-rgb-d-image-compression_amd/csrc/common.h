@@ -170,7 +170,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 // (1 / 2 / 4 = 64 / 128 / 256 pixels per workgroup) or 0 when this pair of layers on this grid is not worth fusing.
 int conv_fused_plan(int cout_pad, int cout2_pad, int ntaps, int N, int GH, int GW, int loaded);
 int launch_conv_fused(const ConvArgs& a, hipStream_t s);
-int conv_log_enable(int on);            // shape log for tools/tune_tiles.py
+int conv_log_enable(int on);
+int conv_tile_override(const char* csv);  // in-situ tile overrides by shape key (tools/tune_insitu.py); nullptr / "" clears
 long conv_log_read(char* buf, long cap);  // CSV text; returns the size needed
 
 // y = mul * sigmoid(t) + res2 with the reference's per-element choice of sigmoid form (vector / scalar tail of torch's CPU loop)

@@ -12,6 +12,10 @@
 // Numerics: every output element is one k-ordered fp32 fma chain (MFMA f32 semantics) whose order depends only on
 // the layer (chunk -> tap -> channel), never on tiling or batch size: results are run-to-run, batch- and
 // tile-invariant, which the entropy decoder relies on to reproduce the encoder's means/scales bit for bit.
+#include <array>
+#include <map>
+#include <string>
+
 #include "conv_mfma_body.h"
 
 // conv_mfma_blk.hip: the blocked-accumulation instantiations (ConvArgs::blocked)
@@ -262,6 +266,33 @@ long conv_log_read(char* buf, long cap)
     return (long)out.size() + 1;
 }
 
+// in-situ tile overrides (tools/tune_insitu.py): shape key (as in the conv log) -> tile / staging form.  Consulted before the
+// tables; a pure speed matter like every tile choice.  Lines "N,H,W,cin_pad,cout_pad,ntaps,stride,nphase,splitk,wm,mt,nt,kc,dma".
+static std::map<std::string, std::array<int, 5>> g_ovr;
+int conv_tile_override(const char* csv)
+{
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    g_ovr.clear();
+    if (!csv) return RGBD_OK;
+    const char* p = csv;
+    while (*p) {
+        int v[14], n = 0, used = 0;
+        while (n < 14 && sscanf(p, "%d%n", &v[n], &used) == 1) {
+            p += used;
+            ++n;
+            if (*p == ',') ++p;
+            else break;
+        }
+        while (*p && *p != '\n') ++p;
+        if (*p == '\n') ++p;
+        if (n != 14) return RGBD_EINVAL;
+        char key[160];
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
+        g_ovr[key] = {v[9], v[10], v[11], v[12], v[13]};
+    }
+    return RGBD_OK;
+}
+
 int launch_conv(const ConvArgs& a_in, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -325,6 +356,20 @@ static int launch_conv_main(const ConvArgs& a, hipStream_t s)
                  a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd + (a.blocked ? 100 : 0), a.splitk);
         std::lock_guard<std::mutex> lk(g_log_mu);
         ++g_log[key];
+    }
+    if (!g_ovr.empty()) {
+        char key[160];
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%d,%d", a.N * (a.groups == 2 ? 2 : 1), a.H, a.W, a.cin_pad, a.cout_pad, a.ntaps_total,
+                 a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd + (a.blocked ? 100 : 0), a.splitk);
+        std::lock_guard<std::mutex> lk(g_log_mu);
+        auto it = g_ovr.find(key);
+        if (it != g_ovr.end()) {
+            c.wm = it->second[0];
+            c.mt = it->second[1];
+            c.nt = it->second[2];
+            set_mode(c, it->second[3], it->second[4]);
+            c.tw_log2 = pick_tw_log2(a.ckbd ? (a.GW + 1) / 2 : a.GW, a.GH, 16 * c.nt * (c.wm == 2 ? 2 : 4));
+        }
     }
     static const char* force_env = getenv("RGBD_CONV_FORCE");  // "wm,mt,nt[,kc[,dma]]" -- tuning experiments only
     const char* force = g_conv_force[0] ? g_conv_force : force_env;

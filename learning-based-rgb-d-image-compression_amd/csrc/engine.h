@@ -439,6 +439,7 @@ struct rgbd_elic {
 
     // conv-kernel profiling (bench.py roofline): HIP event pairs around every conv launch on the launch stream
     bool profile = false;
+    bool profile_keys = false;  // rgbd_elic_set_profile(m, 2): the recorded layer names carry the launch's shape key (tools/tune_insitu.py)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct EvName {
@@ -1071,7 +1072,15 @@ struct rgbd_elic {
             prof_flops += fl;
             prof_flops_exec += fx;
             ++prof_launches;
-            ev_names.push_back({p.name, fl, fx});
+            if (profile_keys) {
+                char key[200];
+                snprintf(key, sizeof(key), "|%d,%d,%d,%d,%d,%d,%d,%d,%d|%d", a.N * (a.groups == 2 ? 2 : 1), a.H, a.W, a.cin_pad, a.cout_pad,
+                         a.ntaps_total, a.nphase > 1 ? a.OS : a.IS, a.nphase + 10 * a.ckbd + (a.blocked ? 100 : 0),
+                         std::max(1, std::min(a.splitk, a.cin_pad / 16)), p.fused ? 1 : 0);
+                ev_names.push_back({p.name + key, fl, fx});
+            } else {
+                ev_names.push_back({p.name, fl, fx});
+            }
         }
         arena.top = pmark;  // stream order protects the scratch: later kernels of this stream run after the reducer
         if (r) {

@@ -296,6 +296,12 @@ int rgbd_debug_force_tile(const char* cfg)
     return RGBD_OK;
 }
 
+int rgbd_debug_tile_override(const char* csv)
+{
+    ++g_cfg_epoch;  // cached HIP graphs have the old kernel choices baked in
+    return conv_tile_override(csv);
+}
+
 int rgbd_debug_conv_log(int32_t on) { return conv_log_enable(on); }
 int64_t rgbd_debug_conv_log_read(char* buf, int64_t cap) { return conv_log_read(buf, (long)cap); }
 
@@ -997,6 +1003,7 @@ int rgbd_elic_set_profile(rgbd_elic* m, int32_t on)
 {
     if (!m) return RGBD_EINVAL;
     m->profile = on != 0;
+    m->profile_keys = on == 2;
     m->ev_used = 0;
     m->prof_flops = 0.0;
     m->prof_flops_exec = 0.0;
