@@ -8,7 +8,8 @@ around every conv launch of one engine instance, rgbd_elic_set_profile(m, 2): na
 time under that candidate, so ~25 passes cover 25 candidates for all shapes at once.  Candidates are filtered first by one
 kernel-only launch (rgbd_conv_bench) so that a pass never meets a form a shape cannot take.  Tile choice never changes a result.
 
-    python tools/tune_insitu.py [--write] B H W        (default 16 512 640; writes gpurun_out/insitu_*.h, --write: csrc/)
+    python tools/tune_insitu.py [--write] [--latency] B H W   (default 16 512 640; writes gpurun_out/insitu_*.h, --write: csrc/;
+                                                             --latency: the tables a lone engine instance uses, tile_table[_blk].h)
 """
 import collections
 import ctypes
@@ -26,6 +27,7 @@ from rgbd_amd._lib import lib  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B, H, W = (int(v) for v in args[:3]) if len(args) >= 3 else (16, 512, 640)
 WRITE = "--write" in sys.argv
+LATENCY = "--latency" in sys.argv
 REPS = 3
 L = lib()
 net = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
@@ -33,7 +35,7 @@ net.load_state_dict(synth.synthetic_state_dict(0))
 net.update(force=True)
 net = net.to("cuda")
 net.per_image_streams = True
-net.set_tile_mode("throughput")
+net.set_tile_mode("latency" if LATENCY else "throughput")
 r, d = synth.synthetic_batch(B, H, W, config_id=2)
 rgb, depth = torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda()
 
@@ -131,7 +133,7 @@ for ks in sorted(keep, key=lambda k: -base[k]):
     print(f"  {ks}: {min(base[ks], base2.get(ks, 1e30))*1e3:9.1f} us -> {conf.get(ks, 0)*1e3:9.1f} us  {keep[ks]}")
 out_dir = os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc") if WRITE else os.path.join(ROOT, "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
-for blocked, fname in ((True, "tile_table_blk_loaded.h"), (False, "tile_table_loaded.h")):
+for blocked, fname in ((True, "tile_table_blk.h" if LATENCY else "tile_table_blk_loaded.h"), (False, "tile_table.h" if LATENCY else "tile_table_loaded.h")):
     src = os.path.join(ROOT, "learning-based-rgb-d-image-compression_amd", "csrc", fname)
     table, head = {}, []
     for ln in open(src):
