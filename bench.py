@@ -440,6 +440,8 @@ def main():
 
     prof1 = conv_pass(tile_mode)
     prof_lat = prof1 if tile_mode == "latency" else conv_pass("latency")
+    if os.environ.get("RGBD_BENCH_DEBUG"):
+        print("[bench] conv passes:", tile_mode, prof1, "| latency", prof_lat, file=sys.stderr)
     solo.set_tile_mode(tile_mode)
     flops_step = prof1["flops"] / 2.0 / G        # (the pass runs two calls of G steps each)
     launches_call = prof1["launches"] // 2
