@@ -361,3 +361,13 @@ def test_hw_queue_count_outside_the_tested_range_is_refused():
         check_hw_queues({"GPU_MAX_HW_QUEUES": "64"})
     with pytest.raises(ValueError, match="not an integer"):
         check_hw_queues({"GPU_MAX_HW_QUEUES": "many"})
+
+
+def test_tile_override_csv_is_parsed_on_the_host():
+    """rgbd_debug_tile_override (tools/tune_insitu.py): 14 integers per line, "" clears; a short line is refused.  Pure host code."""
+    from rgbd_amd._lib import lib
+
+    L = lib()
+    assert L.rgbd_debug_tile_override(b"16,32,40,192,384,25,1,101,1,2,2,8,16,1\n32,256,320,192,192,9,1,101,1,1,3,4,16,1") == 0
+    assert L.rgbd_debug_tile_override(b"16,32,40,192,384,25,1,101,1,2,2,8") == -22
+    assert L.rgbd_debug_tile_override(b"") == 0
