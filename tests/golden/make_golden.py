@@ -119,10 +119,10 @@ def container(H, W, shape, strings) -> bytes:
     return f.getvalue()
 
 
-def model_case(net, synth, name, B, H, W, config_id, full: bool):
+def model_case(net, synth, name, B, H, W, config_id, full: bool, smooth: bool = False):
     from dataset.utils import crop0, pad  # reference harness pieces that import cleanly
 
-    r, d = synth.synthetic_batch(B, H, W, config_id=config_id)
+    r, d = synth.synthetic_batch(B, H, W, config_id=config_id, smooth=smooth)
     r, d = torch.from_numpy(r), torch.from_numpy(d)
     rp, dp = pad(r, "replicate0"), pad(d, "replicate0")
     with torch.no_grad():
@@ -131,6 +131,8 @@ def model_case(net, synth, name, B, H, W, config_id, full: bool):
     xr, xd = crop0(dec["x_hat"]["r"], (H, W)), crop0(dec["x_hat"]["d"], (H, W))
     g = {"B": B, "H": H, "W": W, "config_id": config_id, "shape": np.array(tuple(out["shape"]), np.int32),
          "padded": np.array(rp.shape[-2:], np.int32)}
+    if smooth:
+        g["smooth"] = 1  # spatially correlated inputs (synth.synthetic_pair(smooth=True)) instead of uniform noise
     for m, key in (("r", "r_strings"), ("d", "d_strings")):
         g[f"{m}_y"] = np.frombuffer(out[key][0][0], np.uint8)
         for i, s in enumerate(out[key][1]):

@@ -130,7 +130,7 @@ def same_streams(path, pairs):
                              "(another CPU / oneDNN path than the one that made the golden): not rewriting anything")
 
 
-def united_case(ELIC, model_config, synth, name, B, H, W, cid, seed=0, recipe=None, new=False):
+def united_case(ELIC, model_config, synth, name, B, H, W, cid, seed=0, recipe=None, new=False, smooth=False):
     from dataset.utils import pad
 
     net = ELIC(config=model_config(), channel=4).eval()
@@ -138,9 +138,9 @@ def united_case(ELIC, model_config, synth, name, B, H, W, cid, seed=0, recipe=No
     net.load_state_dict(sd)
     assert net.update(force=True)
     if new:
-        mg.model_case(net, synth, name, B, H, W, cid, False)
+        mg.model_case(net, synth, name, B, H, W, cid, False, smooth=smooth)
     obs = observe(net, {"r": "rgb_", "d": "depth_"})
-    r, d = synth.synthetic_batch(B, H, W, config_id=cid)
+    r, d = synth.synthetic_batch(B, H, W, config_id=cid, smooth=smooth)
     rp, dp = pad(torch.from_numpy(r), "replicate0"), pad(torch.from_numpy(d), "replicate0")
     out = run(obs, lambda: net.compress(rp, dp))
     same_streams(os.path.join(HERE, f"model_{name}.npz"), [("r_y", out["r_strings"][0][0]), ("d_y", out["d_strings"][0][0]),
@@ -212,6 +212,8 @@ def main():
         united_case(ELIC, model_config, synth, "j_192x256_s3", 1, 192, 256, 12, seed=3, new=True)
     if "l_b2_192x256_s5" in want:  # third held-out case: the reference's batched calling convention (one stream per batch of two)
         united_case(ELIC, model_config, synth, "l_b2_192x256_s5", 2, 192, 256, 14, seed=5, new=True)
+    if "m_256x320_smooth_s7" in want:  # fourth held-out case: spatially correlated images (every other golden codes uniform noise)
+        united_case(ELIC, model_config, synth, "m_256x320_smooth_s7", 1, 256, 320, 15, seed=7, new=True, smooth=True)
     if "k_200x300_tl_s4" in want:  # a second held-out case: a size that needs padding (-> 256 x 320), trained-like weights, seed 4
         united_case(ELIC, model_config, synth, "k_200x300_tl_s4", 1, 200, 300, 13, seed=4, recipe="trained_like", new=True)
     if on("i_128x192_hr"):  # the high_rate weights (wide CDF rows); golden from make_golden.py --only-hr

@@ -248,10 +248,10 @@ def _symbols(m, mods=2):
     return gsym, gidx
 
 
-def _pad_inputs(B, H, W, cid):
+def _pad_inputs(B, H, W, cid, smooth=False):
     from rgbd_amd import synth
 
-    r, d = synth.synthetic_batch(B, H, W, config_id=cid)
+    r, d = synth.synthetic_batch(B, H, W, config_id=cid, smooth=smooth)
     r, d = torch.from_numpy(r), torch.from_numpy(d)
     return r, d, eo.pad_replicate0(r), eo.pad_replicate0(d)
 
@@ -288,13 +288,15 @@ def test_elic_united_vs_reference_golden(net, gc, name):
 
 
 @pytest.mark.parametrize("name,seed,recipe", [("g_256x256_s1", 1, None), ("h_256x256_s2", 2, None), ("j_192x256_s3", 3, None),
-                                              ("k_200x300_tl_s4", 4, "trained_like"), ("l_b2_192x256_s5", 5, None)])
+                                              ("k_200x300_tl_s4", 4, "trained_like"), ("l_b2_192x256_s5", 5, None),
+                                              ("m_256x320_smooth_s7", 7, None)])
 def test_elic_united_other_weight_seeds_vs_reference_golden(gc, name, seed, recipe):
     """The flip census seeds (profiles/r02_flip_census.json was against the box's oracle) against the reference itself.
     j_192x256_s3 and k_200x300_tl_s4 (round 5) are HELD-OUT cases: image sizes (the second one needs padding, -> 256 x 320, and
     runs the trained-like weights) and weight seeds nothing had seen when the reference-arithmetic path was written; only their
     layer shapes were measured afterwards (tools/refarith/discover.py --add united:H:W:B).  l_b2_192x256_s5 is the reference's
-    batched calling convention (one stream per batch of two) at a held-out size and seed."""
+    batched calling convention (one stream per batch of two) at a held-out size and seed; m_256x320_smooth_s7 codes spatially
+    correlated images (every other golden codes uniform noise)."""
     from rgbd_amd import synth
 
     require_gpu()
@@ -305,7 +307,7 @@ def test_elic_united_other_weight_seeds_vs_reference_golden(gc, name, seed, reci
 def _vs_golden(net, gc, name):
     g = load_golden(name)
     B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
-    r, d, rp, dp = _pad_inputs(B, H, W, int(g["config_id"]))
+    r, d, rp, dp = _pad_inputs(B, H, W, int(g["config_id"]), smooth="smooth" in g)
     net.per_image_streams = False  # the reference's format (one y-stream per modality for the batch)
     net.set_debug_floats(True)
     try:
