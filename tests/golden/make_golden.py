@@ -184,10 +184,10 @@ def bicee_case(net, synth, name, B, h, w, seed):
     return g
 
 
-def elic_single_case(ext, model_config, synth, name, B, H, W, config_id):
+def elic_single_case(ext, model_config, synth, name, B, H, W, config_id, seed=0):
     """BASELINE config 1: the reference's single-modal ELIC (models/elic.py) compress()/decompress() on one RGB image."""
     net = ext["ELIC"](config=model_config(), channel=3).eval()
-    net.load_state_dict(synth.synthetic_state_dict(0, model="ELIC"))
+    net.load_state_dict(synth.synthetic_state_dict(seed, model="ELIC"))
     assert net.update(force=True)
     r, _ = synth.synthetic_batch(B, H, W, config_id=config_id)
     x = torch.from_numpy(r)
@@ -304,6 +304,9 @@ def main():
         net.load_state_dict(synth.synthetic_state_dict(0, recipe="high_rate"))
         assert net.update(force=True)
         model_case(net, synth, "i_128x192_hr", 1, 128, 192, 41, False)
+        return
+    if "--only-single-heldout" in sys.argv:  # round 5: a held-out single-modal case (new size, new seed; see make_margins.py j_ / k_ / l_ / m_)
+        elic_single_case(ext, model_config, synth, "n_192x256_s8", 1, 192, 256, 16, seed=8)
         return
     if "--only-e" in sys.argv:  # the bench's image shape (480x640 -> 512x640) with the trained-like weights (~3.6 bpp)
         net = ELIC(config=model_config(), channel=4).eval()

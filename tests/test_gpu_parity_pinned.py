@@ -394,29 +394,33 @@ def test_r2d_vs_reference_golden(gc):
     _check("r2d_128x192", **vals)
 
 
-def test_elic_single_vs_reference_golden(gc):
+@pytest.mark.parametrize("case,seed", [("c1_256x256", 0), ("n_192x256_s8", 8)])
+def test_elic_single_vs_reference_golden(gc, case, seed):
+    """c1_256x256: BASELINE config 1.  n_192x256_s8 (round 5): a held-out single-modal case -- image size and weight seed chosen after
+    the fact, its layer shapes measured with tools/refarith/discover.py --add single:192:256:1."""
     from rgbd_amd import synth
 
     require_gpu()
-    m = _model("ELIC", synth.synthetic_state_dict(0, model="ELIC"))
-    g = np.load(os.path.join(GOLDEN, "elic_c1_256x256.npz"))
-    r, _ = synth.synthetic_batch(1, 256, 256, config_id=int(g["config_id"]))
+    m = _model("ELIC", synth.synthetic_state_dict(seed, model="ELIC"))
+    g = np.load(os.path.join(GOLDEN, f"elic_{case}.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    r, _ = synth.synthetic_batch(1, H, W, config_id=int(g["config_id"]))
     x = torch.from_numpy(r)
     m.set_debug_floats(True)
     out = m.compress(x.cuda())
     m.set_debug_floats(False)
     gsym, gidx = _symbols(m, 1)
-    clean, total = golden_parts_identical(gsym, gidx, {0: g["y_stream"].tobytes()}, gc, part_sizes(m.slice_ch, 16, 16),
+    clean, total = golden_parts_identical(gsym, gidx, {0: g["y_stream"].tobytes()}, gc, part_sizes(m.slice_ch, H // 16, W // 16),
                                           modalities=1)
     same = out["strings"][0][0] == g["y_stream"].tobytes() and out["strings"][1][0] == g["z0"].tobytes()
-    flip = {} if same else _first_flip(m, "elic_c1_256x256", gsym, gidx, medians=m.eb_medians_numpy(), mods=("r",))
+    flip = {} if same else _first_flip(m, "elic_" + case, gsym, gidx, medians=m.eb_medians_numpy(), mods=("r",))
     rec = m.decompress(out["strings"], out["shape"])
     vals = {"clean_parts_vs_golden": clean, "identical_streams": same,
             "dpsnr": abs(eo.psnr(rec["x_hat"].cpu().clamp(0, 1), x) - g["psnr"][0]),
             "dlen": abs(len(out["strings"][0][0]) - g["y_stream"].shape[0])}
     vals.update(flip)
-    print("elic single", vals)
-    _check("elic_c1_256x256", **vals)
+    print("elic single", case, vals)
+    _check("elic_" + case, **vals)
 
 
 def test_stf_vs_reference_golden(kat):
