@@ -151,20 +151,22 @@ def test_bicee_alone(codec, name):
     assert np.array_equal(yhat_r.numpy(), g["yhat_r"]) and np.array_equal(yhat_d.numpy(), g["yhat_d"])
 
 
-def test_single_modal_elic_config1():
-    """BASELINE config 1: single-modal ELIC (models/elic.py), one 256x256 RGB image, vs the reference's golden."""
+@pytest.mark.parametrize("case,seed", [("c1_256x256", 0), ("n_192x256_s8", 8)])
+def test_single_modal_elic_config1(case, seed):
+    """BASELINE config 1: single-modal ELIC (models/elic.py), one 256x256 RGB image, vs the reference's golden; n_192x256_s8 is
+    the held-out case of round 5 (size and seed chosen after the fact)."""
     import os
 
     from rgbd_amd import arch, synth
 
     entries = arch.elic_entries()
     assert len(entries) == 409 and arch.count_parameters(entries) == 36932427  # measured on the reference
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "elic_c1_256x256.npz"))
-    sd = synth.synthetic_state_dict(0, model="ELIC")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"elic_{case}.npz"))
+    sd = synth.synthetic_state_dict(seed, model="ELIC")
     orc = eo.OracleCodecSingle(sd)
     orc.update()
     assert np.array_equal(orc.eb.cdf, g["eb_cdf"])
-    r, _ = synth.synthetic_batch(1, 256, 256, config_id=1)
+    r, _ = synth.synthetic_batch(1, int(g["H"]), int(g["W"]), config_id=int(g["config_id"]))
     x = torch.from_numpy(r)
     orc.trace = {}
     out = orc.compress(x)
