@@ -244,12 +244,12 @@ def stf_case(model_config, synth, name, B, H, W, config_id):
     return g
 
 
-def r2d_case(model_config, synth, name, B, H, W, config_id):
+def r2d_case(model_config, synth, name, B, H, W, config_id, seed=0):
     """the reference's ELIC_united_R2D (models/elic_united_R2D.py) compress()/decompress()."""
     from models.elic_united_R2D import ELIC_united_R2D
 
     net = ELIC_united_R2D(config=model_config(), channel=4).eval()
-    net.load_state_dict(synth.synthetic_state_dict(0, model="ELIC_united_R2D"))
+    net.load_state_dict(synth.synthetic_state_dict(seed, model="ELIC_united_R2D"))
     assert net.update(force=True)
     r, d = synth.synthetic_batch(B, H, W, config_id=config_id)
     r, d = torch.from_numpy(r), torch.from_numpy(d)
@@ -304,6 +304,9 @@ def main():
         net.load_state_dict(synth.synthetic_state_dict(0, recipe="high_rate"))
         assert net.update(force=True)
         model_case(net, synth, "i_128x192_hr", 1, 128, 192, 41, False)
+        return
+    if "--only-r2d-heldout" in sys.argv:  # round 5: a held-out ELIC_united_R2D case (new size, new seed)
+        r2d_case(model_config, synth, "o_192x256_s9", 1, 192, 256, 17, seed=9)
         return
     if "--only-single-heldout" in sys.argv:  # round 5: a held-out single-modal case (new size, new seed; see make_margins.py j_ / k_ / l_ / m_)
         elic_single_case(ext, model_config, synth, "n_192x256_s8", 1, 192, 256, 16, seed=8)

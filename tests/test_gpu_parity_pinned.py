@@ -372,17 +372,20 @@ def test_bicee_vs_reference_golden(net, gc, name):
 
 
 # ---- the other model families ---------------------------------------------------------------------------------------------
-def test_r2d_vs_reference_golden(gc):
+@pytest.mark.parametrize("case,seed", [("128x192", 0), ("o_192x256_s9", 9)])
+def test_r2d_vs_reference_golden(gc, case, seed):
+    """o_192x256_s9 (round 5): the held-out case of this model family (tools/refarith/discover.py --add r2d:192:256:1)."""
     from rgbd_amd import synth
 
     require_gpu()
-    m = _model("ELIC_united_R2D", synth.synthetic_state_dict(0, model="ELIC_united_R2D"))
-    g = np.load(os.path.join(GOLDEN, "r2d_128x192.npz"))
-    r, d = synth.synthetic_batch(1, 128, 192, config_id=int(g["config_id"]))
+    m = _model("ELIC_united_R2D", synth.synthetic_state_dict(seed, model="ELIC_united_R2D"))
+    g = np.load(os.path.join(GOLDEN, f"r2d_{case}.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    r, d = synth.synthetic_batch(1, H, W, config_id=int(g["config_id"]))
     out = m.compress(torch.from_numpy(r).cuda(), torch.from_numpy(d).cuda())
     gsym, gidx = _symbols(m)
     clean, total = golden_parts_identical(gsym, gidx, {0: g["r_y"].tobytes(), 1: g["d_y"].tobytes()}, gc,
-                                          part_sizes(m.slice_ch, 8, 12))
+                                          part_sizes(m.slice_ch, H // 16, W // 16))
     same = (out["r_strings"][0][0] == g["r_y"].tobytes() and out["d_strings"][0][0] == g["d_y"].tobytes() and
             out["r_strings"][1][0] == g["r_z0"].tobytes() and out["d_strings"][1][0] == g["d_z0"].tobytes())
     rec = m.decompress(out["r_strings"], out["d_strings"], out["shape"])
@@ -390,8 +393,8 @@ def test_r2d_vs_reference_golden(gc):
     vals = {"clean_parts_vs_golden": clean, "identical_streams": same,
             "dpsnr_r": abs(eo.psnr(xr, torch.from_numpy(r)) - g["psnr"][0]),
             "dpsnr_d": abs(eo.psnr(xd, torch.from_numpy(d)) - g["psnr"][1])}
-    print("r2d", vals)
-    _check("r2d_128x192", **vals)
+    print("r2d", case, vals)
+    _check("r2d_" + case, **vals)
 
 
 @pytest.mark.parametrize("case,seed", [("c1_256x256", 0), ("n_192x256_s8", 8)])
