@@ -214,6 +214,8 @@ def main():
         united_case(ELIC, model_config, synth, "l_b2_192x256_s5", 2, 192, 256, 14, seed=5, new=True)
     if "m_256x320_smooth_s7" in want:  # fourth held-out case: spatially correlated images (every other golden codes uniform noise)
         united_case(ELIC, model_config, synth, "m_256x320_smooth_s7", 1, 256, 320, 15, seed=7, new=True, smooth=True)
+    if "p_480x640_s10" in want:  # held-out at the bench's own image shape: another weight seed (10) and other images
+        united_case(ELIC, model_config, synth, "p_480x640_s10", 1, 480, 640, 18, seed=10, new=True)
     if "k_200x300_tl_s4" in want:  # a second held-out case: a size that needs padding (-> 256 x 320), trained-like weights, seed 4
         united_case(ELIC, model_config, synth, "k_200x300_tl_s4", 1, 200, 300, 13, seed=4, recipe="trained_like", new=True)
     if on("i_128x192_hr"):  # the high_rate weights (wide CDF rows); golden from make_golden.py --only-hr

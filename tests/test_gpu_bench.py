@@ -56,7 +56,7 @@ def test_single_rank_line_has_the_contract_fields():
     sus = r["sustained"]
     assert sus["steps"] == 24 and len(sus["ms_per_step_by_round"]) == 3 and sus["value"] > 0.5 * r["value"]
     par = r["parity"]
-    assert par["of"] == 20 and 0 < par["goldens_identical"] <= 20 and "f_480x640_stress" in par["operating_point"]
+    assert par["of"] == 21 and 0 < par["goldens_identical"] <= 21 and "f_480x640_stress" in par["operating_point"]
     assert "BATCH THROUGHPUT" in r["vs_cpu"]["note"]
 
 

@@ -289,14 +289,15 @@ def test_elic_united_vs_reference_golden(net, gc, name):
 
 @pytest.mark.parametrize("name,seed,recipe", [("g_256x256_s1", 1, None), ("h_256x256_s2", 2, None), ("j_192x256_s3", 3, None),
                                               ("k_200x300_tl_s4", 4, "trained_like"), ("l_b2_192x256_s5", 5, None),
-                                              ("m_256x320_smooth_s7", 7, None)])
+                                              ("m_256x320_smooth_s7", 7, None), ("p_480x640_s10", 10, None)])
 def test_elic_united_other_weight_seeds_vs_reference_golden(gc, name, seed, recipe):
     """The flip census seeds (profiles/r02_flip_census.json was against the box's oracle) against the reference itself.
     j_192x256_s3 and k_200x300_tl_s4 (round 5) are HELD-OUT cases: image sizes (the second one needs padding, -> 256 x 320, and
     runs the trained-like weights) and weight seeds nothing had seen when the reference-arithmetic path was written; only their
     layer shapes were measured afterwards (tools/refarith/discover.py --add united:H:W:B).  l_b2_192x256_s5 is the reference's
     batched calling convention (one stream per batch of two) at a held-out size and seed; m_256x320_smooth_s7 codes spatially
-    correlated images (every other golden codes uniform noise)."""
+    correlated images (every other golden codes uniform noise); p_480x640_s10 is the bench's own image shape with another
+    weight seed and other images."""
     from rgbd_amd import synth
 
     require_gpu()
