@@ -9,8 +9,10 @@
 One step = compress() + decompress() of one batch of synthetic RGB-D pairs per rank.  The default workload is BASELINE
 config 3's per-GPU share: 4 pairs of 480x640 (replicate-padded to 512x640) per GPU and step, so `--gpus 8` codes config
 3's 32 images per step (weak scaling: every rank codes its own images; no collective on the data path, only the
-all-gather of the finished streams).  Inputs are resident in HBM before the timed region; conv profiling (HIP events)
-runs in a separate pass after it.  Rank 0 prints ONE JSON line:
+all-gather of the finished streams).  An engine call codes `--steps-per-call` steps together (default 4 for c3 and c2: the
+driver's 20 steps are 5 calls of 16 images on 5 engine instances -- same images in flight as 20 instances of 4, faster
+kernels; streams are per image and the kernels batch-invariant, so no output bit depends on it).  Inputs are resident in
+HBM before the timed region; conv profiling (HIP events) runs in a separate pass after it.  Rank 0 prints ONE JSON line:
 
   value / ms_per_step   wall-clock job throughput with W engine instances in flight per GPU (`engine_instances`)
   latency               the reference tester's calling pattern (testing/tester_united.py:142-147,180-186): B=1, one engine
@@ -18,7 +20,9 @@ runs in a separate pass after it.  Rank 0 prints ONE JSON line:
                         (sum(enc) + sum(dec))  -- SURVEY.md 8(d)'s metric definition
   cpu_baseline          the CPU oracle at the same B=1 semantics on this box's host cores; `vs_cpu` holds both ratios
   workloads             the same throughput figure for the secondary workload (c2: 8 x 256x256)
-  roofline              conv kernel (fp32 MFMA): job-level achieved FLOP/s, and `isolated` = one engine instance alone
+  roofline              conv kernel (fp32 MFMA): job-level achieved FLOP/s (algorithmic FLOPs of the reference's layers; `executed_frac`
+                        = what the launches compute), `isolated` = one engine instance alone, `hbm` = PMC bytes of the conv launches,
+                        `entropy` = the entropy stage (rANS ns per symbol on the model's own symbols, checkerboard pass GB/s)
   sustained             three more rounds on the same engine instances right after the headline (60 steps at --steps 20)
   parity                the parity state the numbers were measured under (tests/golden/parity_floors.json: how many reference
                         goldens are bit-identical, the largest dbpp / dPSNR, the state at the bench's own operating point)
