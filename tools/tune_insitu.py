@@ -8,8 +8,9 @@ around every conv launch of one engine instance, rgbd_elic_set_profile(m, 2): na
 time under that candidate, so ~25 passes cover 25 candidates for all shapes at once.  Candidates are filtered first by one
 kernel-only launch (rgbd_conv_bench) so that a pass never meets a form a shape cannot take.  Tile choice never changes a result.
 
-    python tools/tune_insitu.py [--write] [--latency] B H W   (default 16 512 640; writes gpurun_out/insitu_*.h, --write: csrc/;
-                                                             --latency: the tables a lone engine instance uses, tile_table[_blk].h)
+    python tools/tune_insitu.py [--write] [--latency] [--model STF_united] B H W
+           (default 16 512 640, ELIC_united; writes gpurun_out/insitu_*.h, --write: csrc/; --latency: the tables a lone engine
+            instance uses, tile_table[_blk].h)
 """
 import collections
 import ctypes
@@ -24,14 +25,15 @@ import rgbd_amd  # noqa: E402
 from rgbd_amd import ELIC_united, synth  # noqa: E402
 from rgbd_amd._lib import lib  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+MODEL = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else "ELIC_united"
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--model"]
 B, H, W = (int(v) for v in args[:3]) if len(args) >= 3 else (16, 512, 640)
 WRITE = "--write" in sys.argv
 LATENCY = "--latency" in sys.argv
 REPS = 3
 L = lib()
-net = ELIC_united(config=rgbd_amd.model_config(), channel=4).eval()
-net.load_state_dict(synth.synthetic_state_dict(0))
+net = rgbd_amd.modelZoo[MODEL](config=rgbd_amd.model_config(), channel=4).eval()
+net.load_state_dict(synth.synthetic_state_dict(0, model=MODEL) if MODEL != "ELIC_united" else synth.synthetic_state_dict(0))
 net.update(force=True)
 net = net.to("cuda")
 net.per_image_streams = True
@@ -147,7 +149,7 @@ for blocked, fname in ((True, "tile_table_blk.h" if LATENCY else "tile_table_blk
         key = tuple(int(v) for v in ks.split(","))
         if (key[7] >= 100) == blocked:
             table[key] = c
-    note = f"// + in-situ winners of tools/tune_insitu.py {B} {H} {W} (timed inside the codec call, one engine instance)"
+    note = f"// + in-situ winners of tools/tune_insitu.py {B} {H} {W} {MODEL if MODEL != 'ELIC_united' else ''} (timed inside the codec call, one engine instance)".replace("  (", " (")
     if note not in head:
         head.append(note)
     with open(os.path.join(out_dir, ("" if WRITE else "insitu_") + fname), "w") as f:
